@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by running the REFERENCE (imported from /root/reference).
+
+TEST INFRASTRUCTURE.  Runs only in the build container: the reference does not
+travel to the GPU box, so when /root/reference is missing this script says so
+and leaves the committed fixtures alone.
+
+Import recipe: ``model.py:7`` imports ``utils`` whose
+top level does ``from librosa.filters import mel`` (utils.py:5; used only by
+make_spect_f0.py).  librosa is not installed here, so an empty module object is
+registered under that name before the import.  Nothing of the reference is
+copied: fixtures hold inputs, seeds and the reference's numeric outputs.
+"""
+import json
+import os
+import pickle
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+
+from oracle import weights as W          # noqa: E402
+from oracle import interp_np             # noqa: E402
+
+
+def import_reference():
+    if not os.path.isdir(REF):
+        return None
+    lib = types.ModuleType('librosa')
+    filt = types.ModuleType('librosa.filters')
+    filt.mel = None
+    lib.filters = filt
+    sys.modules.setdefault('librosa', lib)
+    sys.modules.setdefault('librosa.filters', filt)
+    sys.path.insert(0, REF)
+    import model as ref_model            # noqa
+    import utils as ref_utils            # noqa
+    return ref_model, ref_utils
+
+
+def draws_for(seed, B, ncalls, lo=19, hi=32, nseg=7):
+    """Replays the reference's RNG consumption (model.py:392-393 then 399-402, per call)."""
+    torch.manual_seed(seed)
+    out = []
+    for _ in range(ncalls):
+        sc = torch.rand(B * nseg) + 0.5
+        ls = torch.randint(low=lo, high=hi, size=(B * nseg, 1))
+        out.append((sc.numpy().copy(), ls.numpy().reshape(-1).copy()))
+    return out
+
+
+def tensor_stats(t):
+    a = t.detach().double().reshape(-1)
+    n = a.numel()
+    pos = np.unique(np.linspace(0, n - 1, 8).astype(np.int64))
+    return dict(sum=float(a.sum()), l2=float(a.norm()), amax=float(a.abs().max()),
+                pos=pos.tolist(), val=[float(a[p]) for p in pos])
+
+
+def synth_batch(seed, B, T, len_lo=64):
+    """Synthetic batch as SURVEY.md section 8(d) / BASELINE.md section 4 describes it."""
+    g = torch.Generator().manual_seed(seed)
+    mel = torch.rand(B, T, 80, generator=g)
+    f0 = torch.rand(B, T, 1, generator=g)
+    uv = torch.rand(B, T, 1, generator=g) < 0.4
+    lens = torch.randint(len_lo, T + 1, (B,), generator=g)
+    tt = torch.arange(T)[None, :, None]
+    pad = tt >= lens[:, None, None]
+    f0 = torch.where(uv | pad, torch.full_like(f0, -1e10), f0)
+    mel = torch.where(pad, torch.zeros_like(mel), mel)
+    spk = torch.randint(0, 82, (B,), generator=g)
+    emb = torch.nn.functional.one_hot(spk, 82).float()
+    return mel, f0, emb, lens
+
+
+def main():
+    mods = import_reference()
+    if mods is None:
+        print('gen_fixtures: /root/reference not present; committed fixtures are kept as they are')
+        return 0
+    ref_model, ref_utils = mods
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+
+    # ---------------------------------------------------------------- F0: state_dict keys
+    for kind, cls in (('G3', ref_model.Generator_3), ('G6', ref_model.Generator_6)):
+        hp = W.default_hparams()
+        m = cls(hp)
+        sd = m.state_dict()
+        named = [n for n, _ in m.named_parameters()]
+        json.dump(dict(keys=list(sd.keys()), shapes=[list(v.shape) for v in sd.values()],
+                       params=named, numel=int(sum(p.numel() for p in m.parameters()))),
+                  open(os.path.join(GOLD, f'keys_{kind}.json'), 'w'), indent=0)
+
+    # ---------------------------------------------------------------- F3: InterpLnr
+    cases = []
+    for ci, (B, T, C, pad, lens, seed) in enumerate([
+            (3, 128, 5, 128, [64, 100, 128], 11),
+            (4, 192, 81, 192, [96, 135, 160, 192], 12),
+            (2, 192, 7, 192, [192, 192], 13),
+            (2, 128, 6, 128, [128, 128], 14),          # encoder-style call: len = max_len_pad
+            (5, 128, 3, 128, [64, 65, 127, 128, 90], 15),
+            (16, 128, 4, 128, [128] * 16, 16)]):
+        hp = W.default_hparams(max_len_pad=pad)
+        mod = ref_model.InterpLnr(hp).train()
+        x = torch.randn(B, T, C, generator=torch.Generator().manual_seed(100 + ci))
+        ls = torch.tensor(lens)
+        torch.manual_seed(seed)
+        y = mod(x, ls)
+        (sc, sg), = draws_for(seed, B, 1)
+        cases.append(dict(x=x.numpy(), len_seq=np.array(lens), scales=sc, len_seg=sg, y=y.numpy(),
+                          max_len_pad=np.int64(pad)))
+    flat = {}
+    for i, c in enumerate(cases):
+        for k, v in c.items():
+            flat[f'c{i}_{k}'] = v
+    flat['n'] = np.int64(len(cases))
+    np.savez_compressed(os.path.join(GOLD, 'interp.npz'), **flat)
+
+    # ---------------------------------------------------------------- quantiser
+    xq = torch.rand(4, 64, generator=torch.Generator().manual_seed(5))
+    xq[xq < 0.3] = -1e10
+    xq[0, :8] = torch.tensor([0.0, 1.0, 0.5, 1.5 / 255, 2.5 / 255, 0.5 / 255, 254.5 / 255, 3.5 / 255])
+    enc, idx = ref_utils.quantize_f0_torch(xq)
+    np.savez_compressed(os.path.join(GOLD, 'quantize.npz'), x=xq.numpy(), idx=idx.numpy(),
+                        onehot_argmax=enc.argmax(-1).numpy(), onehot_sum=enc.sum(-1).numpy())
+
+    # ---------------------------------------------------------------- F2: blocks (small, full tensors)
+    hp = W.default_hparams()
+    w3 = W.make_weights('G3', hp, seed=3)
+    G = ref_model.Generator_3(hp)
+    G.load_state_dict({**{k: torch.from_numpy(v) for k, v in w3.items()},
+                       'encoder_1.len_org': torch.tensor(hp.max_len_pad)})
+    blocks = {}
+    g = torch.Generator().manual_seed(21)
+    # conv block 80 -> 128 (Encoder_t's), fwd + input/weight grads
+    x = torch.randn(2, 80, 40, generator=g, requires_grad=True)
+    blk = G.encoder_2.convolutions[0]
+    y = torch.relu(blk(x))
+    gy = torch.randn(y.shape, generator=g)
+    G.zero_grad()
+    y.backward(gy)
+    blocks.update(conv_x=x.detach().numpy(), conv_y=y.detach().numpy(), conv_gy=gy.numpy(),
+                  conv_gx=x.grad.numpy(), conv_gw=blk[0].conv.weight.grad.numpy(),
+                  conv_gb=blk[0].conv.bias.grad.numpy(), conv_ggamma=blk[1].weight.grad.numpy(),
+                  conv_gbeta=blk[1].bias.grad.numpy())
+    # LSTMs of every shape on the path: outputs + input grads
+    for name, mod, cin, T in (('lstm_t', G.encoder_2.lstm, 128, 24), ('lstm_1', G.encoder_1.lstm_1, 512, 24),
+                              ('lstm_2', G.encoder_1.lstm_2, 256, 24), ('lstm_d', G.decoder.lstm, 164, 16)):
+        x = torch.randn(2, T, cin, generator=g, requires_grad=True)
+        y = mod(x)[0]
+        gy = torch.randn(y.shape, generator=g)
+        G.zero_grad()
+        y.backward(gy)
+        blocks.update({f'{name}_x': x.detach().numpy(), f'{name}_y': y.detach().numpy(), f'{name}_gy': gy.numpy(),
+                       f'{name}_gx': x.grad.numpy(),
+                       f'{name}_gwhh0': mod.weight_hh_l0.grad.numpy()[:96, :96].copy(),   # top-left corner only
+
+                       f'{name}_gbih0r': mod.bias_ih_l0_reverse.grad.numpy().copy()})
+    np.savez_compressed(os.path.join(GOLD, 'blocks.npz'), **blocks)
+
+    # ---------------------------------------------------------------- F1: demo.pkl, config 1 (eval, B=1, T=192)
+    demo = pickle.load(open(os.path.join(REF, 'assets', 'demo.pkl'), 'rb'))
+    w6 = W.make_weights('G6', hp, seed=4)
+    P6 = ref_model.Generator_6(hp)
+    P6.load_state_dict({**{k: torch.from_numpy(v) for k, v in w6.items()},
+                        'encoder_3.len_org': torch.tensor(hp.max_len_pad)})
+    G.eval()
+    P6.eval()
+    d = {}
+    for n, ent in enumerate(demo):
+        emb = torch.from_numpy(ent[1])
+        mel, f0, L = ent[2][0], ent[2][1], ent[2][2]
+        mel_pad, _ = ref_utils.pad_seq_to_2(mel[np.newaxis, :, :], 192)          # solver.py:213
+        f0_pad = np.pad(f0, (0, 192 - L), 'constant', constant_values=(0, 0))    # :215
+        onehot, qidx = ref_utils.quantize_f0_numpy(f0_pad)                       # :216
+        x_real = torch.from_numpy(mel_pad)
+        x_f0 = torch.cat((x_real, torch.from_numpy(onehot[np.newaxis])), -1)
+        with torch.no_grad():
+            out3 = G(x_f0, x_real, emb)
+            rhythm = G.rhythm(x_real)
+            out6 = P6(x_real, torch.from_numpy(onehot[np.newaxis]))
+        d.update({f'u{n}_mel_pad': mel_pad.astype(np.float32), f'u{n}_f0_pad': f0_pad.astype(np.float32),
+                  f'u{n}_qidx': qidx.astype(np.int16), f'u{n}_emb': ent[1], f'u{n}_len': np.int64(L),
+                  f'u{n}_out3': out3.numpy(), f'u{n}_rhythm': rhythm.numpy(),
+                  f'u{n}_out6': out6.numpy().astype(np.float32)})
+    d['seed_g3'] = np.int64(3)
+    d['seed_g6'] = np.int64(4)
+    np.savez_compressed(os.path.join(GOLD, 'demo_config1.npz'), **d)
+
+    # ---------------------------------------------------------------- F4/F5: full train steps (stats + output)
+    steps = {}
+    for tag, B, T, wseed, bseed, dseed, nsteps in (('b2_t128', 2, 128, 3, 31, 41, 3), ('b2_t192', 2, 192, 3, 32, 42, 1),
+                                                   ('b8_t128', 8, 128, 3, 33, 43, 1)):
+        hp = W.default_hparams(max_len_pad=T)
+        w = W.make_weights('G3', hp, wseed)
+        M = ref_model.Generator_3(hp)
+        M.load_state_dict({**{k: torch.from_numpy(v) for k, v in w.items()},
+                           'encoder_1.len_org': torch.tensor(T)})
+        I = ref_model.InterpLnr(hp)
+        opt = torch.optim.Adam(M.parameters(), 1e-4, [0.9, 0.999])                # solver.py:62
+        mel, f0, emb, lens = synth_batch(bseed, B, T, 64 if T == 128 else 96)
+        rec = dict(B=B, T=T, wseed=wseed, bseed=bseed, dseed=dseed, losses=[])
+        torch.manual_seed(dseed)
+        for it in range(nsteps):
+            M.train()
+            x_f0 = torch.cat((mel, f0), -1)                                       # solver.py:160
+            xi = I(x_f0, lens)                                                    # :161
+            q = ref_utils.quantize_f0_torch(xi[:, :, -1])[0]                      # :162
+            x_in = torch.cat((xi[:, :, :-1], q), -1)                              # :163
+            out = M(x_in, mel, emb)                                               # :165
+            loss = torch.nn.functional.mse_loss(mel, out, reduction='mean')       # :166
+            opt.zero_grad()
+            loss.backward()
+            if it == 0:
+                rec['grads'] = {n: tensor_stats(p.grad) for n, p in M.named_parameters()}
+                np.save(os.path.join(GOLD, f'train_{tag}_out.npy'), out.detach().numpy())
+                np.save(os.path.join(GOLD, f'train_{tag}_xin_f0idx.npy'),
+                        x_in[:, :, 80:].argmax(-1).numpy().astype(np.int16))
+                np.save(os.path.join(GOLD, f'train_{tag}_xin_mel.npy'), x_in[:, :, :80].detach().numpy())
+            opt.step()
+            if it == 0:
+                rec['params_after'] = {n: tensor_stats(p) for n, p in M.named_parameters()}
+            rec['losses'].append(float(loss.detach()))
+        steps[tag] = rec
+    json.dump(steps, open(os.path.join(GOLD, 'train_steps.json'), 'w'))
+
+    # ---------------------------------------------------------------- Generator_6 train-mode forward (+ CE grads)
+    hp = W.default_hparams(max_len_pad=192)
+    mel, f0, emb, lens = synth_batch(51, 2, 192, 96)
+    qidx = torch.from_numpy(interp_np.quantize_f0(f0[:, :, 0].numpy()))
+    onehot = torch.nn.functional.one_hot(qidx, 257).float()
+    P6.train()
+    torch.manual_seed(61)
+    logits = P6(mel, onehot)
+    ce = torch.nn.functional.cross_entropy(logits.reshape(-1, 257), qidx.reshape(-1))
+    P6.zero_grad()
+    ce.backward()
+    json.dump(dict(B=2, T=192, wseed=4, bseed=51, dseed=61, loss=float(ce),
+                   grads={n: tensor_stats(p.grad) for n, p in P6.named_parameters()}),
+              open(os.path.join(GOLD, 'g6_train.json'), 'w'))
+    np.save(os.path.join(GOLD, 'g6_train_logits.npy'), logits.detach().numpy())
+
+    # ---------------------------------------------------------------- reference-init statistics (for the init mirror)
+    torch.manual_seed(0)
+    M0 = ref_model.Generator_3(W.default_hparams())
+    json.dump({n: tensor_stats(p) for n, p in M0.named_parameters()},
+              open(os.path.join(GOLD, 'init_seed0_G3.json'), 'w'))
+    print('fixtures written to', GOLD)
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

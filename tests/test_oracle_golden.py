@@ -1,0 +1,194 @@
+"""Pins the CPU oracle (oracle/) against vectors produced by the imported reference
+(oracle/gen_fixtures.py -> tests/golden).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import interp_np, ref_model, weights as W
+
+torch.set_num_threads(4)
+
+
+def _rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def _stats(t):
+    a = t.detach().double().reshape(-1)
+    return float(a.sum()), float(a.norm())
+
+
+@pytest.mark.parametrize('kind', ['G3', 'G6'])
+def test_param_table_matches_reference_state_dict(gold_dir, kind):
+    ref = json.load(open(os.path.join(gold_dir, f'keys_{kind}.json')))
+    spec = W.param_spec(kind, W.default_hparams())
+    assert [n for n, _ in spec] == ref['params']
+    shapes = dict(zip(ref['keys'], ref['shapes']))
+    for n, s in spec:
+        assert list(s) == shapes[n], n
+    assert sum(int(np.prod(s)) for _, s in spec) == ref['numel']
+    assert [k for k in ref['keys'] if k not in dict(spec)] == W.buffer_spec(kind)
+    assert ref['numel'] == (19437800 if kind == 'G3' else 3485849)
+
+
+def test_interp_bit_exact(gold_dir):
+    z = np.load(os.path.join(gold_dir, 'interp.npz'))
+    for i in range(int(z['n'])):
+        pad = int(z[f'c{i}_max_len_pad'])
+        y = interp_np.interp_forward(z[f'c{i}_x'], z[f'c{i}_len_seq'], z[f'c{i}_scales'], z[f'c{i}_len_seg'],
+                                     max_len_pad=pad)
+        ref = z[f'c{i}_y']
+        assert y.shape == ref.shape
+        assert np.array_equal(y, ref), f'case {i}: max diff {np.abs(y - ref).max()}'
+        # torch flavour used inside the model oracle
+        hp = W.default_hparams(max_len_pad=pad)
+        yt = ref_model.interp(torch.from_numpy(z[f'c{i}_x']), z[f'c{i}_len_seq'],
+                              (z[f'c{i}_scales'], z[f'c{i}_len_seg']), hp).numpy()
+        assert np.array_equal(yt, ref)
+
+
+def test_interp_truncation_case_present(gold_dir):
+    z = np.load(os.path.join(gold_dir, 'interp.npz'))
+    seen = False
+    for i in range(int(z['n'])):
+        pad = int(z[f'c{i}_max_len_pad'])
+        _, _, counts, nrows = interp_np.interp_plan(z[f'c{i}_scales'], z[f'c{i}_len_seg'], z[f'c{i}_len_seq'],
+                                                    max_len_pad=pad)
+        seen |= bool((counts > pad).any())
+        assert (nrows <= pad).all()
+    assert seen, 'fixtures should include count > max_len_pad'
+
+
+def test_interp_backward_is_adjoint():
+    rs = np.random.RandomState(0)
+    B, T, C = 3, 128, 5
+    x = rs.randn(B, T, C).astype(np.float32)
+    sc = (rs.rand(B * 7) + 0.5).astype(np.float32)
+    sg = rs.randint(19, 32, B * 7)
+    i0, lam, _, nrows = interp_np.interp_plan(sc, sg, [128, 100, 64], max_len_pad=128)
+    y = interp_np.interp_apply(x, i0, lam, nrows)
+    dy = rs.randn(*y.shape).astype(np.float32)
+    dx = interp_np.interp_backward(dy, i0, lam, nrows, T)
+    assert abs(float((y.astype(np.float64) * dy).sum()) - float((x.astype(np.float64) * dx).sum())) < 1e-3
+
+
+def test_quantize(gold_dir):
+    z = np.load(os.path.join(gold_dir, 'quantize.npz'))
+    idx = interp_np.quantize_f0(z['x'])
+    assert np.array_equal(idx, z['idx'])
+    assert np.array_equal(idx, z['onehot_argmax'])
+    assert (z['onehot_sum'] == 1).all()
+    oh = interp_np.onehot(idx)
+    assert oh.shape[-1] == 257 and (oh.sum(-1) == 1).all()
+
+
+def test_blocks(gold_dir):
+    z = np.load(os.path.join(gold_dir, 'blocks.npz'))
+    hp = W.default_hparams()
+    P = ref_model.as_params(W.make_weights('G3', hp, 3))
+    x = torch.from_numpy(z['conv_x']).requires_grad_(True)
+    y = ref_model.conv_gn_relu(x, P, 'encoder_2.convolutions.0')
+    assert _rel(y.detach().numpy(), z['conv_y']) < 1e-6
+    y.backward(torch.from_numpy(z['conv_gy']))
+    assert _rel(x.grad.numpy(), z['conv_gx']) < 1e-5
+    assert _rel(P['encoder_2.convolutions.0.0.conv.weight'].grad.numpy(), z['conv_gw']) < 1e-5
+    assert _rel(P['encoder_2.convolutions.0.0.conv.bias'].grad.numpy(), z['conv_gb']) < 1e-5
+    assert _rel(P['encoder_2.convolutions.0.1.weight'].grad.numpy(), z['conv_ggamma']) < 1e-5
+    assert _rel(P['encoder_2.convolutions.0.1.bias'].grad.numpy(), z['conv_gbeta']) < 1e-5
+    for name, prefix, layers in (('lstm_t', 'encoder_2.lstm', 1), ('lstm_1', 'encoder_1.lstm_1', 2),
+                                 ('lstm_2', 'encoder_1.lstm_2', 1), ('lstm_d', 'decoder.lstm', 3)):
+        for fn in (ref_model.blstm, ref_model.lstm_explicit):
+            for p in P.values():
+                p.grad = None
+            x = torch.from_numpy(z[f'{name}_x']).requires_grad_(True)
+            y = fn(x, P, prefix, layers)
+            assert _rel(y.detach().numpy(), z[f'{name}_y']) < 2e-6, (name, fn.__name__)
+            y.backward(torch.from_numpy(z[f'{name}_gy']))
+            assert _rel(x.grad.numpy(), z[f'{name}_gx']) < 1e-5, (name, fn.__name__)
+            assert _rel(P[prefix + '.weight_hh_l0'].grad.numpy()[:96, :96], z[f'{name}_gwhh0']) < 1e-5
+            assert _rel(P[prefix + '.bias_ih_l0_reverse'].grad.numpy(), z[f'{name}_gbih0r']) < 1e-5
+
+
+def test_demo_config1(gold_dir):
+    """BASELINE config 1: demo.pkl utterances, eval forward (solver.py:206-221, demo.ipynb cell 0)."""
+    z = np.load(os.path.join(gold_dir, 'demo_config1.npz'))
+    hp = W.default_hparams()
+    P3 = ref_model.as_params(W.make_weights('G3', hp, int(z['seed_g3'])), False)
+    P6 = ref_model.as_params(W.make_weights('G6', hp, int(z['seed_g6'])), False)
+    for n in range(2):
+        mel = torch.from_numpy(z[f'u{n}_mel_pad'])
+        qidx = interp_np.quantize_f0(z[f'u{n}_f0_pad'])
+        assert np.array_equal(qidx, z[f'u{n}_qidx'].astype(np.int64))
+        onehot = torch.from_numpy(interp_np.onehot(qidx))[None]
+        emb = torch.from_numpy(z[f'u{n}_emb'])
+        with torch.no_grad():
+            out3 = ref_model.generator_3(P3, hp, torch.cat((mel, onehot), -1), mel, emb)
+            rhythm = ref_model.encoder_t(mel.transpose(2, 1), P3, hp)
+            out6 = ref_model.generator_6(P6, hp, mel, onehot)
+        assert out3.shape == (1, 192, 80) and out6.shape == (1, 192, 257)
+        assert _rel(out3.numpy(), z[f'u{n}_out3']) < 1e-6
+        assert _rel(rhythm.numpy(), z[f'u{n}_rhythm']) < 1e-6
+        assert _rel(out6.numpy(), z[f'u{n}_out6']) < 1e-6
+
+
+def _synth(seed, B, T, lo):
+    from oracle.gen_fixtures import synth_batch
+    return synth_batch(seed, B, T, lo)
+
+
+def _draws(seed, B, n):
+    from oracle.gen_fixtures import draws_for
+    return draws_for(seed, B, n)
+
+
+@pytest.mark.parametrize('tag', ['b2_t128', 'b2_t192'])
+def test_train_step(gold_dir, tag):
+    rec = json.load(open(os.path.join(gold_dir, 'train_steps.json')))[tag]
+    B, T = rec['B'], rec['T']
+    hp = W.default_hparams(max_len_pad=T)
+    st = ref_model.TrainState(W.make_weights('G3', hp, rec['wseed']))
+    mel, f0, emb, lens = _synth(rec['bseed'], B, T, 64 if T == 128 else 96)
+    nsteps = len(rec['losses'])
+    draws = _draws(rec['dseed'], B, 4 * nsteps)
+    for it in range(nsteps):
+        loss, out = ref_model.g3_loss(st.P, hp, mel, f0, emb, lens.numpy(), draws[4 * it:4 * it + 4])
+        st.opt.zero_grad()
+        loss.backward()
+        if it == 0:
+            assert _rel(out.detach().numpy(), np.load(os.path.join(gold_dir, f'train_{tag}_out.npy'))) < 1e-5
+            for n, s in rec['grads'].items():
+                g = st.P[n].grad
+                gs, gl = _stats(g)
+                assert abs(gl - s['l2']) <= 1e-4 * s['l2'] + 1e-12, n
+                flat = g.reshape(-1)
+                for p, v in zip(s['pos'], s['val']):
+                    assert abs(float(flat[p]) - v) <= 1e-4 * s['amax'] + 1e-12, (n, p)
+        st.opt.step()
+        if it == 0:
+            for n, s in rec['params_after'].items():
+                flat = st.P[n].detach().reshape(-1)
+                for p, v in zip(s['pos'], s['val']):
+                    assert abs(float(flat[p]) - v) <= 1e-6 * s['amax'] + 1e-9, (n, p)
+        assert abs(float(loss) - rec['losses'][it]) <= 1e-5 * abs(rec['losses'][it]), it
+
+
+def test_g6_train_forward_and_ce(gold_dir):
+    rec = json.load(open(os.path.join(gold_dir, 'g6_train.json')))
+    hp = W.default_hparams(max_len_pad=rec['T'])
+    P = ref_model.as_params(W.make_weights('G6', hp, rec['wseed']))
+    mel, f0, emb, lens = _synth(rec['bseed'], rec['B'], rec['T'], 96)
+    qidx = torch.from_numpy(interp_np.quantize_f0(f0[:, :, 0].numpy()))
+    onehot = torch.nn.functional.one_hot(qidx, 257).float()
+    draws = _draws(rec['dseed'], rec['B'], 3)
+    loss, logits = ref_model.g6_loss(P, hp, mel, onehot, qidx, draws)
+    assert _rel(logits.detach().numpy(), np.load(os.path.join(gold_dir, 'g6_train_logits.npy'))) < 1e-5
+    assert abs(float(loss) - rec['loss']) < 1e-5 * rec['loss']
+    loss.backward()
+    for n, s in rec['grads'].items():
+        gl = float(P[n].grad.double().norm())
+        assert abs(gl - s['l2']) <= 1e-4 * s['l2'] + 1e-12, n
