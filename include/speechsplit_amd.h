@@ -1,0 +1,112 @@
+/* speechsplit_amd.h -- C ABI of the MI355X (gfx950) SpeechSplit engine.
+ *
+ * The reference (biggytruck/SpeechSplit) is pure PyTorch and has no FFI of its own; the
+ * boundary a maintainer binds is therefore derived from what its Python surface needs.  Each entry point names
+ * the reference statement(s) it replaces.  Conventions:
+ *   - plain C types only; every pointer marked "dev" is caller-owned device memory (e.g. tensor.data_ptr());
+ *     the engine never frees caller memory and allocates nothing after ss_bind;
+ *   - every call is asynchronous on the hipStream_t passed as `stream` (void*; NULL = default stream);
+ *   - return value 0 = ok, negative = error, text via ss_last_error() (no C++ exceptions cross the ABI);
+ *   - one engine per device per process; an engine is not thread-safe;
+ *   - tensors are contiguous fp32, batch-first [B, T, C] exactly as the reference passes them (model.py:297,337);
+ *   - T must be a multiple of the code down-sampling factor 8 (model.py:87,223-227) and <= max_frames;
+ *   - the random-resampling draws of InterpLnr (model.py:392-393 rand(B*7)+0.5; :399-402 randint) are INPUTS:
+ *     `scales` f32 and `len_seg` i32, one [B*7] row per InterpLnr call in call order.  Given equal draws the
+ *     index path is bit-exact against the reference.
+ */
+#ifndef SPEECHSPLIT_AMD_H
+#define SPEECHSPLIT_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ss_engine ss_engine;
+
+/* reference hparams.py:9-32 (only the values the hot path reads) */
+typedef struct ss_hparams {
+    int freq, dim_neck, freq_2, dim_neck_2, freq_3, dim_neck_3;
+    int dim_enc, dim_enc_2, dim_enc_3, dim_freq, dim_spk_emb, dim_f0, chs_grp;
+    int min_len_seg, max_len_seg, max_len_seq, max_len_pad;
+} ss_hparams;
+
+#define SS_GENERATOR_3 3 /* model.py:283 Generator_3 = Encoder_7 | Encoder_t | Decoder_3 */
+#define SS_GENERATOR_6 6 /* model.py:324 Generator_6 = Encoder_t | Encoder_6 | Decoder_4 */
+
+#define SS_STEP_NO_ADAM 1 /* ss_*_train_step: stop after backward (data-parallel: all-reduce grads, then ss_adam_step) */
+
+const char* ss_last_error(void);
+int ss_abi_version(void);
+
+/* model.py:285-295 / 327-334 (constructor).  No device memory is touched until ss_bind. */
+ss_engine* ss_create(int kind, const ss_hparams* hp, int max_batch, int max_frames);
+void ss_destroy(ss_engine* e);
+
+/* state_dict() table, reference key names and shapes, in parameters() order.
+ * `offset` is in floats into each of the four arenas (params / grads / Adam m / Adam v). */
+int ss_num_params(const ss_engine* e);
+int ss_param_info(const ss_engine* e, int index, char* name, int name_cap, long* offset, int* ndim, long shape[3]);
+long ss_arena_numel(const ss_engine* e);     /* floats per arena, alignment gaps included */
+long ss_workspace_bytes(const ss_engine* e); /* activation workspace for (max_batch, max_frames) */
+
+/* .to(device) (solver.py:65): adopt caller-allocated device memory.  All four arenas hold ss_arena_numel floats.
+ * The workspace is zero-filled here. */
+int ss_bind(ss_engine* e, float* params_dev, float* grads_dev, float* adam_m_dev, float* adam_v_dev, void* workspace_dev,
+            long workspace_bytes, void* stream);
+
+/* ---- Generator_3 (model.py:297-320) ---- */
+/* G(x_f0, x_org, c_trg): x_f0 [B,T,337] = [mel 80 | f0 one-hot 257], x_org [B,T,80], c_trg [B,82] -> out [B,T,80].
+ * training != 0 applies InterpLnr after each of the three encoder conv layers (model.py:203): scales/len_seg [3][B*7]. */
+int ss_g3_forward(ss_engine* e, const float* x_f0_dev, const float* x_org_dev, const float* c_trg_dev,
+                  const float* scales_dev, const int* len_seg_dev, int B, int T, int training, float* out_dev,
+                  void* stream);
+/* loss.backward() for the last ss_g3_forward: d_out [B,T,80] -> grads arena (overwritten, not accumulated). */
+int ss_g3_backward(ss_engine* e, const float* d_out_dev, void* stream);
+/* G.rhythm(x_org) (model.py:316-320): codes [B, T/8, 2] */
+int ss_g3_rhythm(ss_engine* e, const float* x_org_dev, int B, int T, float* codes_dev, void* stream);
+
+/* ---- Generator_6 (model.py:337-351) ---- */
+/* P(x_org, f0_trg): x_org [B,T,80], f0_trg [B,T,257] -> logits [B,T,257]; training: scales/len_seg [3][B*7] (model.py:128) */
+int ss_g6_forward(ss_engine* e, const float* x_org_dev, const float* f0_trg_dev, const float* scales_dev,
+                  const int* len_seg_dev, int B, int T, int training, float* out_dev, void* stream);
+int ss_g6_backward(ss_engine* e, const float* d_out_dev, void* stream);
+
+/* ---- Solver.train step body (solver.py:157-172), fused: cat(mel,f0) -> InterpLnr -> quantize_f0 -> G -> mse(mean)
+ *      -> backward -> Adam.  mel [B,T,80], f0 [B,T,1] (-1e10 = unvoiced), emb [B,82], len_org i32[B];
+ *      scales/len_seg [4][B*7] (outer call first).  T must equal hp.max_len_pad (model.py:105,157).
+ *      grad_scale multiplies the gradients (1/world_size under data parallelism).  loss: one device float. */
+int ss_g3_train_step(ss_engine* e, const float* mel_dev, const float* f0_dev, const float* emb_dev,
+                     const int* len_org_dev, const float* scales_dev, const int* len_seg_dev, int B, int T,
+                     float grad_scale, int flags, float* loss_dev, void* stream);
+/* Generator_6 has no training loop in the reference; cross-entropy against target_idx i32[B,T] is this
+ * engine's choice.  f0_onehot [B,T,257]; scales/len_seg [3][B*7]. */
+int ss_g6_train_step(ss_engine* e, const float* mel_dev, const float* f0_onehot_dev, const int* target_idx_dev,
+                     const float* scales_dev, const int* len_seg_dev, int B, int T, float grad_scale, int flags,
+                     float* loss_dev, void* stream);
+
+/* torch.optim.Adam(G.parameters(), lr, [beta1, beta2]) (solver.py:62,172).  `step` = updates already applied. */
+int ss_set_adam(ss_engine* e, double lr, double beta1, double beta2, double eps, long step, void* stream);
+int ss_adam_step(ss_engine* e, float grad_scale, void* stream);
+int ss_zero_grads(ss_engine* e, void* stream);
+
+/* ---- InterpLnr as a standalone module (model.py:355-436; solver.py:59,161) ---- */
+/* x [B,T,C], len_seq i32[B], draws [B*7] -> y [B,max_len_pad,C].  Optional outputs (may be NULL): i0 i32[B,P],
+ * lam f32[B,P], counts i32[B] (un-truncated, model.py:418). */
+int ss_interp_forward(ss_engine* e, const float* x_dev, const int* len_seq_dev, const float* scales_dev,
+                      const int* len_seg_dev, int B, int T, int C, float* y_dev, int* i0_dev, float* lam_dev,
+                      int* counts_dev, void* stream);
+/* adjoint of the last ss_interp_forward: dy [B,P,C] -> dx [B,T,C] */
+int ss_interp_backward(ss_engine* e, const float* dy_dev, int B, int T, int C, float* dx_dev, void* stream);
+
+/* ---- test / profiling hooks ---- */
+/* C[M,N] = A . B^T style fp32 MFMA GEMM used by every contraction on the path (flags: 1 = A stored [K,M], 2 = B stored [K,N]) */
+int ss_op_gemm(const float* a_dev, long lda, const float* b_dev, long ldb, float* c_dev, long ldc, const float* bias_dev,
+               int M, int N, int K, int flags, int ksplit, void* stream);
+/* named internal slab of the last call ("enc1.xf2", "dec.out2", ...); layout [B, T+4, C], frame t at row t+2 */
+int ss_debug_buffer(ss_engine* e, const char* name, float** ptr_dev, long* rows, long* cols);
+int ss_debug_names(ss_engine* e, char* buf, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

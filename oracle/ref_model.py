@@ -17,12 +17,21 @@ import torch.nn.functional as F
 
 from . import interp_np
 
+TAP = None      # set to a dict to record intermediates (name -> [B,T,C] tensor) for kernel-level debugging
+
+
+def _tap(name, t, nct=False):
+    if TAP is not None:
+        TAP[name] = (t.transpose(1, 2) if nct else t).detach().clone()
+
 
 # --------------------------------------------------------------------------- blocks
-def conv_gn_relu(x_nct, P, prefix, chs_grp=16):
+def conv_gn_relu(x_nct, P, prefix, chs_grp=16, tap=None):
     """relu(GroupNorm(Conv1d(k=5,p=2)))  -- model.py:61-67,76-77 / 109-115,125-126 / 164-185,200-201."""
     w = P[prefix + '.0.conv.weight']
     y = F.conv1d(x_nct, w, P[prefix + '.0.conv.bias'], stride=1, padding=2, dilation=1)
+    if tap:
+        _tap(tap, y, nct=True)
     y = F.group_norm(y, w.shape[0] // chs_grp, P[prefix + '.1.weight'], P[prefix + '.1.bias'], eps=1e-5)
     return F.relu(y)
 
@@ -36,13 +45,18 @@ def _lstm_flat(P, prefix, layers):
     return flat
 
 
-def blstm(x_btc, P, prefix, layers):
-    """nn.LSTM(batch_first=True, bidirectional=True), zero initial state -- model.py:71,81 etc."""
+def blstm(x_btc, P, prefix, layers, tap=None):
+    """nn.LSTM(batch_first=True, bidirectional=True), zero initial state -- model.py:71,81 etc.
+    Evaluated one layer per aten::lstm call (a stacked LSTM is exactly that) so layer outputs can be tapped."""
     hid = P[f'{prefix}.weight_hh_l0'].shape[1]
     B = x_btc.shape[0]
-    h0 = x_btc.new_zeros(2 * layers, B, hid)
-    out, _, _ = torch._VF.lstm(x_btc, (h0, h0), _lstm_flat(P, prefix, layers), True, layers, 0.0,
-                               False, True, True)
+    h0 = x_btc.new_zeros(2, B, hid)
+    flat = _lstm_flat(P, prefix, layers)
+    out = x_btc
+    for l in range(layers):
+        out, _, _ = torch._VF.lstm(out, (h0, h0), flat[8 * l:8 * l + 8], True, 1, 0.0, False, True, True)
+        if tap:
+            _tap(f'{tap}.out{l}', out)
     return out
 
 
@@ -100,8 +114,9 @@ def codes_from(out_btc, hid, freq):
 # --------------------------------------------------------------------------- modules
 def encoder_t(x_nct, P, hp, prefix='encoder_2'):
     """Encoder_t.forward (mask is always None) -- model.py:74-89."""
-    x = conv_gn_relu(x_nct, P, prefix + '.convolutions.0', hp.chs_grp)
-    out = blstm(x.transpose(1, 2), P, prefix + '.lstm', 1)
+    x = conv_gn_relu(x_nct, P, prefix + '.convolutions.0', hp.chs_grp, tap='enc2.c.conv')
+    _tap('enc2.act', x, nct=True)
+    out = blstm(x.transpose(1, 2), P, prefix + '.lstm', 1, tap='enc2.lstm')
     return codes_from(out, hp.dim_neck_2, hp.freq_2)
 
 
@@ -111,15 +126,16 @@ def encoder_7(x_f0_nct, P, hp, draws, training, prefix='encoder_1'):
     f0 = x_f0_nct[:, hp.dim_freq:]
     B = x.shape[0]
     for i in range(3):
-        x = conv_gn_relu(x, P, f'{prefix}.convolutions_1.{i}', hp.chs_grp)
-        f0 = conv_gn_relu(f0, P, f'{prefix}.convolutions_2.{i}', hp.chs_grp)
+        x = conv_gn_relu(x, P, f'{prefix}.convolutions_1.{i}', hp.chs_grp, tap=f'enc1.c1_{i}.conv')
+        f0 = conv_gn_relu(f0, P, f'{prefix}.convolutions_2.{i}', hp.chs_grp, tap=f'enc1.c2_{i}.conv')
         xf = torch.cat((x, f0), 1).transpose(1, 2)
         if training:
             xf = interp(xf, np.full(B, hp.max_len_pad), draws[i], hp)       # :203, len_org = max_len_pad
+        _tap(f'enc.xf{i}', xf)
         x = xf[:, :, :hp.dim_enc].transpose(1, 2)
         f0 = xf[:, :, hp.dim_enc:].transpose(1, 2)
-    ox = blstm(x.transpose(1, 2), P, prefix + '.lstm_1', 2)
-    of = blstm(f0.transpose(1, 2), P, prefix + '.lstm_2', 1)
+    ox = blstm(x.transpose(1, 2), P, prefix + '.lstm_1', 2, tap='enc1.lstm1')
+    of = blstm(f0.transpose(1, 2), P, prefix + '.lstm_2', 1, tap='enc1.lstm2')
     return codes_from(ox, hp.dim_neck, hp.freq), codes_from(of, hp.dim_neck_3, hp.freq_3)
 
 
@@ -128,16 +144,18 @@ def encoder_6(f0_nct, P, hp, draws, training, prefix='encoder_3'):
     x = f0_nct
     B = x.shape[0]
     for i in range(3):
-        x = conv_gn_relu(x, P, f'{prefix}.convolutions.{i}', hp.chs_grp)
+        x = conv_gn_relu(x, P, f'{prefix}.convolutions.{i}', hp.chs_grp, tap=f'enc3.c_{i}.conv')
         if training:
             x = interp(x.transpose(1, 2), np.full(B, hp.max_len_pad), draws[i], hp).transpose(1, 2)
-    out = blstm(x.transpose(1, 2), P, prefix + '.lstm', 1)
+        _tap(f'enc.xf{i}', x, nct=True)
+    out = blstm(x.transpose(1, 2), P, prefix + '.lstm', 1, tap='enc3.lstm')
     return codes_from(out, hp.dim_neck_3, hp.freq_3)
 
 
 def decoder(x_btc, P, layers, prefix='decoder'):
     """Decoder_3 / Decoder_4 forward -- model.py:249-255, 273-279."""
-    h = blstm(x_btc, P, prefix + '.lstm', layers)
+    _tap('dec.in', x_btc)
+    h = blstm(x_btc, P, prefix + '.lstm', layers, tap='dec.lstm')
     return F.linear(h, P[prefix + '.linear_projection.linear_layer.weight'],
                     P[prefix + '.linear_projection.linear_layer.bias'])
 

@@ -1,0 +1,45 @@
+// Shared declarations for the SpeechSplit gfx950 kernels (internal; the public C ABI is include/speechsplit_amd.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ss {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// One GEMM operand.  Element (row, col) lives at
+//   p + batch*bstride + row*ld + (col / seglen)*segstride + (col % seglen)        (seglen == 0: + col)
+// The segmented form lets a k=5 "same" convolution over a zero-haloed [T+4, C] slab be read as a plain
+// matrix with overlapping rows: col = tap*Cin + ci  ->  row + tap rows further down, channel ci.
+struct Operand {
+    const float* p;
+    long ld;
+    long bstride;
+    int seglen;
+    long segstride;
+};
+
+enum GemmFlags {
+    GEMM_TA = 1,        // A is reduction-major:  A(m,k) stored at row k, col m   (else row m, col k)
+    GEMM_TB = 2,        // B is reduction-major:  B(n,k) stored at row k, col n   (else row n, col k)
+    GEMM_ACCUM = 4,     // C += result (plain read-modify-write; atomics when ksplit > 1)
+};
+
+struct GemmDesc {
+    Operand A, B;
+    float* C;
+    long ldc, cstride;
+    const float* bias;      // per output column n, may be null
+    int M, N, K;
+    int batch;
+    int flags;
+    int ksplit;             // >1: split the reduction over blockIdx.z, atomically accumulate into C (C pre-zeroed or ACCUM)
+};
+
+// C[b][m][n] (+)= sum_k A(m,k) * B(n,k) (+ bias[n]);  fp32 in, fp32 MFMA accumulate (exact fp32 fma chain)
+hipError_t launch_gemm(const GemmDesc& d, hipStream_t stream);
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace ss

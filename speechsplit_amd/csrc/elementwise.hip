@@ -1,0 +1,505 @@
+// HBM/L2-bound kernels of the SpeechSplit path: GroupNorm+ReLU (fwd/bwd), bias/affine gradient sums, weight
+// re-layouts, decoder-input assembly, losses and the flat Adam update.
+#include "common.h"
+#include "kernels.h"
+
+namespace ss {
+
+namespace {
+
+constexpr int GN_MAXIT = 16;     // T <= 256
+constexpr float GN_EPS = 1e-5f;
+
+// ------------------------------------------------------------------------------------------------ GroupNorm + ReLU
+// One workgroup per (utterance, 64 channels = 4 groups).  Thread (rg = tid>>4, l16 = tid&15) owns float4 channel
+// slot l16 of rows rg, rg+16, ...; the whole (T x 64) slab stays in registers between the statistics and the output.
+__device__ __forceinline__ float block_group_sum(float v, float* red, float* out4, int tid) {
+    red[tid] = v;
+    __syncthreads();
+    if (tid < 4) {
+        float s = 0.f;
+        for (int rg = 0; rg < 16; ++rg)
+#pragma unroll
+            for (int l = 0; l < 4; ++l) s += red[rg * 16 + tid * 4 + l];
+        out4[tid] = s;
+    }
+    __syncthreads();
+    return out4[(tid & 15) >> 2];
+}
+
+__global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const float* __restrict__ x, long x_ld, long x_bs,
+                                                          float* __restrict__ y, long y_ld, long y_bs,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ stats, int T, int C) {
+    __shared__ float red[256];
+    __shared__ float g4[4];
+    const int tid = threadIdx.x, l16 = tid & 15, rg = tid >> 4;
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 64 + l16 * 4;
+    const int nit = (T + 15) >> 4;
+    const float* xb = x + b * x_bs + (long)HALO * x_ld + c;
+    f32x4 v[GN_MAXIT];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < GN_MAXIT; ++it) {
+        const int t = rg + it * 16;
+        if (it < nit && t < T) {
+            v[it] = *reinterpret_cast<const f32x4*>(xb + (long)t * x_ld);
+            s += (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]);
+        } else {
+            v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float inv_n = 1.0f / (16.0f * (float)T);
+    const float mean = block_group_sum(s, red, g4, tid) * inv_n;
+    float ss = 0.f;
+#pragma unroll
+    for (int it = 0; it < GN_MAXIT; ++it) {
+        const int t = rg + it * 16;
+        if (it < nit && t < T) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dlt = v[it][j] - mean;
+                ss += dlt * dlt;
+            }
+        }
+    }
+    const float var = block_group_sum(ss, red, g4, tid) * inv_n;
+    const float rstd = 1.0f / sqrtf(var + GN_EPS);
+    if (rg == 0 && (l16 & 3) == 0) {
+        const int g = (c >> 4);
+        stats[((long)b * (C >> 4) + g) * 2 + 0] = mean;
+        stats[((long)b * (C >> 4) + g) * 2 + 1] = rstd;
+    }
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(beta + c);
+    float* yb = y + b * y_bs + (long)HALO * y_ld + c;
+#pragma unroll
+    for (int it = 0; it < GN_MAXIT; ++it) {
+        const int t = rg + it * 16;
+        if (it < nit && t < T) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float z = (v[it][j] - mean) * rstd * ga[j] + be[j];
+                o[j] = z > 0.f ? z : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(yb + (long)t * y_ld) = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restrict__ x, long x_ld, long x_bs,
+                                                          float* __restrict__ dy, long dy_ld, long dy_bs,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ stats, float* __restrict__ part,
+                                                          int B, int T, int C) {
+    __shared__ float red[256];
+    __shared__ float g4[4];
+    __shared__ float colred[3][16][64];
+    const int tid = threadIdx.x, l16 = tid & 15, rg = tid >> 4;
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 64 + l16 * 4;
+    const int nit = (T + 15) >> 4;
+    const int g = c >> 4;
+    const float mean = stats[((long)b * (C >> 4) + g) * 2 + 0];
+    const float rstd = stats[((long)b * (C >> 4) + g) * 2 + 1];
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(beta + c);
+    const float* xb = x + b * x_bs + (long)HALO * x_ld + c;
+    float* db = dy + b * dy_bs + (long)HALO * dy_ld + c;
+    f32x4 xh[GN_MAXIT], dh[GN_MAXIT];
+    f32x4 dgam = {0.f, 0.f, 0.f, 0.f}, dbet = {0.f, 0.f, 0.f, 0.f};
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < GN_MAXIT; ++it) {
+        const int t = rg + it * 16;
+        if (it < nit && t < T) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + (long)t * x_ld);
+            const f32x4 dv = *reinterpret_cast<const f32x4*>(db + (long)t * dy_ld);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float h = (xv[j] - mean) * rstd;
+                const float z = h * ga[j] + be[j];
+                const float dz = z > 0.f ? dv[j] : 0.f;
+                dgam[j] += dz * h;
+                dbet[j] += dz;
+                const float dxh = dz * ga[j];
+                xh[it][j] = h;
+                dh[it][j] = dxh;
+                s1 += dxh;
+                s2 += dxh * h;
+            }
+        } else {
+            xh[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dh[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float inv_n = 1.0f / (16.0f * (float)T);
+    const float m1 = block_group_sum(s1, red, g4, tid) * inv_n;
+    const float m2 = block_group_sum(s2, red, g4, tid) * inv_n;
+    f32x4 dbias = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < GN_MAXIT; ++it) {
+        const int t = rg + it * 16;
+        if (it < nit && t < T) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = rstd * (dh[it][j] - m1 - xh[it][j] * m2);
+                dbias[j] += o[j];
+            }
+            *reinterpret_cast<f32x4*>(db + (long)t * dy_ld) = o;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        colred[0][rg][l16 * 4 + j] = dgam[j];
+        colred[1][rg][l16 * 4 + j] = dbet[j];
+        colred[2][rg][l16 * 4 + j] = dbias[j];
+    }
+    __syncthreads();
+    if (tid < 192) {
+        const int which = tid >> 6, cc = tid & 63;
+        float s = 0.f;
+        for (int r = 0; r < 16; ++r) s += colred[which][r][cc];
+        part[((long)which * B + b) * C + blockIdx.x * 64 + cc] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ column sums
+// grid = (ceil(C/64), chunks); block 256 = 64 columns x 4 row lanes
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, long ld, int R, int C, int rows_per_chunk,
+                                                     float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int r0 = blockIdx.y * rows_per_chunk;
+    int r1 = r0 + rows_per_chunk;
+    if (r1 > R) r1 = R;
+    float s = 0.f;
+    if (c < C)
+        for (int r = r0 + rl; r < r1; r += 4) s += in[(long)r * ld + c];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) atomicAdd(out + c, (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
+}
+
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, long s_ld, long s_bs,
+                                                        float* __restrict__ dst, long d_ld, long d_bs, int T, int C) {
+    const int b = blockIdx.y;
+    const long n = (long)T * C;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int t = (int)(i / C), c = (int)(i - (long)t * C);
+        dst[b * d_bs + t * d_ld + c] = src[b * s_bs + t * s_ld + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict__ w, int Co, int Ci, int Cp,
+                                                        float* __restrict__ wf, float* __restrict__ wb) {
+    // wf[co][k][cp] ; wb[ci][k][co] = w[co][ci][4-k]
+    const long nf = (long)Co * 5 * Cp;
+    const long nb = (long)Ci * 5 * Co;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < nf + nb; i += (long)gridDim.x * 256) {
+        if (i < nf) {
+            const int cp = (int)(i % Cp);
+            const int k = (int)((i / Cp) % 5);
+            const int co = (int)(i / (5L * Cp));
+            wf[i] = cp < Ci ? w[((long)co * Ci + cp) * 5 + k] : 0.f;
+        } else if (wb) {
+            const long q = i - nf;
+            const int co = (int)(q % Co);
+            const int k = (int)((q / Co) % 5);
+            const int ci = (int)(q / (5L * Co));
+            wb[q] = w[((long)co * Ci + ci) * 5 + (4 - k)];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void conv_unpack_grad_kernel(const float* __restrict__ gp, int Co, int Ci, int Cp,
+                                                               float* __restrict__ g) {
+    const long n = (long)Co * Ci * 5;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int k = (int)(i % 5);
+        const int ci = (int)((i / 5) % Ci);
+        const int co = (int)(i / (5L * Ci));
+        g[i] = gp[((long)co * 5 + k) * Cp + ci];
+    }
+}
+
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int R, int C, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < R && c0 + tx < C) tile[j][tx] = in[(long)(r0 + j) * C + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < C && r0 + tx < R) out[(long)(c0 + j) * R + r0 + tx] = tile[tx][j];
+}
+
+__global__ __launch_bounds__(256) void add_vec_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      float* __restrict__ out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+
+// ------------------------------------------------------------------------------------------------ decoder input
+struct CodeSrcPack {
+    CodeSrc s[4];
+    int n;
+};
+
+// grid = (T, B), block 256
+__global__ __launch_bounds__(256) void build_dec_in_kernel(CodeSrcPack p, const float* __restrict__ emb, int emb_dim,
+                                                           int emb_col, float* __restrict__ dec_in, int ld, int T) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    const int TP = T + 2 * HALO;
+    float* row = dec_in + ((long)b * TP + t + HALO) * ld;
+    for (int c = threadIdx.x; c < ld; c += 256) {
+        float v = 0.f;
+        if (c >= emb_col && c < emb_col + emb_dim) {
+            v = emb[(long)b * emb_dim + c - emb_col];      // c_trg broadcast over time (model.py:309)
+        } else {
+            for (int i = 0; i < p.n; ++i) {
+                const int H = p.s[i].H, col = p.s[i].col;
+                if (c >= col && c < col + 2 * H) {
+                    const int cc = c - col, f = p.s[i].freq;
+                    const int blk = t / f;
+                    // forward half sampled at the END of each block, backward half at its START (model.py:223-227)
+                    const int ts = cc < H ? blk * f + f - 1 : blk * f;
+                    v = p.s[i].o[((long)b * TP + ts + HALO) * (2 * H) + cc];
+                }
+            }
+        }
+        row[c] = v;
+    }
+}
+
+// grid = (T, B): writes the full gradient slab of every encoder BLSTM output (zeros where the code is not sampled)
+__global__ __launch_bounds__(128) void dec_in_grad_kernel(CodeSrcPack p, const float* __restrict__ d_dec_in, int ld, int T) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    const int TP = T + 2 * HALO;
+    for (int i = 0; i < p.n; ++i) {
+        const int H = p.s[i].H, f = p.s[i].freq, col = p.s[i].col;
+        float* drow = p.s[i].d_o + ((long)b * TP + t + HALO) * (2 * H);
+        for (int cc = threadIdx.x; cc < 2 * H; cc += 128) {
+            const bool sampled = cc < H ? (t % f == f - 1) : (t % f == 0);
+            float v = 0.f;
+            if (sampled) {
+                const int t0 = (t / f) * f;
+                for (int u = 0; u < f; ++u) v += d_dec_in[((long)b * TP + t0 + u + HALO) * ld + col + cc];
+            }
+            drow[cc] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ losses
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ out, long o_ld, long o_bs,
+                                                  const float* __restrict__ tgt, long t_ld, long t_bs,
+                                                  float* __restrict__ d_out, long d_ld, long d_bs, int T, int C,
+                                                  float gscale, float* __restrict__ partials) {
+    __shared__ float red[256];
+    const int b = blockIdx.y;
+    const long n = (long)T * C;
+    float s = 0.f;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int t = (int)(i / C), c = (int)(i - (long)t * C);
+        const float o = out[b * o_bs + t * o_ld + c];
+        const float y = tgt[b * t_bs + t * t_ld + c];
+        const float e = o - y;
+        s += e * e;
+        d_out[b * d_bs + t * d_ld + c] = e * gscale;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[blockIdx.y * gridDim.x + blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void finish_loss_kernel(const float* __restrict__ partials, int n, float scale,
+                                                          float* __restrict__ loss) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)partials[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = (float)(red[0] * (double)scale);
+}
+
+// one wavefront per (b, t) row: log-softmax over C classes.  grid = (T, B), block 64
+__global__ __launch_bounds__(64) void ce_kernel(const float* __restrict__ logits, long o_ld, long o_bs,
+                                                const int* __restrict__ tgt, float* __restrict__ d_out, long d_ld,
+                                                long d_bs, int T, int C, float gscale, float* __restrict__ partials) {
+    const int t = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const float* row = logits + b * o_bs + t * o_ld;
+    float mx = -INFINITY;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, row[c]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float se = 0.f;
+    for (int c = lane; c < C; c += 64) se += expf(row[c] - mx);
+    for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+    const int y = tgt[(long)b * T + t];
+    const float lse = mx + logf(se);
+    float* drow = d_out + b * d_bs + t * d_ld;
+    for (int c = lane; c < C; c += 64) drow[c] = (expf(row[c] - lse) - (c == y ? 1.f : 0.f)) * gscale;
+    if (lane == 0) partials[(long)b * T + t] = lse - row[y];
+}
+
+// ------------------------------------------------------------------------------------------------ Adam
+// torch.optim.Adam defaults as solver.py:62 constructs it (no amsgrad, no weight decay), single-tensor formulas:
+//   m = lerp(m, g, 1-b1); v = v*b2 + (1-b2) g*g; p -= step_size * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void adam_prepare_kernel(AdamState* st) {
+    st->step += 1;
+    const double t = (double)st->step;
+    const double bc1 = 1.0 - pow(st->beta1, t);
+    const double bc2 = 1.0 - pow(st->beta2, t);
+    st->step_size = (float)(st->lr / bc1);
+    st->bc2_sqrt = (float)sqrt(bc2);
+    st->f_beta1 = (float)st->beta1;
+    st->f_beta2 = (float)st->beta2;
+    st->f_eps = (float)st->eps;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n4,
+                                                   const AdamState* __restrict__ st, float gscale) {
+    const float step_size = st->step_size, bc2s = st->bc2_sqrt, b1 = st->f_beta1, b2 = st->f_beta2, eps = st->f_eps;
+    const float w1 = (float)(1.0 - st->beta1), w2 = (float)(1.0 - st->beta2);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+        f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+        f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gg = gv[j] * gscale;
+            mv[j] = mv[j] + w1 * (gg - mv[j]);
+            vv[j] = vv[j] * b2 + w2 * gg * gg;
+            const float denom = sqrtf(vv[j]) / bc2s + eps;
+            pv[j] = pv[j] - step_size * (mv[j] / denom);
+        }
+        (void)b1;
+        reinterpret_cast<f32x4*>(p)[i] = pv;
+        reinterpret_cast<f32x4*>(m)[i] = mv;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+    }
+}
+
+}  // namespace
+
+hipError_t gn_relu_fwd(const float* x, long x_ld, long x_bs, float* y, long y_ld, long y_bs, const float* gamma,
+                       const float* beta, float* stats, int B, int T, int C, hipStream_t s) {
+    if (C % 64 != 0 || T > 16 * GN_MAXIT) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gn_relu_fwd_kernel, dim3(C / 64, B), dim3(256), 0, s, x, x_ld, x_bs, y, y_ld, y_bs, gamma, beta, stats,
+                       T, C);
+    return hipGetLastError();
+}
+
+hipError_t gn_relu_bwd(const float* x, long x_ld, long x_bs, float* dy, long dy_ld, long dy_bs, const float* gamma,
+                       const float* beta, const float* stats, float* part, int B, int T, int C, hipStream_t s) {
+    if (C % 64 != 0 || T > 16 * GN_MAXIT) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(C / 64, B), dim3(256), 0, s, x, x_ld, x_bs, dy, dy_ld, dy_bs, gamma, beta,
+                       stats, part, B, T, C);
+    return hipGetLastError();
+}
+
+hipError_t colsum_acc(const float* in, long ld, int R, int C, float* out, hipStream_t s) {
+    const int cblocks = cdiv(C, 64);
+    int chunks = cdiv(1024, cblocks);
+    if (chunks > cdiv(R, 16)) chunks = cdiv(R, 16);
+    if (chunks < 1) chunks = 1;
+    const int rpc = cdiv(R, chunks);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cblocks, cdiv(R, rpc)), dim3(256), 0, s, in, ld, R, C, rpc, out);
+    return hipGetLastError();
+}
+
+hipError_t copy_rows(const float* src, long s_ld, long s_bs, float* dst, long d_ld, long d_bs, int B, int T, int C,
+                     hipStream_t s) {
+    int gx = cdiv((long)T * C, 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(gx, B), dim3(256), 0, s, src, s_ld, s_bs, dst, d_ld, d_bs, T, C);
+    return hipGetLastError();
+}
+
+hipError_t conv_pack(const float* w, int Co, int Ci, int Cp, float* wf, float* wb, hipStream_t s) {
+    const long n = (long)Co * 5 * Cp + (long)Ci * 5 * Co;
+    int g = cdiv(n, 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(conv_pack_kernel, dim3(g), dim3(256), 0, s, w, Co, Ci, Cp, wf, wb);
+    return hipGetLastError();
+}
+
+hipError_t conv_unpack_grad(const float* gp, int Co, int Ci, int Cp, float* g, hipStream_t s) {
+    int gr = cdiv((long)Co * Ci * 5, 256);
+    if (gr > 2048) gr = 2048;
+    hipLaunchKernelGGL(conv_unpack_grad_kernel, dim3(gr), dim3(256), 0, s, gp, Co, Ci, Cp, g);
+    return hipGetLastError();
+}
+
+hipError_t transpose2d(const float* in, int R, int C, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, s, in, R, C, out);
+    return hipGetLastError();
+}
+
+hipError_t add_vec(const float* a, const float* b, float* out, int n, hipStream_t s) {
+    hipLaunchKernelGGL(add_vec_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, a, b, out, n);
+    return hipGetLastError();
+}
+
+hipError_t build_dec_in(const CodeSrc* src, int nsrc, const float* emb, int emb_dim, int emb_col, float* dec_in, int ld,
+                        int B, int T, hipStream_t s) {
+    if (nsrc > 4) return hipErrorInvalidValue;
+    CodeSrcPack p;
+    p.n = nsrc;
+    for (int i = 0; i < nsrc; ++i) p.s[i] = src[i];
+    hipLaunchKernelGGL(build_dec_in_kernel, dim3(T, B), dim3(256), 0, s, p, emb, emb_dim, emb_col, dec_in, ld, T);
+    return hipGetLastError();
+}
+
+hipError_t dec_in_grad(const CodeSrc* src, int nsrc, const float* d_dec_in, int ld, int B, int T, hipStream_t s) {
+    if (nsrc > 4) return hipErrorInvalidValue;
+    CodeSrcPack p;
+    p.n = nsrc;
+    for (int i = 0; i < nsrc; ++i) p.s[i] = src[i];
+    hipLaunchKernelGGL(dec_in_grad_kernel, dim3(T, B), dim3(128), 0, s, p, d_dec_in, ld, T);
+    return hipGetLastError();
+}
+
+hipError_t mse_loss(const float* out, long o_ld, long o_bs, const float* tgt, long t_ld, long t_bs, float* d_out, long d_ld,
+                    long d_bs, int B, int T, int C, float grad_scale, float* partials, float* loss, hipStream_t s) {
+    const int gx = 8;
+    const double n = (double)B * T * C;
+    hipLaunchKernelGGL(mse_kernel, dim3(gx, B), dim3(256), 0, s, out, o_ld, o_bs, tgt, t_ld, t_bs, d_out, d_ld, d_bs, T, C,
+                       (float)(2.0 / n) * grad_scale, partials);
+    hipLaunchKernelGGL(finish_loss_kernel, dim3(1), dim3(256), 0, s, partials, gx * B, (float)(1.0 / n), loss);
+    return hipGetLastError();
+}
+
+hipError_t ce_loss(const float* logits, long o_ld, long o_bs, const int* tgt, float* d_out, long d_ld, long d_bs, int B,
+                   int T, int C, float grad_scale, float* partials, float* loss, hipStream_t s) {
+    const double n = (double)B * T;
+    hipLaunchKernelGGL(ce_kernel, dim3(T, B), dim3(64), 0, s, logits, o_ld, o_bs, tgt, d_out, d_ld, d_bs, T, C,
+                       (float)(1.0 / n) * grad_scale, partials);
+    hipLaunchKernelGGL(finish_loss_kernel, dim3(1), dim3(256), 0, s, partials, B * T, (float)(1.0 / n), loss);
+    return hipGetLastError();
+}
+
+hipError_t adam_step(float* p, const float* g, float* m, float* v, long n, AdamState* st, float grad_scale, hipStream_t s) {
+    if (n % 4 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, s, st);
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, s, p, g, m, v, n / 4, st, grad_scale);
+    return hipGetLastError();
+}
+
+}  // namespace ss

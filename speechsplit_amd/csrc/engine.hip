@@ -1,0 +1,983 @@
+// Host-side engine: parameter table, workspace plan and the forward / backward / training-step schedules of
+// Generator_3 and Generator_6 over the kernels in this directory, behind the C ABI of include/speechsplit_amd.h.
+//
+// Mirrors (does not translate) reference model.py:46-351 and solver.py:157-172: same operators in the same
+// order, but activations live in haloed time-major slabs (kernels.h), the three InterpLnr calls of Encoder_7
+// operate on one fused 768-channel slab, channel concats / splits / transposes are pointer arithmetic, and
+// every contraction is the one fp32 MFMA GEMM.
+#include <map>
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+
+#include "common.h"
+#include "kernels.h"
+#include "../../include/speechsplit_amd.h"
+
+using namespace ss;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(const std::string& m) {
+    g_err = m;
+    return -1;
+}
+#define HIPCHK(x)                                                                      \
+    do {                                                                               \
+        hipError_t _e = (x);                                                           \
+        if (_e != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+#define CHK(x)                 \
+    do {                       \
+        int _r = (x);          \
+        if (_r != 0) return _r; \
+    } while (0)
+
+struct ParamInfo {
+    std::string name;
+    long offset;
+    int ndim;
+    long shape[3];
+    long numel() const { return shape[0] * (ndim > 1 ? shape[1] : 1) * (ndim > 2 ? shape[2] : 1); }
+};
+
+struct ConvBlk {
+    int Ci = 0, Co = 0, Cp = 0;
+    long w = 0, b = 0, ga = 0, be = 0;     // arena offsets
+    float *wf = nullptr, *wb = nullptr, *gp = nullptr, *cout = nullptr, *stats = nullptr, *part = nullptr;
+    bool need_dx = false;
+};
+
+struct LstmDir {
+    long wih, whh, bih, bhh;
+};
+
+struct LstmBlk {
+    int In = 0, H = 0, L = 0;
+    std::vector<LstmDir> pd;               // [L*2]
+    std::vector<float*> gates, out, csave; // per layer
+    float* bsum = nullptr;                 // [L][2][4H]
+    float* whhT = nullptr;                 // [2][H][4H]   (step kernels only)
+    float* dc = nullptr;                   // [2][B][H]
+    float* dmid[2] = {nullptr, nullptr};   // gradient slabs of inner layer outputs [B,TP,2H]
+    bool big() const { return H > 32; }
+    int in_of(int l) const { return l == 0 ? In : 2 * H; }
+};
+
+struct Slab {   // view of a haloed slab: p points at slab row 0, first channel of interest
+    float* p = nullptr;
+    long ld = 0;
+};
+
+}  // namespace
+
+struct ss_engine {
+    int kind;
+    ss_hparams hp;
+    int maxB, maxT;
+    std::vector<ParamInfo> params;
+    long arena = 0;
+
+    float *P = nullptr, *G = nullptr, *Mm = nullptr, *Vv = nullptr;
+    char* ws = nullptr;
+    long ws_bytes = 0;
+    int curB = 0, curT = 0;
+    bool fwd_training = false;
+    bool have_fwd = false;
+    int enc_plan0 = 0;                     // plan[] index of the first encoder InterpLnr call of the last forward
+
+    // components
+    ConvBlk c1[3], c2[3], ct;              // Encoder_7 stream 1 / stream 2 (or Encoder_6 in c2), Encoder_t
+    LstmBlk l1, l2, lt, ld;                // lstm_1, lstm_2 (or Encoder_6.lstm), Encoder_t.lstm, decoder.lstm
+    long head_w = 0, head_b = 0;
+    int head_out = 0, dec_in_dim = 0, CE = 0;   // CE = channels of the fused encoder slab (768 for G3, 256 for G6)
+
+    // workspace slabs
+    float *in_mel = nullptr, *in_f0 = nullptr, *org = nullptr, *emb = nullptr;
+    int f0p = 0;                           // padded one-hot width (260)
+    float *act = nullptr, *d_act = nullptr, *d_xf = nullptr, *xf[3] = {nullptr, nullptr, nullptr};
+    float *act_t = nullptr, *d_act_t = nullptr;
+    float *dec_in = nullptr, *d_dec_in = nullptr, *d_top = nullptr;
+    float *d_o1 = nullptr, *d_o2 = nullptr, *d_ot = nullptr;
+    float *out_slab = nullptr, *d_out_slab = nullptr;
+    float *loss_part = nullptr;
+    int* qidx = nullptr;
+    InterpPlan plan[4];
+    AdamState* adam = nullptr;
+    std::map<std::string, std::pair<float*, long>> dbg;   // name -> (ptr, cols)
+
+    long carve(int B, int T, bool assign);
+};
+
+namespace {
+
+long align4(long x) { return (x + 3) & ~3L; }
+
+// ------------------------------------------------------------------------------------------------ parameter table
+struct TableBuilder {
+    std::vector<ParamInfo>& v;
+    long off = 0;
+    long add(const std::string& name, long a, long b = -1, long c = -1) {
+        ParamInfo p;
+        p.name = name;
+        p.offset = off;
+        p.ndim = b < 0 ? 1 : (c < 0 ? 2 : 3);
+        p.shape[0] = a;
+        p.shape[1] = b < 0 ? 1 : b;
+        p.shape[2] = c < 0 ? 1 : c;
+        v.push_back(p);
+        off = align4(off + p.numel());
+        return p.offset;
+    }
+    void conv(const std::string& pre, int ci, int co, ConvBlk& cb) {
+        cb.Ci = ci;
+        cb.Co = co;
+        cb.Cp = (int)align4(ci);
+        cb.w = add(pre + ".0.conv.weight", co, ci, 5);
+        cb.b = add(pre + ".0.conv.bias", co);
+        cb.ga = add(pre + ".1.weight", co);
+        cb.be = add(pre + ".1.bias", co);
+    }
+    void lstm(const std::string& pre, int in, int hid, int layers, LstmBlk& lb) {
+        lb.In = in;
+        lb.H = hid;
+        lb.L = layers;
+        lb.pd.clear();
+        for (int l = 0; l < layers; ++l) {
+            const int i = l == 0 ? in : 2 * hid;
+            for (int d = 0; d < 2; ++d) {
+                const std::string sfx = "_l" + std::to_string(l) + (d ? "_reverse" : "");
+                LstmDir pd;
+                pd.wih = add(pre + ".weight_ih" + sfx, 4 * hid, i);
+                pd.whh = add(pre + ".weight_hh" + sfx, 4 * hid, hid);
+                pd.bih = add(pre + ".bias_ih" + sfx, 4 * hid);
+                pd.bhh = add(pre + ".bias_hh" + sfx, 4 * hid);
+                lb.pd.push_back(pd);
+            }
+        }
+    }
+};
+
+void build_table(ss_engine* e) {
+    const ss_hparams& h = e->hp;
+    TableBuilder tb{e->params};
+    if (e->kind == SS_GENERATOR_3) {      // registration order of model.py:161-191, 59-71, 244-247, 288-290
+        for (int i = 0; i < 3; ++i)
+            tb.conv("encoder_1.convolutions_1." + std::to_string(i), i == 0 ? h.dim_freq : h.dim_enc, h.dim_enc, e->c1[i]);
+        tb.lstm("encoder_1.lstm_1", h.dim_enc, h.dim_neck, 2, e->l1);
+        for (int i = 0; i < 3; ++i)
+            tb.conv("encoder_1.convolutions_2." + std::to_string(i), i == 0 ? h.dim_f0 : h.dim_enc_3, h.dim_enc_3, e->c2[i]);
+        tb.lstm("encoder_1.lstm_2", h.dim_enc_3, h.dim_neck_3, 1, e->l2);
+        tb.conv("encoder_2.convolutions.0", h.dim_freq, h.dim_enc_2, e->ct);
+        tb.lstm("encoder_2.lstm", h.dim_enc_2, h.dim_neck_2, 1, e->lt);
+        e->dec_in_dim = 2 * h.dim_neck + 2 * h.dim_neck_2 + 2 * h.dim_neck_3 + h.dim_spk_emb;
+        tb.lstm("decoder.lstm", e->dec_in_dim, 512, 3, e->ld);
+        e->head_out = h.dim_freq;
+        e->head_w = tb.add("decoder.linear_projection.linear_layer.weight", h.dim_freq, 1024);
+        e->head_b = tb.add("decoder.linear_projection.linear_layer.bias", h.dim_freq);
+        e->CE = h.dim_enc + h.dim_enc_3;
+    } else {                              // model.py:330-332, 107-119, 268-271
+        tb.conv("encoder_2.convolutions.0", h.dim_freq, h.dim_enc_2, e->ct);
+        tb.lstm("encoder_2.lstm", h.dim_enc_2, h.dim_neck_2, 1, e->lt);
+        for (int i = 0; i < 3; ++i)
+            tb.conv("encoder_3.convolutions." + std::to_string(i), i == 0 ? h.dim_f0 : h.dim_enc_3, h.dim_enc_3, e->c2[i]);
+        tb.lstm("encoder_3.lstm", h.dim_enc_3, h.dim_neck_3, 1, e->l2);
+        e->dec_in_dim = 2 * h.dim_neck_2 + 2 * h.dim_neck_3;
+        tb.lstm("decoder.lstm", e->dec_in_dim, 256, 2, e->ld);
+        e->head_out = h.dim_f0;
+        e->head_w = tb.add("decoder.linear_projection.linear_layer.weight", h.dim_f0, 512);
+        e->head_b = tb.add("decoder.linear_projection.linear_layer.bias", h.dim_f0);
+        e->CE = h.dim_enc_3;
+    }
+    e->arena = align4(tb.off);
+    e->f0p = (int)align4(h.dim_f0);
+    for (int i = 0; i < 3; ++i) {
+        e->c1[i].need_dx = i > 0;
+        e->c2[i].need_dx = i > 0;
+    }
+    e->ct.need_dx = false;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ workspace plan
+long ss_engine::carve(int B, int T, bool assign) {
+    const long TP = T + 2 * HALO;
+    const long R = (long)B * TP;
+    long off = 0;
+    dbg.clear();
+    auto take = [&](long bytes) -> char* {
+        char* p = assign ? ws + off : nullptr;
+        off += (bytes + 255) & ~255L;
+        return p;
+    };
+    auto slab = [&](const char* name, long cols) -> float* {
+        float* p = (float*)take(R * cols * 4);
+        if (assign && name) dbg[name] = {p, cols};
+        return p;
+    };
+    auto conv_ws = [&](ConvBlk& cb, const std::string& name) {
+        if (cb.Co == 0) return;
+        cb.wf = (float*)take((long)cb.Co * 5 * cb.Cp * 4);
+        cb.wb = cb.need_dx ? (float*)take((long)cb.Ci * 5 * cb.Co * 4) : nullptr;
+        cb.gp = (float*)take((long)cb.Co * 5 * cb.Cp * 4);
+        cb.cout = slab((name + ".conv").c_str(), cb.Co);
+        cb.stats = (float*)take((long)B * (cb.Co / 16) * 2 * 4);
+        cb.part = (float*)take(3L * B * cb.Co * 4);
+    };
+    auto lstm_ws = [&](LstmBlk& lb, const std::string& name) {
+        if (lb.L == 0) return;
+        lb.gates.assign(lb.L, nullptr);
+        lb.out.assign(lb.L, nullptr);
+        lb.csave.assign(lb.L, nullptr);
+        for (int l = 0; l < lb.L; ++l) {
+            lb.gates[l] = slab((name + ".gates" + std::to_string(l)).c_str(), 8L * lb.H);
+            lb.out[l] = slab((name + ".out" + std::to_string(l)).c_str(), 2L * lb.H);
+            lb.csave[l] = slab((name + ".c" + std::to_string(l)).c_str(), 2L * lb.H);
+        }
+        lb.bsum = (float*)take((long)lb.L * 2 * 4 * lb.H * 4);
+        if (lb.big()) {
+            lb.whhT = (float*)take(2L * lb.H * 4 * lb.H * 4);
+            lb.dc = (float*)take(2L * B * lb.H * 4);
+        }
+        if (lb.L > 1) {
+            lb.dmid[0] = slab((name + ".dmid0").c_str(), 2L * lb.H);
+            lb.dmid[1] = slab((name + ".dmid1").c_str(), 2L * lb.H);
+        }
+    };
+    adam = (AdamState*)take(sizeof(AdamState));        // first: survives geometry changes (offset 0)
+    in_mel = slab("in.mel", hp.dim_freq);
+    in_f0 = slab("in.f0", f0p);
+    org = slab("in.org", hp.dim_freq);
+    emb = (float*)take((long)B * hp.dim_spk_emb * 4);
+    for (int i = 0; i < 3; ++i) {
+        conv_ws(c1[i], "enc1.c1_" + std::to_string(i));
+        conv_ws(c2[i], (kind == SS_GENERATOR_3 ? "enc1.c2_" : "enc3.c_") + std::to_string(i));
+        xf[i] = slab(("enc.xf" + std::to_string(i)).c_str(), CE);
+    }
+    act = slab("enc.act", CE);
+    d_act = slab("enc.d_act", CE);
+    d_xf = slab("enc.d_xf", CE);
+    conv_ws(ct, "enc2.c");
+    act_t = slab("enc2.act", hp.dim_enc_2);
+    d_act_t = slab("enc2.d_act", hp.dim_enc_2);
+    lstm_ws(l1, "enc1.lstm1");
+    lstm_ws(l2, kind == SS_GENERATOR_3 ? "enc1.lstm2" : "enc3.lstm");
+    lstm_ws(lt, "enc2.lstm");
+    lstm_ws(ld, "dec.lstm");
+    if (l1.L) d_o1 = slab("enc1.d_o1", 2L * l1.H);
+    d_o2 = slab("enc.d_o2", 2L * l2.H);
+    d_ot = slab("enc2.d_ot", 2L * lt.H);
+    dec_in = slab("dec.in", dec_in_dim);
+    d_dec_in = slab("dec.d_in", dec_in_dim);
+    d_top = slab("dec.d_top", 2L * ld.H);
+    out_slab = slab("out", head_out);
+    d_out_slab = slab("d_out", head_out);
+    loss_part = (float*)take(((long)B * T + 8L * B) * 4);
+    qidx = (int*)take((long)B * TP * 4);
+    for (int i = 0; i < 4; ++i) {
+        plan[i].S = hp.max_len_seq / hp.min_len_seg + 1;     // model.py:365
+        plan[i].ncand = 2 * hp.max_len_seg;                  // model.py:389
+        plan[i].P = hp.max_len_pad;
+        plan[i].T = T;
+        plan[i].i0 = (int*)take((long)B * hp.max_len_pad * 4);
+        plan[i].lam = (float*)take((long)B * hp.max_len_pad * 4);
+        plan[i].nrows = (int*)take((long)B * 4);
+        plan[i].counts = (int*)take((long)B * 4);
+        plan[i].start = (int*)take((long)B * (T + 1) * 4);
+    }
+    return off;
+}
+
+namespace {
+
+hipStream_t S(void* s) { return (hipStream_t)s; }
+
+int geometry(ss_engine* e, int B, int T, hipStream_t s) {
+    if (!e->ws) return fail("engine is not bound (call ss_bind first)");
+    if (B < 1 || B > e->maxB || T < 8 || T > e->maxT) return fail("batch / frames outside the limits given to ss_create");
+    if (T % e->hp.freq || T % e->hp.freq_2 || T % e->hp.freq_3)
+        return fail("T must be a multiple of the code down-sampling factors (model.py:87,223-227)");
+    if (B == e->curB && T == e->curT) return 0;
+    long need;
+    {
+        ss_engine tmp = *e;
+        need = tmp.carve(B, T, false);
+    }
+    if (need > e->ws_bytes) return fail("workspace too small");
+    // new geometry: halo rows move, so everything except the Adam state (first 256 bytes) is re-zeroed
+    HIPCHK(hipMemsetAsync(e->ws + 256, 0, e->ws_bytes - 256, s));
+    e->carve(B, T, true);
+    e->curB = B;
+    e->curT = T;
+    e->have_fwd = false;
+    return 0;
+}
+
+int pick_ksplit(int M, int N, long K) {
+    const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
+    long ks = 512 / (tiles > 0 ? tiles : 1);
+    if (ks > K / 256) ks = K / 256;
+    if (ks > 32) ks = 32;
+    if (ks < 1) ks = 1;
+    return (int)ks;
+}
+
+#define GEMM(d) HIPCHK(launch_gemm(d, s))
+
+// ---- convolution block -------------------------------------------------------------------------------------
+int conv_pack_all(ss_engine* e, ConvBlk& cb, hipStream_t s) {
+    HIPCHK(conv_pack(e->P + cb.w, cb.Co, cb.Ci, cb.Cp, cb.wf, cb.wb, s));
+    return 0;
+}
+
+// y = relu(GN(conv5(x)))   x: slab view (ld), y: slab view
+int conv_block_fwd(ss_engine* e, ConvBlk& cb, Slab x, Slab y, hipStream_t s) {
+    const int B = e->curB, T = e->curT;
+    const long TP = T + 2 * HALO;
+    GemmDesc d{};
+    d.A = {x.p, x.ld, TP * x.ld, cb.Cp, x.ld};
+    d.B = {cb.wf, 5L * cb.Cp, 0, 0, 0};
+    d.C = cb.cout + HALO * cb.Co;
+    d.ldc = cb.Co;
+    d.cstride = TP * cb.Co;
+    d.bias = e->P + cb.b;
+    d.M = T;
+    d.N = cb.Co;
+    d.K = 5 * cb.Cp;
+    d.batch = B;
+    d.ksplit = 1;
+    GEMM(d);
+    HIPCHK(gn_relu_fwd(cb.cout, cb.Co, TP * cb.Co, y.p, y.ld, TP * y.ld, e->P + cb.ga, e->P + cb.be, cb.stats, B, T, cb.Co, s));
+    return 0;
+}
+
+// dy: gradient of the block output (slab view, overwritten in place with the conv-output gradient);
+// x: the block's forward input; dx: where to put the input gradient (p == nullptr: not needed)
+int conv_block_bwd(ss_engine* e, ConvBlk& cb, Slab dy, Slab x, Slab dx, hipStream_t s) {
+    const int B = e->curB, T = e->curT;
+    const long TP = T + 2 * HALO, R = (long)B * TP;
+    HIPCHK(gn_relu_bwd(cb.cout, cb.Co, TP * cb.Co, dy.p, dy.ld, TP * dy.ld, e->P + cb.ga, e->P + cb.be, cb.stats, cb.part,
+                       B, T, cb.Co, s));
+    HIPCHK(colsum_acc(cb.part, cb.Co, B, cb.Co, e->G + cb.ga, s));
+    HIPCHK(colsum_acc(cb.part + (long)B * cb.Co, cb.Co, B, cb.Co, e->G + cb.be, s));
+    HIPCHK(colsum_acc(cb.part + 2L * B * cb.Co, cb.Co, B, cb.Co, e->G + cb.b, s));
+    // weight gradient: one reduction over every slab row (halo rows of dy are zero)
+    HIPCHK(hipMemsetAsync(cb.gp, 0, (long)cb.Co * 5 * cb.Cp * 4, s));
+    GemmDesc d{};
+    d.A = {dy.p + 2 * dy.ld, dy.ld, 0, 0, 0};
+    d.B = {x.p, x.ld, 0, cb.Cp, x.ld};
+    d.C = cb.gp;
+    d.ldc = 5L * cb.Cp;
+    d.M = cb.Co;
+    d.N = 5 * cb.Cp;
+    d.K = (int)(R - 4);
+    d.batch = 1;
+    d.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM;
+    d.ksplit = pick_ksplit(d.M, d.N, d.K);
+    GEMM(d);
+    HIPCHK(conv_unpack_grad(cb.gp, cb.Co, cb.Ci, cb.Cp, e->G + cb.w, s));
+    if (dx.p) {
+        GemmDesc g{};
+        g.A = {dy.p, dy.ld, TP * dy.ld, cb.Co, dy.ld};
+        g.B = {cb.wb, 5L * cb.Co, 0, 0, 0};
+        g.C = dx.p + HALO * dx.ld;
+        g.ldc = dx.ld;
+        g.cstride = TP * dx.ld;
+        g.M = T;
+        g.N = cb.Ci;
+        g.K = 5 * cb.Co;
+        g.batch = B;
+        g.ksplit = 1;
+        GEMM(g);
+    }
+    return 0;
+}
+
+// ---- BLSTM block -------------------------------------------------------------------------------------------
+int lstm_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
+    const int B = e->curB, T = e->curT, H = lb.H;
+    const long TP = T + 2 * HALO;
+    for (int l = 0; l < lb.L; ++l) {
+        const int In = lb.in_of(l);
+        Slab xi = l == 0 ? x : Slab{lb.out[l - 1], 2L * H};
+        for (int dir = 0; dir < 2; ++dir) {
+            const LstmDir& pd = lb.pd[l * 2 + dir];
+            float* bs = lb.bsum + ((long)l * 2 + dir) * 4 * H;
+            HIPCHK(add_vec(e->P + pd.bih, e->P + pd.bhh, bs, 4 * H, s));
+            GemmDesc d{};
+            d.A = {xi.p + HALO * xi.ld, xi.ld, TP * xi.ld, 0, 0};
+            d.B = {e->P + pd.wih, In, 0, 0, 0};
+            d.C = lb.gates[l] + HALO * 8L * H + dir * 4L * H;
+            d.ldc = 8L * H;
+            d.cstride = TP * 8L * H;
+            d.bias = bs;
+            d.M = T;
+            d.N = 4 * H;
+            d.K = In;
+            d.batch = B;
+            d.ksplit = 1;
+            GEMM(d);
+        }
+        const float* wf = e->P + lb.pd[l * 2].whh;
+        const float* wb = e->P + lb.pd[l * 2 + 1].whh;
+        if (lb.big()) {
+            for (int st = 0; st < T; ++st) HIPCHK(lstm_step_fwd(lb.gates[l], wf, wb, lb.out[l], lb.csave[l], B, T, H, st, s));
+        } else {
+            HIPCHK(lstm_small_fwd(lb.gates[l], wf, wb, lb.out[l], lb.csave[l], B, T, H, s));
+        }
+    }
+    return 0;
+}
+
+// d_top: gradient slab of the last layer's output [B,TP,2H]; x: forward input; dx: input-gradient view or null
+int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hipStream_t s) {
+    const int B = e->curB, T = e->curT, H = lb.H;
+    const long TP = T + 2 * HALO, R = (long)B * TP;
+    const float* dcur = d_top;
+    for (int l = lb.L - 1; l >= 0; --l) {
+        const int In = lb.in_of(l);
+        Slab xi = l == 0 ? x : Slab{lb.out[l - 1], 2L * H};
+        float* dG = lb.gates[l];
+        const float* wf = e->P + lb.pd[l * 2].whh;
+        const float* wb = e->P + lb.pd[l * 2 + 1].whh;
+        if (lb.big()) {
+            HIPCHK(transpose2d(wf, 4 * H, H, lb.whhT, s));
+            HIPCHK(transpose2d(wb, 4 * H, H, lb.whhT + 4L * H * H, s));
+            for (int st = 0; st < T; ++st) HIPCHK(lstm_step_bwd(dG, lb.whhT, dcur, lb.csave[l], lb.dc, B, T, H, st, s));
+        } else {
+            HIPCHK(lstm_small_bwd(dG, wf, wb, dcur, lb.csave[l], B, T, H, s));
+        }
+        for (int dir = 0; dir < 2; ++dir) {
+            const LstmDir& pd = lb.pd[l * 2 + dir];
+            const float* dGd = dG + dir * 4L * H;
+            // dW_ih[n][k] = sum_r dG[r][n] * X[r][k]
+            GemmDesc a{};
+            a.A = {dGd, 8L * H, 0, 0, 0};
+            a.B = {xi.p, xi.ld, 0, 0, 0};
+            a.C = e->G + pd.wih;
+            a.ldc = In;
+            a.M = 4 * H;
+            a.N = In;
+            a.K = (int)R;
+            a.batch = 1;
+            a.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM;
+            a.ksplit = pick_ksplit(a.M, a.N, a.K);
+            GEMM(a);
+            // dW_hh[n][k] = sum_r dG[r][n] * h_prev[r][k];  h_prev = out one row earlier (fwd) / later (reverse)
+            GemmDesc h{};
+            h.A = {dir == 0 ? dGd + 8L * H : dGd, 8L * H, 0, 0, 0};
+            h.B = {dir == 0 ? lb.out[l] : lb.out[l] + 2L * H + H, 2L * H, 0, 0, 0};
+            h.C = e->G + pd.whh;
+            h.ldc = H;
+            h.M = 4 * H;
+            h.N = H;
+            h.K = (int)(R - 1);
+            h.batch = 1;
+            h.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM;
+            h.ksplit = pick_ksplit(h.M, h.N, h.K);
+            GEMM(h);
+            HIPCHK(colsum_acc(dGd, 8L * H, (int)R, 4 * H, e->G + pd.bih, s));
+            HIPCHK(hipMemcpyAsync(e->G + pd.bhh, e->G + pd.bih, 4L * H * 4, hipMemcpyDeviceToDevice, s));
+        }
+        Slab dxi = l == 0 ? dx : Slab{lb.dmid[l & 1], 2L * H};
+        if (dxi.p) {
+            for (int dir = 0; dir < 2; ++dir) {
+                const LstmDir& pd = lb.pd[l * 2 + dir];
+                GemmDesc g{};
+                g.A = {dG + dir * 4L * H, 8L * H, 0, 0, 0};
+                g.B = {e->P + pd.wih, In, 0, 0, 0};
+                g.C = dxi.p;
+                g.ldc = dxi.ld;
+                g.M = (int)R;
+                g.N = In;
+                g.K = 4 * H;
+                g.batch = 1;
+                g.flags = GEMM_TB | (dir ? GEMM_ACCUM : 0);
+                g.ksplit = 1;
+                GEMM(g);
+            }
+        }
+        dcur = dxi.p;
+    }
+    return 0;
+}
+
+// ---- whole-model schedules ---------------------------------------------------------------------------------
+int pack_weights(ss_engine* e, hipStream_t s) {
+    for (int i = 0; i < 3; ++i) {
+        if (e->c1[i].Co) CHK(conv_pack_all(e, e->c1[i], s));
+        if (e->c2[i].Co) CHK(conv_pack_all(e, e->c2[i], s));
+    }
+    CHK(conv_pack_all(e, e->ct, s));
+    return 0;
+}
+
+// Encoder_7 (G3) / Encoder_6 (G6) trunk + their LSTMs, Encoder_t, decoder, head.  Inputs already in in_mel/in_f0/org/emb.
+int forward_core(ss_engine* e, bool training, const float* scales, const int* len_seg, int draw0, hipStream_t s) {
+    const int B = e->curB, T = e->curT;
+    const long TP = T + 2 * HALO;
+    const int CE = e->CE;
+    const bool g3 = e->kind == SS_GENERATOR_3;
+    const int S7 = e->plan[0].S;
+    CHK(pack_weights(e, s));
+    const int off2 = g3 ? e->hp.dim_enc : 0;       // first channel of the f0 stream inside the fused slab
+    for (int i = 0; i < 3; ++i) {
+        float* y = training ? e->act : e->xf[i];
+        if (g3) {
+            Slab x1 = i == 0 ? Slab{e->in_mel, e->hp.dim_freq} : Slab{e->xf[i - 1], CE};
+            CHK(conv_block_fwd(e, e->c1[i], x1, Slab{y, CE}, s));
+        }
+        Slab x2 = i == 0 ? Slab{e->in_f0, e->f0p} : Slab{e->xf[i - 1] + off2, CE};
+        CHK(conv_block_fwd(e, e->c2[i], x2, Slab{y + off2, CE}, s));
+        if (training) {
+            // one warp for both streams (model.py:202-206), len_seq = max_len_pad for every utterance (:105,157,203)
+            InterpPlan& pl = e->plan[draw0 + i];
+            HIPCHK(interp_plan(pl, scales + (long)(draw0 + i) * B * S7, len_seg + (long)(draw0 + i) * B * S7, nullptr,
+                               e->hp.max_len_pad, B, s));
+            HIPCHK(interp_gather(pl, e->act + HALO * CE, CE, TP * CE, e->xf[i] + HALO * CE, CE, TP * CE, CE, B, s));
+        }
+    }
+    if (g3) CHK(lstm_fwd(e, e->l1, Slab{e->xf[2], CE}, s));
+    CHK(lstm_fwd(e, e->l2, Slab{e->xf[2] + off2, CE}, s));
+    // Encoder_t (model.py:74-89)
+    CHK(conv_block_fwd(e, e->ct, Slab{e->org, e->hp.dim_freq}, Slab{e->act_t, e->hp.dim_enc_2}, s));
+    CHK(lstm_fwd(e, e->lt, Slab{e->act_t, e->hp.dim_enc_2}, s));
+    // decoder input (model.py:301-309 / 341-347)
+    CodeSrc src[3];
+    int n = 0;
+    const ss_hparams& h = e->hp;
+    if (g3) {
+        src[n++] = {e->l1.out[1], e->d_o1, h.dim_neck, h.freq, 0};
+        src[n++] = {e->lt.out[0], e->d_ot, h.dim_neck_2, h.freq_2, 2 * h.dim_neck};
+        src[n++] = {e->l2.out[0], e->d_o2, h.dim_neck_3, h.freq_3, 2 * h.dim_neck + 2 * h.dim_neck_2};
+        HIPCHK(build_dec_in(src, n, e->emb, h.dim_spk_emb, 2 * h.dim_neck + 2 * h.dim_neck_2 + 2 * h.dim_neck_3, e->dec_in,
+                            e->dec_in_dim, B, T, s));
+    } else {
+        src[n++] = {e->lt.out[0], e->d_ot, h.dim_neck_2, h.freq_2, 0};
+        src[n++] = {e->l2.out[0], e->d_o2, h.dim_neck_3, h.freq_3, 2 * h.dim_neck_2};
+        HIPCHK(build_dec_in(src, n, nullptr, 0, e->dec_in_dim, e->dec_in, e->dec_in_dim, B, T, s));
+    }
+    CHK(lstm_fwd(e, e->ld, Slab{e->dec_in, e->dec_in_dim}, s));
+    // LinearNorm head (model.py:253 / 277)
+    const long HD = 2L * e->ld.H;
+    GemmDesc d{};
+    d.A = {e->ld.out[e->ld.L - 1] + HALO * HD, HD, TP * HD, 0, 0};
+    d.B = {e->P + e->head_w, HD, 0, 0, 0};
+    d.C = e->out_slab + HALO * e->head_out;
+    d.ldc = e->head_out;
+    d.cstride = TP * e->head_out;
+    d.bias = e->P + e->head_b;
+    d.M = T;
+    d.N = e->head_out;
+    d.K = (int)HD;
+    d.batch = B;
+    d.ksplit = 1;
+    GEMM(d);
+    e->fwd_training = training;
+    e->enc_plan0 = draw0;
+    e->have_fwd = true;
+    return 0;
+}
+
+// gradient of the loss w.r.t. the head output is in d_out_slab (halo rows zero)
+int backward_core(ss_engine* e, hipStream_t s) {
+    if (!e->have_fwd) return fail("backward without a preceding forward");
+    const int B = e->curB, T = e->curT;
+    const long TP = T + 2 * HALO, R = (long)B * TP;
+    const int CE = e->CE;
+    const bool g3 = e->kind == SS_GENERATOR_3;
+    const bool training = e->fwd_training;
+    const ss_hparams& h = e->hp;
+    HIPCHK(hipMemsetAsync(e->G, 0, e->arena * 4, s));
+    // head
+    const long HD = 2L * e->ld.H;
+    const float* h3 = e->ld.out[e->ld.L - 1];
+    {
+        GemmDesc a{};
+        a.A = {e->d_out_slab, e->head_out, 0, 0, 0};
+        a.B = {h3, HD, 0, 0, 0};
+        a.C = e->G + e->head_w;
+        a.ldc = HD;
+        a.M = e->head_out;
+        a.N = (int)HD;
+        a.K = (int)R;
+        a.batch = 1;
+        a.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM;
+        a.ksplit = pick_ksplit(a.M, a.N, a.K);
+        GEMM(a);
+        HIPCHK(colsum_acc(e->d_out_slab, e->head_out, (int)R, e->head_out, e->G + e->head_b, s));
+        GemmDesc g{};
+        g.A = {e->d_out_slab, e->head_out, 0, 0, 0};
+        g.B = {e->P + e->head_w, HD, 0, 0, 0};
+        g.C = e->d_top;
+        g.ldc = HD;
+        g.M = (int)R;
+        g.N = (int)HD;
+        g.K = e->head_out;
+        g.batch = 1;
+        g.flags = GEMM_TB;
+        g.ksplit = 1;
+        GEMM(g);
+    }
+    CHK(lstm_bwd(e, e->ld, e->d_top, Slab{e->dec_in, e->dec_in_dim}, Slab{e->d_dec_in, e->dec_in_dim}, s));
+    CodeSrc src[3];
+    int n = 0;
+    if (g3) {
+        src[n++] = {e->l1.out[1], e->d_o1, h.dim_neck, h.freq, 0};
+        src[n++] = {e->lt.out[0], e->d_ot, h.dim_neck_2, h.freq_2, 2 * h.dim_neck};
+        src[n++] = {e->l2.out[0], e->d_o2, h.dim_neck_3, h.freq_3, 2 * h.dim_neck + 2 * h.dim_neck_2};
+    } else {
+        src[n++] = {e->lt.out[0], e->d_ot, h.dim_neck_2, h.freq_2, 0};
+        src[n++] = {e->l2.out[0], e->d_o2, h.dim_neck_3, h.freq_3, 2 * h.dim_neck_2};
+    }
+    HIPCHK(dec_in_grad(src, n, e->d_dec_in, e->dec_in_dim, B, T, s));
+    const int off2 = g3 ? h.dim_enc : 0;
+    // encoder BLSTMs -> gradient of the last fused slab
+    if (g3) CHK(lstm_bwd(e, e->l1, e->d_o1, Slab{e->xf[2], CE}, Slab{e->d_xf, CE}, s));
+    CHK(lstm_bwd(e, e->l2, e->d_o2, Slab{e->xf[2] + off2, CE}, Slab{e->d_xf + off2, CE}, s));
+    // Encoder_t
+    CHK(lstm_bwd(e, e->lt, e->d_ot, Slab{e->act_t, h.dim_enc_2}, Slab{e->d_act_t, h.dim_enc_2}, s));
+    CHK(conv_block_bwd(e, e->ct, Slab{e->d_act_t, h.dim_enc_2}, Slab{e->org, h.dim_freq}, Slab{nullptr, 0}, s));
+    // conv trunk, last layer first
+    for (int i = 2; i >= 0; --i) {
+        float* dy = e->d_xf;
+        if (training) {
+            HIPCHK(interp_scatter(e->plan[e->enc_plan0 + i], e->d_xf + HALO * CE, CE, TP * CE, e->d_act + HALO * CE, CE, TP * CE, CE, B, s));
+            dy = e->d_act;
+        }
+        // input gradients of layer i become d_xf (the gradient of xf[i-1]); dy is consumed before it is overwritten
+        // only when dy != d_xf, so in eval mode the input gradient goes through d_act instead.
+        float* dxbuf = training ? e->d_xf : e->d_act;
+        if (g3) {
+            Slab x1 = i == 0 ? Slab{e->in_mel, h.dim_freq} : Slab{e->xf[i - 1], CE};
+            CHK(conv_block_bwd(e, e->c1[i], Slab{dy, CE}, x1, i > 0 ? Slab{dxbuf, CE} : Slab{nullptr, 0}, s));
+        }
+        Slab x2 = i == 0 ? Slab{e->in_f0, e->f0p} : Slab{e->xf[i - 1] + off2, CE};
+        CHK(conv_block_bwd(e, e->c2[i], Slab{dy + off2, CE}, x2, i > 0 ? Slab{dxbuf + off2, CE} : Slab{nullptr, 0}, s));
+        if (!training && i > 0) {
+            // eval mode has no resampling between layers: the next (lower) layer reads its output gradient from d_xf
+            HIPCHK(hipMemcpyAsync(e->d_xf, e->d_act, R * CE * 4, hipMemcpyDeviceToDevice, s));
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+namespace {
+
+int stage_g3_inputs(ss_engine* e, const float* x_f0, const float* x_org, const float* c_trg, int B, int T, hipStream_t s) {
+    const ss_hparams& h = e->hp;
+    const long TP = T + 2 * HALO;
+    const int CI = h.dim_freq + h.dim_f0;      // 337
+    // split x_f0 [B,T,337] into the mel slab and the (channel-padded) f0 slab (model.py:196-197)
+    HIPCHK(copy_rows(x_f0, CI, (long)T * CI, e->in_mel + HALO * h.dim_freq, h.dim_freq, TP * h.dim_freq, B, T, h.dim_freq, s));
+    HIPCHK(copy_rows(x_f0 + h.dim_freq, CI, (long)T * CI, e->in_f0 + HALO * e->f0p, e->f0p, TP * e->f0p, B, T, h.dim_f0, s));
+    HIPCHK(copy_rows(x_org, h.dim_freq, (long)T * h.dim_freq, e->org + HALO * h.dim_freq, h.dim_freq, TP * h.dim_freq, B, T,
+                     h.dim_freq, s));
+    HIPCHK(hipMemcpyAsync(e->emb, c_trg, (long)B * h.dim_spk_emb * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int export_out(ss_engine* e, float* out, int B, int T, hipStream_t s) {
+    const long TP = T + 2 * HALO;
+    const int C = e->head_out;
+    HIPCHK(copy_rows(e->out_slab + HALO * C, C, TP * C, out, C, (long)T * C, B, T, C, s));
+    return 0;
+}
+
+int import_dout(ss_engine* e, const float* d_out, int B, int T, hipStream_t s) {
+    const long TP = T + 2 * HALO;
+    const int C = e->head_out;
+    HIPCHK(copy_rows(d_out, C, (long)T * C, e->d_out_slab + HALO * C, C, TP * C, B, T, C, s));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ss_last_error(void) { return g_err.c_str(); }
+int ss_abi_version(void) { return 1; }
+
+ss_engine* ss_create(int kind, const ss_hparams* hp, int max_batch, int max_frames) {
+    if (!hp || (kind != SS_GENERATOR_3 && kind != SS_GENERATOR_6)) {
+        fail("ss_create: kind must be SS_GENERATOR_3 or SS_GENERATOR_6");
+        return nullptr;
+    }
+    if (hp->chs_grp != 16 || hp->dim_enc % 64 || hp->dim_enc_2 % 64 || hp->dim_enc_3 % 64) {
+        fail("ss_create: this build needs chs_grp == 16 and conv widths that are multiples of 64");
+        return nullptr;
+    }
+    if (2 * hp->max_len_seg > 64 || hp->max_len_pad > 512 || max_frames > 256 || max_frames < 8 || max_batch < 1) {
+        fail("ss_create: limits are 2*max_len_seg <= 64, max_len_pad <= 512, 8 <= max_frames <= 256");
+        return nullptr;
+    }
+    for (int hdim : {hp->dim_neck, hp->dim_neck_2, hp->dim_neck_3}) {
+        if (hdim != 1 && hdim != 2 && hdim != 4 && hdim != 8 && hdim != 16 && hdim != 32) {
+            fail("ss_create: bottleneck widths must be one of 1,2,4,8,16,32");
+            return nullptr;
+        }
+    }
+    ss_engine* e = new ss_engine();
+    e->kind = kind;
+    e->hp = *hp;
+    e->maxB = max_batch;
+    e->maxT = max_frames;
+    build_table(e);
+    return e;
+}
+
+void ss_destroy(ss_engine* e) { delete e; }
+
+int ss_num_params(const ss_engine* e) { return (int)e->params.size(); }
+
+int ss_param_info(const ss_engine* e, int i, char* name, int cap, long* offset, int* ndim, long shape[3]) {
+    if (i < 0 || i >= (int)e->params.size()) return fail("ss_param_info: index out of range");
+    const ParamInfo& p = e->params[i];
+    if (name && cap > 0) {
+        std::strncpy(name, p.name.c_str(), cap - 1);
+        name[cap - 1] = 0;
+    }
+    if (offset) *offset = p.offset;
+    if (ndim) *ndim = p.ndim;
+    if (shape)
+        for (int k = 0; k < 3; ++k) shape[k] = p.shape[k];
+    return 0;
+}
+
+long ss_arena_numel(const ss_engine* e) { return e->arena; }
+
+long ss_workspace_bytes(const ss_engine* e) {
+    ss_engine tmp = *e;             // dry run on a copy: carve() assigns the slab pointers
+    return tmp.carve(e->maxB, e->maxT, false);
+}
+
+int ss_bind(ss_engine* e, float* params, float* grads, float* m, float* v, void* workspace, long ws_bytes, void* stream) {
+    if (!params || !grads || !workspace) return fail("ss_bind: null arena");
+    if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v | (uintptr_t)workspace) & 255)
+        return fail("ss_bind: arenas must be 256-byte aligned");
+    const long need = ss_workspace_bytes(e);
+    if (ws_bytes < need) return fail("ss_bind: workspace smaller than ss_workspace_bytes()");
+    e->P = params;
+    e->G = grads;
+    e->Mm = m;
+    e->Vv = v;
+    e->ws = (char*)workspace;
+    e->ws_bytes = ws_bytes;
+    e->curB = e->curT = 0;
+    e->have_fwd = false;
+    HIPCHK(hipMemsetAsync(e->ws, 0, ws_bytes, S(stream)));
+    e->carve(e->maxB, e->maxT, true);
+    AdamState st{};
+    st.lr = 1e-4;
+    st.beta1 = 0.9;
+    st.beta2 = 0.999;
+    st.eps = 1e-8;
+    st.step = 0;
+    HIPCHK(hipMemcpyAsync(e->adam, &st, sizeof(st), hipMemcpyHostToDevice, S(stream)));
+    HIPCHK(hipStreamSynchronize(S(stream)));
+    return 0;
+}
+
+int ss_set_adam(ss_engine* e, double lr, double b1, double b2, double eps, long step, void* stream) {
+    if (!e->ws) return fail("engine is not bound");
+    AdamState st{};
+    st.lr = lr;
+    st.beta1 = b1;
+    st.beta2 = b2;
+    st.eps = eps;
+    st.step = step;
+    HIPCHK(hipMemcpyAsync(e->adam, &st, sizeof(st), hipMemcpyHostToDevice, S(stream)));
+    HIPCHK(hipStreamSynchronize(S(stream)));
+    return 0;
+}
+
+int ss_adam_step(ss_engine* e, float grad_scale, void* stream) {
+    if (!e->ws || !e->Mm || !e->Vv) return fail("ss_adam_step: Adam arenas are not bound");
+    HIPCHK(adam_step(e->P, e->G, e->Mm, e->Vv, e->arena, e->adam, grad_scale, S(stream)));
+    return 0;
+}
+
+int ss_zero_grads(ss_engine* e, void* stream) {
+    if (!e->G) return fail("engine is not bound");
+    HIPCHK(hipMemsetAsync(e->G, 0, e->arena * 4, S(stream)));
+    return 0;
+}
+
+int ss_g3_forward(ss_engine* e, const float* x_f0, const float* x_org, const float* c_trg, const float* scales,
+                  const int* len_seg, int B, int T, int training, float* out, void* stream) {
+    if (e->kind != SS_GENERATOR_3) return fail("ss_g3_forward on a Generator_6 engine");
+    hipStream_t s = S(stream);
+    if (training && T != e->hp.max_len_pad)
+        return fail("train-mode forward needs T == max_len_pad (InterpLnr pads to max_len_pad, model.py:370)");
+    if (training && (!scales || !len_seg)) return fail("train-mode forward needs the InterpLnr draws");
+    CHK(geometry(e, B, T, s));
+    CHK(stage_g3_inputs(e, x_f0, x_org, c_trg, B, T, s));
+    CHK(forward_core(e, training != 0, scales, len_seg, 0, s));
+    if (out) CHK(export_out(e, out, B, T, s));
+    return 0;
+}
+
+int ss_g3_backward(ss_engine* e, const float* d_out, void* stream) {
+    if (e->kind != SS_GENERATOR_3) return fail("ss_g3_backward on a Generator_6 engine");
+    hipStream_t s = S(stream);
+    if (!e->have_fwd) return fail("backward without a preceding forward");
+    CHK(import_dout(e, d_out, e->curB, e->curT, s));
+    return backward_core(e, s);
+}
+
+int ss_g3_rhythm(ss_engine* e, const float* x_org, int B, int T, float* codes, void* stream) {
+    if (e->kind != SS_GENERATOR_3) return fail("ss_g3_rhythm on a Generator_6 engine");
+    hipStream_t s = S(stream);
+    CHK(geometry(e, B, T, s));
+    const ss_hparams& h = e->hp;
+    const long TP = T + 2 * HALO;
+    HIPCHK(copy_rows(x_org, h.dim_freq, (long)T * h.dim_freq, e->org + HALO * h.dim_freq, h.dim_freq, TP * h.dim_freq, B, T,
+                     h.dim_freq, s));
+    CHK(conv_pack_all(e, e->ct, s));
+    CHK(conv_block_fwd(e, e->ct, Slab{e->org, h.dim_freq}, Slab{e->act_t, h.dim_enc_2}, s));
+    CHK(lstm_fwd(e, e->lt, Slab{e->act_t, h.dim_enc_2}, s));
+    // codes = cat(fwd[:, 7::8], bwd[:, ::8]) (model.py:84-87): reuse the decoder-input assembler on a 2H-wide row and pick t % freq == 0
+    CodeSrc src{e->lt.out[0], nullptr, h.dim_neck_2, h.freq_2, 0};
+    HIPCHK(build_dec_in(&src, 1, nullptr, 0, 2 * h.dim_neck_2, e->d_ot, 2 * h.dim_neck_2, B, T, s));
+    const int W = 2 * h.dim_neck_2;
+    HIPCHK(copy_rows(e->d_ot + HALO * W, (long)h.freq_2 * W, TP * W, codes, W, (long)(T / h.freq_2) * W, B, T / h.freq_2, W, s));
+    e->have_fwd = false;
+    return 0;
+}
+
+int ss_g6_forward(ss_engine* e, const float* x_org, const float* f0_trg, const float* scales, const int* len_seg, int B,
+                  int T, int training, float* out, void* stream) {
+    if (e->kind != SS_GENERATOR_6) return fail("ss_g6_forward on a Generator_3 engine");
+    hipStream_t s = S(stream);
+    if (training && T != e->hp.max_len_pad) return fail("train-mode forward needs T == max_len_pad (model.py:370)");
+    if (training && (!scales || !len_seg)) return fail("train-mode forward needs the InterpLnr draws");
+    CHK(geometry(e, B, T, s));
+    const ss_hparams& h = e->hp;
+    const long TP = T + 2 * HALO;
+    HIPCHK(copy_rows(x_org, h.dim_freq, (long)T * h.dim_freq, e->org + HALO * h.dim_freq, h.dim_freq, TP * h.dim_freq, B, T,
+                     h.dim_freq, s));
+    HIPCHK(copy_rows(f0_trg, h.dim_f0, (long)T * h.dim_f0, e->in_f0 + HALO * e->f0p, e->f0p, TP * e->f0p, B, T, h.dim_f0, s));
+    CHK(forward_core(e, training != 0, scales, len_seg, 0, s));
+    if (out) CHK(export_out(e, out, B, T, s));
+    return 0;
+}
+
+int ss_g6_backward(ss_engine* e, const float* d_out, void* stream) {
+    if (e->kind != SS_GENERATOR_6) return fail("ss_g6_backward on a Generator_3 engine");
+    hipStream_t s = S(stream);
+    if (!e->have_fwd) return fail("backward without a preceding forward");
+    CHK(import_dout(e, d_out, e->curB, e->curT, s));
+    return backward_core(e, s);
+}
+
+int ss_g3_train_step(ss_engine* e, const float* mel, const float* f0, const float* emb, const int* len_org,
+                     const float* scales, const int* len_seg, int B, int T, float grad_scale, int flags, float* loss,
+                     void* stream) {
+    if (e->kind != SS_GENERATOR_3) return fail("ss_g3_train_step on a Generator_6 engine");
+    hipStream_t s = S(stream);
+    const ss_hparams& h = e->hp;
+    if (T != h.max_len_pad) return fail("training needs T == max_len_pad (model.py:105,157,370)");
+    CHK(geometry(e, B, T, s));
+    const long TP = T + 2 * HALO;
+    // solver.py:160-163: resample [mel | f0] with the utterance lengths, re-quantise the f0 channel
+    HIPCHK(interp_plan(e->plan[0], scales, len_seg, len_org, 0, B, s));
+    HIPCHK(interp_quant(e->plan[0], mel, f0, h.dim_freq, e->in_mel + HALO * h.dim_freq, h.dim_freq, TP * h.dim_freq,
+                        e->in_f0 + HALO * e->f0p, e->f0p, TP * e->f0p, h.dim_f0, e->qidx, B, s));
+    HIPCHK(copy_rows(mel, h.dim_freq, (long)T * h.dim_freq, e->org + HALO * h.dim_freq, h.dim_freq, TP * h.dim_freq, B, T,
+                     h.dim_freq, s));
+    HIPCHK(hipMemcpyAsync(e->emb, emb, (long)B * h.dim_spk_emb * 4, hipMemcpyDeviceToDevice, s));
+    CHK(forward_core(e, true, scales, len_seg, 1, s));                                      // solver.py:165
+    const int C = e->head_out;
+    HIPCHK(mse_loss(e->out_slab + HALO * C, C, TP * C, e->org + HALO * C, C, TP * C, e->d_out_slab + HALO * C, C, TP * C, B, T,
+                    C, 1.0f, e->loss_part, loss, s));                                       // solver.py:166
+    CHK(backward_core(e, s));                                                               // solver.py:170-171
+    if (!(flags & SS_STEP_NO_ADAM)) CHK(ss_adam_step(e, grad_scale, stream));              // solver.py:172
+    return 0;
+}
+
+int ss_g6_train_step(ss_engine* e, const float* mel, const float* f0_onehot, const int* target_idx, const float* scales,
+                     const int* len_seg, int B, int T, float grad_scale, int flags, float* loss, void* stream) {
+    if (e->kind != SS_GENERATOR_6) return fail("ss_g6_train_step on a Generator_3 engine");
+    hipStream_t s = S(stream);
+    CHK(ss_g6_forward(e, mel, f0_onehot, scales, len_seg, B, T, 1, nullptr, stream));
+    const long TP = T + 2 * HALO;
+    const int C = e->head_out;
+    HIPCHK(ce_loss(e->out_slab + HALO * C, C, TP * C, target_idx, e->d_out_slab + HALO * C, C, TP * C, B, T, C, 1.0f,
+                   e->loss_part, loss, s));
+    CHK(backward_core(e, s));
+    if (!(flags & SS_STEP_NO_ADAM)) CHK(ss_adam_step(e, grad_scale, stream));
+    return 0;
+}
+
+int ss_interp_forward(ss_engine* e, const float* x, const int* len_seq, const float* scales, const int* len_seg, int B, int T,
+                      int C, float* y, int* i0, float* lam, int* counts, void* stream) {
+    hipStream_t s = S(stream);
+    if (!e->ws) return fail("engine is not bound");
+    if (B > e->maxB || T > e->maxT) return fail("ss_interp_forward: batch / frames exceed the engine limits");
+    if (!e->curB) CHK(geometry(e, e->maxB, e->maxT, s));
+    InterpPlan pl = e->plan[3];     // standalone calls use the last plan slot with their own T
+    pl.T = T;
+    if ((long)B * (T + 1) > (long)e->curB * (e->curT + 1)) return fail("ss_interp_forward: plan storage too small");
+    const int P = pl.P;
+    HIPCHK(interp_plan(pl, scales, len_seg, len_seq, 0, B, s));
+    HIPCHK(interp_gather(pl, x, C, (long)T * C, y, C, (long)P * C, C, B, s));
+    if (i0) HIPCHK(hipMemcpyAsync(i0, pl.i0, (long)B * P * 4, hipMemcpyDeviceToDevice, s));
+    if (lam) HIPCHK(hipMemcpyAsync(lam, pl.lam, (long)B * P * 4, hipMemcpyDeviceToDevice, s));
+    if (counts) HIPCHK(hipMemcpyAsync(counts, pl.counts, (long)B * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int ss_interp_backward(ss_engine* e, const float* dy, int B, int T, int C, float* dx, void* stream) {
+    hipStream_t s = S(stream);
+    if (!e->ws || !e->curB) return fail("ss_interp_backward without ss_interp_forward");
+    InterpPlan pl = e->plan[3];
+    pl.T = T;
+    const int P = pl.P;
+    HIPCHK(interp_scatter(pl, dy, C, (long)P * C, dx, C, (long)T * C, C, B, s));
+    return 0;
+}
+
+int ss_op_gemm(const float* a, long lda, const float* b, long ldb, float* c, long ldc, const float* bias, int M, int N, int K,
+               int flags, int ksplit, void* stream) {
+    GemmDesc d{};
+    d.A = {a, lda, 0, 0, 0};
+    d.B = {b, ldb, 0, 0, 0};
+    d.C = c;
+    d.ldc = ldc;
+    d.bias = bias;
+    d.M = M;
+    d.N = N;
+    d.K = K;
+    d.batch = 1;
+    d.ksplit = ksplit < 1 ? 1 : ksplit;
+    d.flags = (flags & 1 ? GEMM_TA : 0) | (flags & 2 ? GEMM_TB : 0) | (d.ksplit > 1 ? GEMM_ACCUM : 0);
+    HIPCHK(launch_gemm(d, S(stream)));
+    return 0;
+}
+
+int ss_debug_buffer(ss_engine* e, const char* name, float** ptr, long* rows, long* cols) {
+    auto it = e->dbg.find(name);
+    if (it == e->dbg.end()) return fail(std::string("no such buffer: ") + name);
+    *ptr = it->second.first;
+    *rows = (long)e->curB * (e->curT + 2 * HALO);
+    *cols = it->second.second;
+    return 0;
+}
+
+int ss_debug_names(ss_engine* e, char* buf, int cap) {
+    std::string all;
+    for (auto& kv : e->dbg) all += kv.first + "\n";
+    if (buf && cap > 0) {
+        std::strncpy(buf, all.c_str(), cap - 1);
+        buf[cap - 1] = 0;
+    }
+    return (int)all.size();
+}
+
+}  // extern "C"

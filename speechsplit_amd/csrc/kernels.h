@@ -1,0 +1,95 @@
+// Internal launcher prototypes for the SpeechSplit gfx950 kernels.
+//
+// Activation layout used by every kernel on the path ("haloed time-major"): [B, TP = T + 4, C] fp32, channels
+// contiguous, real frame t at row t + 2, two all-zero rows on either side of every utterance.  The halo rows give
+// the k=5 "same" convolution its zero padding, give the LSTM recurrences h(-1) = c(-1) = 0 without a branch, and
+// let every weight-gradient contraction run as ONE GEMM over the flat row index b*TP + row.
+#pragma once
+#include "common.h"
+
+namespace ss {
+
+constexpr int HALO = 2;
+
+// ---------------------------------------------------------------- interp.hip
+struct InterpPlan {
+    int S;          // segments per utterance (max_len_seq / min_len_seg + 1 = 7)
+    int ncand;      // candidate positions per segment (2 * max_len_seg = 64)
+    int P;          // output rows (max_len_pad)
+    int T;          // input rows
+    int* i0;        // [B, P]
+    float* lam;     // [B, P]
+    int* nrows;     // [B]   rows kept = min(count, P)
+    int* counts;    // [B]   un-truncated count (model.py:418)
+    int* start;     // [B, T + 1] inverse map for the backward
+};
+hipError_t interp_plan(const InterpPlan& p, const float* scales, const int* len_seg, const int* len_seq,
+                       int len_seq_const, int B, hipStream_t s);
+hipError_t interp_gather(const InterpPlan& p, const float* x, long x_ld, long x_bs, float* y, long y_ld, long y_bs, int C,
+                         int B, hipStream_t s);
+hipError_t interp_quant(const InterpPlan& p, const float* mel, const float* f0, int CM, float* ymel, long ym_ld, long ym_bs,
+                        float* yoh, long yo_ld, long yo_bs, int NOH, int* qidx, int B, hipStream_t s);
+hipError_t interp_scatter(const InterpPlan& p, const float* dy, long dy_ld, long dy_bs, float* dx, long dx_ld, long dx_bs,
+                          int C, int B, hipStream_t s);
+
+// ---------------------------------------------------------------- elementwise.hip
+// GroupNorm(16 channels per group, eps 1e-5, biased variance over 16 x T) + ReLU on rows [HALO, HALO+T) of haloed slabs.
+hipError_t gn_relu_fwd(const float* x, long x_ld, long x_bs, float* y, long y_ld, long y_bs, const float* gamma,
+                       const float* beta, float* stats /*[B, C/16, 2] mean, rstd*/, int B, int T, int C, hipStream_t s);
+// dy (grad of the ReLU output) is replaced in place by the grad of the GroupNorm input (= conv output).
+// part: [3][B][C] per-utterance partial sums of d_gamma, d_beta, d_convbias.
+hipError_t gn_relu_bwd(const float* x, long x_ld, long x_bs, float* dy, long dy_ld, long dy_bs, const float* gamma,
+                       const float* beta, const float* stats, float* part, int B, int T, int C, hipStream_t s);
+// out[c] += sum_r in[r*ld + c]   (atomic accumulate)
+hipError_t colsum_acc(const float* in, long ld, int R, int C, float* out, hipStream_t s);
+hipError_t copy_rows(const float* src, long s_ld, long s_bs, float* dst, long d_ld, long d_bs, int B, int T, int C,
+                     hipStream_t s);
+// conv weight [Co][Ci][5] -> forward pack [Co][5][Cp] (zero-filled for ci >= Ci) and input-grad pack [Ci][5][Co] (taps flipped)
+hipError_t conv_pack(const float* w, int Co, int Ci, int Cp, float* wf, float* wb, hipStream_t s);
+// packed weight grad [Co][5][Cp] -> grad arena [Co][Ci][5] (overwrite)
+hipError_t conv_unpack_grad(const float* gp, int Co, int Ci, int Cp, float* g, hipStream_t s);
+hipError_t transpose2d(const float* in, int R, int C, float* out, hipStream_t s);   // out[c][r] = in[r][c]
+// out[i] = a[i] + b[i]
+hipError_t add_vec(const float* a, const float* b, float* out, int n, hipStream_t s);
+
+struct CodeSrc {          // one encoder BLSTM output feeding the decoder input (model.py:87, 223-227, 301-309)
+    const float* o;       // [B, TP, 2*H]
+    float* d_o;           // gradient slab of the same shape (backward only)
+    int H, freq, col;     // col: first column inside the decoder input
+};
+hipError_t build_dec_in(const CodeSrc* src, int nsrc, const float* emb, int emb_dim, int emb_col, float* dec_in, int ld,
+                        int B, int T, hipStream_t s);
+hipError_t dec_in_grad(const CodeSrc* src, int nsrc, const float* d_dec_in, int ld, int B, int T, hipStream_t s);
+
+// loss = mean((tgt - out)^2) over B*T*C real elements (solver.py:166); d_out = 2 (out - tgt) / N * scale
+hipError_t mse_loss(const float* out, long o_ld, long o_bs, const float* tgt, long t_ld, long t_bs, float* d_out,
+                    long d_ld, long d_bs, int B, int T, int C, float grad_scale, float* partials, float* loss,
+                    hipStream_t s);
+// softmax cross-entropy over C classes against integer targets; mean over B*T rows
+hipError_t ce_loss(const float* logits, long o_ld, long o_bs, const int* tgt, float* d_out, long d_ld, long d_bs, int B,
+                   int T, int C, float grad_scale, float* partials, float* loss, hipStream_t s);
+
+struct AdamState {        // device-resident so a captured graph can replay the step
+    double lr, beta1, beta2, eps;
+    long step;
+    float step_size, bc2_sqrt, f_beta1, f_beta2, f_eps, pad;
+};
+hipError_t adam_step(float* p, const float* g, float* m, float* v, long n, AdamState* st, float grad_scale, hipStream_t s);
+
+// ---------------------------------------------------------------- lstm_small.hip  (hidden <= 32: whole recurrence in one launch)
+// gates: [B, TP, 8H] holds x.W_ih^T + b_ih + b_hh on entry (column = dir*4H + gate*H + j, gate order i,f,g,o) and the
+// activated gates on exit.  out: [B, TP, 2H].  csave: [B, TP, 2H] cell states.  whh: [2][4H][H].
+hipError_t lstm_small_fwd(float* gates, const float* whh_f, const float* whh_b, float* out, float* csave, int B, int T,
+                          int H, hipStream_t s);
+// d_out: [B, TP, 2H] gradient of out.  gates is replaced in place by the pre-activation gradients.
+hipError_t lstm_small_bwd(float* gates, const float* whh_f, const float* whh_b, const float* d_out, const float* csave,
+                          int B, int T, int H, hipStream_t s);
+
+// ---------------------------------------------------------------- lstm_step.hip  (hidden % 64 == 0: one launch per time step)
+hipError_t lstm_step_fwd(float* gates, const float* whh_f, const float* whh_b, float* out, float* csave, int B, int T,
+                         int H, int step, hipStream_t s);
+// whhT: [2][H][4H] (transposed recurrent weights).  dc: [2][B][H] running cell-state gradient (zeroed before step 0).
+hipError_t lstm_step_bwd(float* gates, const float* whhT, const float* d_out, const float* csave, float* dc, int B, int T,
+                         int H, int step, hipStream_t s);
+
+}  // namespace ss

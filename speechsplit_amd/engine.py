@@ -1,0 +1,213 @@
+"""Thin Python owner of one HIP engine: allocates the four parameter arenas and the workspace as torch CUDA
+tensors (PyTorch is only the allocator / stream provider here), hands their device pointers to the C ABI and
+exposes zero-copy parameter / gradient views under the reference's state_dict names."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+
+KIND = {'G3': 3, 'G6': 6}
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def draw_interp(batch, ncalls, hp, generator=None):
+    """Draw the InterpLnr randomness exactly as the reference consumes it (model.py:392-393 then 399-402, per
+    call, from the default CPU generator unless one is given).  Returns (scales f32[ncalls, B*S], len_seg i32[...])."""
+    S = hp.max_len_seq // hp.min_len_seg + 1
+    sc, ls = [], []
+    for _ in range(ncalls):
+        sc.append(torch.rand(batch * S, generator=generator) + 0.5)
+        ls.append(torch.randint(low=hp.min_len_seg, high=hp.max_len_seg, size=(batch * S, 1), generator=generator))
+    return torch.stack(sc), torch.stack(ls).reshape(ncalls, -1).to(torch.int32)
+
+
+class Engine:
+    def __init__(self, kind, hp, max_batch, max_frames=None, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError('speechsplit_amd.Engine needs a ROCm GPU (no CPU fallback)')
+        self.lib = _capi.lib()
+        self.kind = kind
+        self.hp = hp
+        self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
+        self.max_batch = int(max_batch)
+        self.max_frames = int(max_frames or hp.max_len_pad)
+        self._hps = _capi.hparams_struct(hp)
+        self.h = self.lib.ss_create(KIND[kind], C.byref(self._hps), self.max_batch, self.max_frames)
+        if not self.h:
+            raise RuntimeError('speechsplit_amd: ' + self.lib.ss_last_error().decode())
+        self.table = []
+        name = C.create_string_buffer(256)
+        off, nd, shp = C.c_long(), C.c_int(), (C.c_long * 3)()
+        for i in range(self.lib.ss_num_params(self.h)):
+            _capi.check(self.lib.ss_param_info(self.h, i, name, 256, C.byref(off), C.byref(nd), C.byref(shp)))
+            self.table.append((name.value.decode(), off.value, tuple(shp[k] for k in range(nd.value))))
+        n = self.lib.ss_arena_numel(self.h)
+        with torch.cuda.device(self.device):
+            self.params = torch.zeros(n, device=self.device)
+            self.grads = torch.zeros(n, device=self.device)
+            self.adam_m = torch.zeros(n, device=self.device)
+            self.adam_v = torch.zeros(n, device=self.device)
+            self.ws = torch.empty(self.lib.ss_workspace_bytes(self.h), dtype=torch.uint8, device=self.device)
+            self.loss = torch.zeros(1, device=self.device)
+            _capi.check(self.lib.ss_bind(self.h, _ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v),
+                                         _ptr(self.ws), self.ws.numel(), _stream()))
+
+    def __del__(self):
+        try:
+            if getattr(self, 'h', None):
+                self.lib.ss_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ parameters
+    def views(self, arena):
+        return {n: arena[o:o + int(np.prod(s))].view(*s) for n, o, s in self.table}
+
+    def param_views(self):
+        return self.views(self.params)
+
+    def grad_views(self):
+        return self.views(self.grads)
+
+    def load_weights(self, weights):
+        """weights: dict name -> numpy / tensor with the reference's shapes."""
+        pv = self.param_views()
+        for n, _, s in self.table:
+            w = weights[n]
+            w = torch.from_numpy(np.ascontiguousarray(w)) if isinstance(w, np.ndarray) else w.detach()
+            assert tuple(w.shape) == tuple(s), (n, w.shape, s)
+            pv[n].copy_(w.to(torch.float32))
+
+    def set_adam(self, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, step=0):
+        _capi.check(self.lib.ss_set_adam(self.h, lr, beta1, beta2, eps, int(step), _stream()))
+
+    # ------------------------------------------------------------------ helpers
+    def _f(self, t):
+        return t.to(device=self.device, dtype=torch.float32).contiguous()
+
+    def _i(self, t):
+        return t.to(device=self.device, dtype=torch.int32).contiguous()
+
+    def _draws(self, draws):
+        if draws is None:
+            return None, None
+        sc, ls = draws
+        return self._f(torch.as_tensor(sc)), self._i(torch.as_tensor(ls))
+
+    # ------------------------------------------------------------------ Generator_3
+    def g3_forward(self, x_f0, x_org, c_trg, draws=None, training=False):
+        B, T, _ = x_org.shape
+        x_f0, x_org, c_trg = self._f(x_f0), self._f(x_org), self._f(c_trg)
+        if c_trg.shape[0] != B:
+            c_trg = c_trg.expand(B, -1).contiguous()
+        sc, ls = self._draws(draws)
+        out = torch.empty(B, T, self.hp.dim_freq, device=self.device)
+        _capi.check(self.lib.ss_g3_forward(self.h, _ptr(x_f0), _ptr(x_org), _ptr(c_trg), _ptr(sc), _ptr(ls), B, T,
+                                           int(training), _ptr(out), _stream()))
+        return out
+
+    def g3_backward(self, d_out):
+        d_out = self._f(d_out)
+        _capi.check(self.lib.ss_g3_backward(self.h, _ptr(d_out), _stream()))
+
+    def g3_rhythm(self, x_org):
+        B, T, _ = x_org.shape
+        x_org = self._f(x_org)
+        codes = torch.empty(B, T // self.hp.freq_2, 2 * self.hp.dim_neck_2, device=self.device)
+        _capi.check(self.lib.ss_g3_rhythm(self.h, _ptr(x_org), B, T, _ptr(codes), _stream()))
+        return codes
+
+    def g3_train_step(self, mel, f0, emb, len_org, draws, grad_scale=1.0, no_adam=False):
+        B, T, _ = mel.shape
+        mel, f0, emb, len_org = self._f(mel), self._f(f0), self._f(emb), self._i(len_org)
+        sc, ls = self._draws(draws)
+        assert sc.shape[0] == 4 and ls.shape[0] == 4
+        _capi.check(self.lib.ss_g3_train_step(self.h, _ptr(mel), _ptr(f0), _ptr(emb), _ptr(len_org), _ptr(sc), _ptr(ls),
+                                              B, T, float(grad_scale), 1 if no_adam else 0, _ptr(self.loss), _stream()))
+        return self.loss
+
+    # ------------------------------------------------------------------ Generator_6
+    def g6_forward(self, x_org, f0_trg, draws=None, training=False):
+        B, T, _ = x_org.shape
+        x_org, f0_trg = self._f(x_org), self._f(f0_trg)
+        sc, ls = self._draws(draws)
+        out = torch.empty(B, T, self.hp.dim_f0, device=self.device)
+        _capi.check(self.lib.ss_g6_forward(self.h, _ptr(x_org), _ptr(f0_trg), _ptr(sc), _ptr(ls), B, T, int(training),
+                                           _ptr(out), _stream()))
+        return out
+
+    def g6_backward(self, d_out):
+        d_out = self._f(d_out)
+        _capi.check(self.lib.ss_g6_backward(self.h, _ptr(d_out), _stream()))
+
+    def g6_train_step(self, mel, f0_onehot, target_idx, draws, grad_scale=1.0, no_adam=False):
+        B, T, _ = mel.shape
+        mel, f0_onehot, target_idx = self._f(mel), self._f(f0_onehot), self._i(target_idx)
+        sc, ls = self._draws(draws)
+        _capi.check(self.lib.ss_g6_train_step(self.h, _ptr(mel), _ptr(f0_onehot), _ptr(target_idx), _ptr(sc), _ptr(ls), B, T,
+                                              float(grad_scale), 1 if no_adam else 0, _ptr(self.loss), _stream()))
+        return self.loss
+
+    # ------------------------------------------------------------------ optimiser / misc
+    def adam_step(self, grad_scale=1.0):
+        _capi.check(self.lib.ss_adam_step(self.h, float(grad_scale), _stream()))
+
+    def zero_grads(self):
+        _capi.check(self.lib.ss_zero_grads(self.h, _stream()))
+
+    def interp_forward(self, x, len_seq, scales, len_seg, want_plan=False):
+        B, T, Cc = x.shape
+        P = self.hp.max_len_pad
+        x, len_seq = self._f(x), self._i(torch.as_tensor(len_seq))
+        sc, ls = self._f(torch.as_tensor(scales)), self._i(torch.as_tensor(len_seg))
+        y = torch.empty(B, P, Cc, device=self.device)
+        i0 = torch.empty(B, P, dtype=torch.int32, device=self.device) if want_plan else None
+        lam = torch.empty(B, P, device=self.device) if want_plan else None
+        cnt = torch.empty(B, dtype=torch.int32, device=self.device) if want_plan else None
+        _capi.check(self.lib.ss_interp_forward(self.h, _ptr(x), _ptr(len_seq), _ptr(sc), _ptr(ls), B, T, Cc, _ptr(y),
+                                               _ptr(i0), _ptr(lam), _ptr(cnt), _stream()))
+        return (y, i0, lam, cnt) if want_plan else y
+
+    def interp_backward(self, dy, T):
+        B, P, Cc = dy.shape
+        dy = self._f(dy)
+        dx = torch.empty(B, T, Cc, device=self.device)
+        _capi.check(self.lib.ss_interp_backward(self.h, _ptr(dy), B, T, Cc, _ptr(dx), _stream()))
+        return dx
+
+    def debug_names(self):
+        buf = C.create_string_buffer(1 << 14)
+        self.lib.ss_debug_names(self.h, buf, len(buf))
+        return [s for s in buf.value.decode().split('\n') if s]
+
+    def debug_buffer(self, name, B, T):
+        """Real frames of an internal haloed slab as a [B, T, C] tensor (copy)."""
+        p, rows, cols = C.c_void_p(), C.c_long(), C.c_long()
+        _capi.check(self.lib.ss_debug_buffer(self.h, name.encode(), C.byref(p), C.byref(rows), C.byref(cols)))
+        off = p.value - self.ws.data_ptr()
+        n = rows.value * cols.value
+        flat = self.ws[off:off + 4 * n].view(torch.float32)
+        return flat.view(B, T + 4, cols.value)[:, 2:2 + T].clone()
+
+
+def gemm(a, b, bias=None, ta=False, tb=False, ksplit=1):
+    """Test hook for the MFMA GEMM: C[M,N] = A(m,k) B(n,k) (+bias).  a: [M,K] or [K,M] if ta; b: [N,K] or [K,N] if tb."""
+    lib = _capi.lib()
+    M = a.shape[1] if ta else a.shape[0]
+    K = a.shape[0] if ta else a.shape[1]
+    N = b.shape[1] if tb else b.shape[0]
+    assert (b.shape[0] if tb else b.shape[1]) == K
+    c = torch.zeros(M, N, device=a.device)
+    _capi.check(lib.ss_op_gemm(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(c), N, _ptr(bias), M, N, K,
+                               (1 if ta else 0) | (2 if tb else 0), ksplit, _stream()))
+    return c
