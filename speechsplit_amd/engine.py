@@ -200,14 +200,14 @@ class Engine:
         return flat.view(B, T + 4, cols.value)[:, 2:2 + T].clone()
 
 
-def gemm(a, b, bias=None, ta=False, tb=False, ksplit=1):
+def gemm(a, b, bias=None, ta=False, tb=False, ksplit=1, out=None):
     """Test hook for the MFMA GEMM: C[M,N] = A(m,k) B(n,k) (+bias).  a: [M,K] or [K,M] if ta; b: [N,K] or [K,N] if tb."""
     lib = _capi.lib()
     M = a.shape[1] if ta else a.shape[0]
     K = a.shape[0] if ta else a.shape[1]
     N = b.shape[1] if tb else b.shape[0]
     assert (b.shape[0] if tb else b.shape[1]) == K
-    c = torch.zeros(M, N, device=a.device)
+    c = torch.zeros(M, N, device=a.device) if out is None else out
     _capi.check(lib.ss_op_gemm(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(c), N, _ptr(bias), M, N, K,
                                (1 if ta else 0) | (2 if tb else 0), ksplit, _stream()))
     return c
