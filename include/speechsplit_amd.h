@@ -32,6 +32,7 @@ typedef struct ss_hparams {
 
 #define SS_GENERATOR_3 3 /* model.py:283 Generator_3 = Encoder_7 | Encoder_t | Decoder_3 */
 #define SS_GENERATOR_6 6 /* model.py:324 Generator_6 = Encoder_t | Encoder_6 | Decoder_4 */
+#define SS_INTERP_ONLY 0 /* model.py:355 a bare InterpLnr module: no parameters, ss_interp_* only (arenas may be NULL) */
 
 #define SS_STEP_NO_ADAM 1 /* ss_*_train_step: stop after backward (data-parallel: all-reduce grads, then ss_adam_step) */
 

@@ -33,6 +33,8 @@ def conv_gn_relu(x_nct, P, prefix, chs_grp=16, tap=None):
     if tap:
         _tap(tap, y, nct=True)
     y = F.group_norm(y, w.shape[0] // chs_grp, P[prefix + '.1.weight'], P[prefix + '.1.bias'], eps=1e-5)
+    if tap and TAP is not None:
+        TAP['zmin:' + tap] = float(y.detach().abs().min())     # distance of the closest pre-activation to the ReLU kink
     return F.relu(y)
 
 

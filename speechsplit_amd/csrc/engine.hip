@@ -163,6 +163,10 @@ struct TableBuilder {
 void build_table(ss_engine* e) {
     const ss_hparams& h = e->hp;
     TableBuilder tb{e->params};
+    if (e->kind == SS_INTERP_ONLY) {
+        e->arena = 0;
+        return;
+    }
     if (e->kind == SS_GENERATOR_3) {      // registration order of model.py:161-191, 59-71, 244-247, 288-290
         for (int i = 0; i < 3; ++i)
             tb.conv("encoder_1.convolutions_1." + std::to_string(i), i == 0 ? h.dim_freq : h.dim_enc, h.dim_enc, e->c1[i]);
@@ -248,6 +252,20 @@ long ss_engine::carve(int B, int T, bool assign) {
         }
     };
     adam = (AdamState*)take(sizeof(AdamState));        // first: survives geometry changes (offset 0)
+    if (kind == SS_INTERP_ONLY) {                      // a bare InterpLnr module only needs one plan
+        for (int i = 0; i < 4; ++i) {
+            plan[i].S = hp.max_len_seq / hp.min_len_seg + 1;
+            plan[i].ncand = 2 * hp.max_len_seg;
+            plan[i].P = hp.max_len_pad;
+            plan[i].T = T;
+        }
+        plan[3].i0 = (int*)take((long)B * hp.max_len_pad * 4);
+        plan[3].lam = (float*)take((long)B * hp.max_len_pad * 4);
+        plan[3].nrows = (int*)take((long)B * 4);
+        plan[3].counts = (int*)take((long)B * 4);
+        plan[3].start = (int*)take((long)B * (T + 1) * 4);
+        return off;
+    }
     in_mel = slab("in.mel", hp.dim_freq);
     in_f0 = slab("in.f0", f0p);
     org = slab("in.org", hp.dim_freq);
@@ -297,8 +315,8 @@ hipStream_t S(void* s) { return (hipStream_t)s; }
 
 int geometry(ss_engine* e, int B, int T, hipStream_t s) {
     if (!e->ws) return fail("engine is not bound (call ss_bind first)");
-    if (B < 1 || B > e->maxB || T < 8 || T > e->maxT) return fail("batch / frames outside the limits given to ss_create");
-    if (T % e->hp.freq || T % e->hp.freq_2 || T % e->hp.freq_3)
+    if (B < 1 || B > e->maxB || T < 1 || T > e->maxT) return fail("batch / frames outside the limits given to ss_create");
+    if (e->kind != SS_INTERP_ONLY && (T % e->hp.freq || T % e->hp.freq_2 || T % e->hp.freq_3))
         return fail("T must be a multiple of the code down-sampling factors (model.py:87,223-227)");
     if (B == e->curB && T == e->curT) return 0;
     long need;
@@ -705,8 +723,8 @@ const char* ss_last_error(void) { return g_err.c_str(); }
 int ss_abi_version(void) { return 1; }
 
 ss_engine* ss_create(int kind, const ss_hparams* hp, int max_batch, int max_frames) {
-    if (!hp || (kind != SS_GENERATOR_3 && kind != SS_GENERATOR_6)) {
-        fail("ss_create: kind must be SS_GENERATOR_3 or SS_GENERATOR_6");
+    if (!hp || (kind != SS_GENERATOR_3 && kind != SS_GENERATOR_6 && kind != SS_INTERP_ONLY)) {
+        fail("ss_create: kind must be SS_GENERATOR_3, SS_GENERATOR_6 or SS_INTERP_ONLY");
         return nullptr;
     }
     if (hp->chs_grp != 16 || hp->dim_enc % 64 || hp->dim_enc_2 % 64 || hp->dim_enc_3 % 64) {
@@ -758,7 +776,7 @@ long ss_workspace_bytes(const ss_engine* e) {
 }
 
 int ss_bind(ss_engine* e, float* params, float* grads, float* m, float* v, void* workspace, long ws_bytes, void* stream) {
-    if (!params || !grads || !workspace) return fail("ss_bind: null arena");
+    if (!workspace || (e->kind != SS_INTERP_ONLY && (!params || !grads))) return fail("ss_bind: null arena");
     if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v | (uintptr_t)workspace) & 255)
         return fail("ss_bind: arenas must be 256-byte aligned");
     const long need = ss_workspace_bytes(e);

@@ -1,0 +1,117 @@
+"""Host-side batch producer with the reference's interface (reference data_loader.py:14-175): ``get_loader(hparams)``
+returns an iterable of ``(melsp f32[B,192,80], spk_emb f32[B,82], pitch f32[B,192,1], len_org int64[B])``.
+
+This is the step BEFORE the hot path; it is restated so that the reference's
+``main.py`` finds the names it imports.  The collator reproduces the reference's intent -- random crop of
+min_len_seq..max_len_seq frames, clip to [0,1], zero-pad mel / pad F0 with -1e10 -- without the stray
+``pdb.set_trace()`` at data_loader.py:108.  ``SyntheticUtterances`` stands in when the corpus
+(assets/spmel, assets/raptf0: download links only) is absent.
+"""
+import os
+import pickle
+
+import numpy as np
+import torch
+from torch.utils import data
+from torch.utils.data.sampler import Sampler
+
+
+class Utterances(data.Dataset):
+    """train.pkl = list of [speaker, onehot82, relpath...] (make_metadata.py); loads every .npy into RAM."""
+
+    def __init__(self, root_dir, feat_dir, mode):
+        self.root_dir, self.feat_dir, self.mode = root_dir, feat_dir, mode
+        meta = pickle.load(open(os.path.join(root_dir, 'train.pkl'), 'rb'))
+        self.items = []
+        for sbmt in meta:
+            spk, emb = sbmt[0], sbmt[1]
+            for rel in sbmt[2:]:
+                sp = np.load(os.path.join(root_dir, rel))
+                f0 = np.load(os.path.join(feat_dir, rel))
+                self.items.append((sp, np.asarray(emb, np.float32), f0))
+        self.num_tokens = len(self.items)
+
+    def __getitem__(self, index):
+        return self.items[index]
+
+    def __len__(self):
+        return self.num_tokens
+
+
+class SyntheticUtterances(data.Dataset):
+    """Seeded stand-in corpus: `n` utterances of 150-400 frames, mel in [0,1], normalised log-F0 in [0,1] with
+    ~40 % unvoiced frames (-1e10), one-hot speaker embedding over 82."""
+
+    def __init__(self, n=64, seed=0):
+        rs = np.random.RandomState(seed)
+        self.items = []
+        for _ in range(n):
+            L = int(rs.randint(150, 400))
+            mel = rs.rand(L, 80).astype(np.float32)
+            f0 = rs.rand(L).astype(np.float32)
+            f0[rs.rand(L) < 0.4] = -1e10
+            emb = np.zeros(82, np.float32)
+            emb[rs.randint(0, 82)] = 1
+            self.items.append((mel, emb, f0))
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+    def __len__(self):
+        return len(self.items)
+
+
+class MyCollator(object):
+    def __init__(self, hparams):
+        self.min_len_seq, self.max_len_seq, self.max_len_pad = hparams.min_len_seq, hparams.max_len_seq, hparams.max_len_pad
+
+    def __call__(self, batch):
+        mels, embs, f0s, lens = [], [], [], []
+        for mel, emb, f0 in batch:
+            n = int(np.random.randint(self.min_len_seq, self.max_len_seq + 1))          # data_loader.py:106
+            n = min(n, self.max_len_pad)
+            left = int(np.random.randint(0, max(len(mel) - n, 1)))                       # :107
+            a = np.clip(mel[left:left + n], 0, 1)                                        # :110-113
+            c = f0[left:left + n]
+            mels.append(np.pad(a, ((0, self.max_len_pad - a.shape[0]), (0, 0)), 'constant'))           # :115
+            f0s.append(np.pad(c[:, None], ((0, self.max_len_pad - c.shape[0]), (0, 0)), 'constant',
+                              constant_values=-1e10))                                                  # :116
+            embs.append(emb)
+            lens.append(a.shape[0])
+        return (torch.from_numpy(np.stack(mels).astype(np.float32)), torch.from_numpy(np.stack(embs)),
+                torch.from_numpy(np.stack(f0s).astype(np.float32)), torch.from_numpy(np.asarray(lens, np.int64)))
+
+
+class MultiSampler(Sampler):
+    """Each index `n_repeats` times per pass, optionally shuffled (data_loader.py:133-151)."""
+
+    def __init__(self, num_samples, n_repeats, shuffle=False):
+        self.num_samples, self.n_repeats, self.shuffle = num_samples, n_repeats, shuffle
+        self.sample_idx_array = None
+
+    def gen_sample_array(self):
+        arr = torch.arange(self.num_samples, dtype=torch.int64).repeat(self.n_repeats)
+        if self.shuffle:
+            arr = arr[torch.randperm(len(arr))]
+        self.sample_idx_array = arr
+        return arr
+
+    def __iter__(self):
+        return iter(self.gen_sample_array())
+
+    def __len__(self):
+        return self.num_samples * self.n_repeats
+
+
+def get_loader(hparams, dataset=None):
+    """data_loader.py:156-175.  Falls back to the synthetic corpus when hparams.root_dir has no train.pkl."""
+    if dataset is None:
+        if os.path.exists(os.path.join(hparams.root_dir, 'train.pkl')):
+            dataset = Utterances(hparams.root_dir, hparams.feat_dir, hparams.mode)
+        else:
+            print(f'[speechsplit_amd] {hparams.root_dir}/train.pkl not found: using the synthetic corpus')
+            dataset = SyntheticUtterances(max(4 * hparams.batch_size, 64))
+    sampler = MultiSampler(len(dataset), hparams.samplier, shuffle=hparams.shuffle)
+    return data.DataLoader(dataset=dataset, batch_size=hparams.batch_size, sampler=sampler,
+                           num_workers=hparams.num_workers, drop_last=True, pin_memory=torch.cuda.is_available(),
+                           collate_fn=MyCollator(hparams))

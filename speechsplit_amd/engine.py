@@ -8,7 +8,7 @@ import torch
 
 from . import _capi
 
-KIND = {'G3': 3, 'G6': 6}
+KIND = {'G3': 3, 'G6': 6, 'interp': 0}
 
 
 def _ptr(t):

@@ -1,0 +1,165 @@
+"""Host-side mirror of the reference's ``Solver`` (boundary B2; reference solver.py:18-269).
+
+Same constructor (``Solver(vcc_loader, config, hparams)``), same ``config`` attributes, same ``train()`` loop
+structure, log line and checkpoint files; the six statements of the step body (solver.py:157-172) are ONE C-ABI
+call into the HIP engine (``ss_g3_train_step``).  Out of scope here, as in SURVEY.md section 2: tensorboard, the
+matplotlib ablation plots and the demo.pkl validation block (solver.py:206-269).
+
+Data parallelism is new (the reference is single-device): under ``torchrun`` each rank takes its shard of every
+batch and of the resampling draws, gradients are summed with one RCCL all-reduce over the flat arena, and every
+rank applies the same Adam update (speechsplit_amd/dist.py).
+"""
+import datetime
+import os
+import time
+
+import torch
+
+from . import dist as _dist
+from .engine import draw_interp
+from .model import Generator_3 as Generator
+from .model import InterpLnr
+
+
+class Solver(object):
+    """Solver for training"""
+
+    def __init__(self, vcc_loader, config, hparams):
+        self.vcc_loader = vcc_loader
+        self.hparams = hparams
+        self.num_iters = config.num_iters
+        self.g_lr = config.g_lr
+        self.beta1 = config.beta1
+        self.beta2 = config.beta2
+        self.resume_iters = config.resume_iters
+        self.use_tensorboard = getattr(config, 'use_tensorboard', False)
+        self.rank, self.local_rank, self.world = _dist.world_info()
+        self.use_cuda = torch.cuda.is_available()
+        if not self.use_cuda:
+            raise RuntimeError('speechsplit_amd.Solver needs a ROCm GPU (the engine has no CPU fallback)')
+        dev_id = self.local_rank if self.world > 1 else config.device_id
+        self.device = torch.device('cuda:{}'.format(dev_id))
+        torch.cuda.set_device(self.device)
+        self.log_dir = config.log_dir
+        self.sample_dir = config.sample_dir
+        self.model_save_dir = config.model_save_dir
+        self.log_step = config.log_step
+        self.sample_step = config.sample_step
+        self.model_save_step = config.model_save_step
+        self.build_model()
+
+    def build_model(self):
+        per_rank = self.hparams.batch_size // max(self.world, 1)
+        self.G = Generator(self.hparams, max_batch=per_rank)
+        self.Interp = InterpLnr(self.hparams)
+        self.print_network(self.G, 'G')
+        self.G.to(self.device)                      # creates the engine, parameters now live in its arena
+        self.eng = self.G._eng
+        self.eng.set_adam(self.g_lr, self.beta1, self.beta2, 1e-8, 0)      # solver.py:62
+        self.step_count = 0
+        if self.world > 1:
+            _dist.init('nccl', self.device)
+            import torch.distributed as dist
+            dist.broadcast(self.eng.params, src=0)   # identical replicas
+
+    def print_network(self, model, name):
+        num_params = sum(p.numel() for p in model.parameters())
+        if self.rank == 0:
+            print(model)
+            print(name)
+            print("The number of parameters: {}".format(num_params))
+
+    # ---- checkpoints in the reference's format: {'model': state_dict, 'optimizer': Adam.state_dict()} (solver.py:198-202)
+    def optimizer_state_dict(self):
+        mv, vv = self.eng.views(self.eng.adam_m), self.eng.views(self.eng.adam_v)
+        state = {i: {'step': torch.tensor(float(self.step_count)), 'exp_avg': mv[n].detach().cpu().clone(),
+                     'exp_avg_sq': vv[n].detach().cpu().clone()} for i, n in enumerate(self.G._names)}
+        group = {'lr': self.g_lr, 'betas': (self.beta1, self.beta2), 'eps': 1e-8, 'weight_decay': 0, 'amsgrad': False,
+                 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                 'params': list(range(len(self.G._names)))}
+        return {'state': state if self.step_count else {}, 'param_groups': [group]}
+
+    def load_optimizer_state_dict(self, sd):
+        group = sd['param_groups'][0]
+        self.g_lr = group['lr']
+        self.beta1, self.beta2 = group['betas']
+        mv, vv = self.eng.views(self.eng.adam_m), self.eng.views(self.eng.adam_v)
+        step = 0
+        for i, n in enumerate(self.G._names):
+            st = sd['state'].get(i)
+            if st is None:
+                continue
+            mv[n].copy_(st['exp_avg'])
+            vv[n].copy_(st['exp_avg_sq'])
+            step = int(st['step'])
+        self.step_count = step
+        self.eng.set_adam(self.g_lr, self.beta1, self.beta2, group.get('eps', 1e-8), step)
+
+    def save_model(self, it):
+        G_path = os.path.join(self.model_save_dir, '{}-G.ckpt'.format(it))
+        torch.save({'model': {k: v.detach().cpu() for k, v in self.G.state_dict().items()},
+                    'optimizer': self.optimizer_state_dict()}, G_path)
+
+    def restore_model(self, resume_iters):
+        print('Loading the trained models from step {}...'.format(resume_iters))
+        G_path = os.path.join(self.model_save_dir, '{}-G.ckpt'.format(resume_iters))
+        ckpt = torch.load(G_path, map_location=lambda storage, loc: storage, weights_only=False)
+        self.G.load_state_dict(ckpt['model'])
+        self.load_optimizer_state_dict(ckpt['optimizer'])
+
+    # ---- one iteration of solver.py:141-172 on a collated batch
+    def train_on_batch(self, batch, draws=None):
+        x_real_org, emb_org, f0_org, len_org = batch
+        Bg = x_real_org.shape[0]
+        if draws is None:
+            draws = draw_interp(Bg, 4, self.hparams)                 # same generator calls, same order as the reference
+        if self.world > 1:
+            x_real_org, emb_org, f0_org, len_org = _dist.shard_batch(batch, self.rank, self.world)
+            draws = _dist.shard_draws(draws[0], draws[1], Bg, self.rank, self.world)
+        to = dict(device=self.device, non_blocking=True)
+        loss = self.eng.g3_train_step(x_real_org.to(**to), f0_org.to(**to), emb_org.to(**to), len_org.to(**to), draws,
+                                      no_adam=self.world > 1)
+        if self.world > 1:
+            scale = _dist.allreduce_mean_(self.eng.grads, self.world)
+            self.eng.adam_step(scale)
+        self.step_count += 1
+        return loss
+
+    def train(self):
+        data_loader = self.vcc_loader
+        data_iter = iter(data_loader)
+        start_iters = 0
+        if self.resume_iters:
+            print('Resuming ...')
+            start_iters = self.resume_iters
+            self.num_iters += self.resume_iters
+            self.restore_model(self.resume_iters)
+        if self.rank == 0:
+            print('Current learning rates, g_lr: {}.'.format(self.g_lr))
+            print('Start training...')
+        keys = ['G/loss_id']
+        start_time = time.time()
+        for i in range(start_iters, self.num_iters):
+            try:
+                batch = next(data_iter)
+            except StopIteration:
+                data_iter = iter(data_loader)
+                batch = next(data_iter)
+            self.G = self.G.train()
+            loss_dev = self.train_on_batch(batch)
+            if (i + 1) % self.log_step == 0:
+                loss = {'G/loss_id': loss_dev.item()}             # the only device sync, on log steps
+                if self.world > 1:
+                    import torch.distributed as dist
+                    t = loss_dev.clone()
+                    dist.all_reduce(t)
+                    loss['G/loss_id'] = t.item() / self.world
+                if self.rank == 0:
+                    et = str(datetime.timedelta(seconds=time.time() - start_time))[:-7]
+                    log = "Elapsed [{}], Iteration [{}/{}]".format(et, i + 1, self.num_iters)
+                    for tag in keys:
+                        log += ", {}: {:.8f}".format(tag, loss[tag])
+                    print(log)
+            if (i + 1) % self.model_save_step == 0 and self.rank == 0:
+                self.save_model(i + 1)
+                print('Saved model checkpoints into {}...'.format(self.model_save_dir))

@@ -1,0 +1,188 @@
+"""CPU-only checks of the C-ABI library and of the host-side mirror of the reference's Python surface.
+No kernel is launched here (there is no GPU in the build container)."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import interp_np, weights as W
+from oracle.gen_fixtures import draws_for
+from speechsplit_amd import _capi, data_loader, dist, hparams as HP, utils
+from speechsplit_amd.engine import draw_interp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _capi.lib()
+    header = open(os.path.join(ROOT, 'include', 'speechsplit_amd.h')).read()
+    declared = set(re.findall(r'\b(ss_[a-z0-9_]+)\s*\(', header))
+    declared -= {'ss_engine', 'ss_hparams'}
+    assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ss_abi_version() == 1
+
+
+@pytest.mark.parametrize('kind', ['G3', 'G6'])
+def test_param_table_matches_reference(gold_dir, kind):
+    lib = _capi.lib()
+    hp = HP.default_hparams()
+    hps = _capi.hparams_struct(hp)
+    h = lib.ss_create(3 if kind == 'G3' else 6, C.byref(hps), 4, 192)
+    assert h
+    ref = json.load(open(os.path.join(gold_dir, f'keys_{kind}.json')))
+    shapes = dict(zip(ref['keys'], ref['shapes']))
+    name = C.create_string_buffer(256)
+    off, nd, shp = C.c_long(), C.c_int(), (C.c_long * 3)()
+    names, total, prev_end = [], 0, 0
+    for i in range(lib.ss_num_params(h)):
+        assert lib.ss_param_info(h, i, name, 256, C.byref(off), C.byref(nd), C.byref(shp)) == 0
+        n = name.value.decode()
+        s = [shp[k] for k in range(nd.value)]
+        assert s == shapes[n], n
+        assert off.value % 4 == 0 and off.value >= prev_end          # 16-byte aligned, non-overlapping, ordered
+        prev_end = off.value + int(np.prod(s))
+        total += int(np.prod(s))
+        names.append(n)
+    assert names == ref['params']                                     # parameters() order of the reference
+    assert total == ref['numel']
+    assert lib.ss_arena_numel(h) >= prev_end
+    assert lib.ss_workspace_bytes(h) > 0
+    lib.ss_destroy(h)
+
+
+def test_create_rejects_bad_arguments():
+    lib = _capi.lib()
+    hps = _capi.hparams_struct(HP.default_hparams())
+    assert not lib.ss_create(5, C.byref(hps), 4, 192)
+    assert b'kind' in lib.ss_last_error()
+    bad = _capi.hparams_struct(HP.default_hparams(chs_grp=8))
+    assert not lib.ss_create(3, C.byref(bad), 4, 192)
+    assert not lib.ss_create(3, C.byref(hps), 0, 192)
+
+
+def test_unbound_engine_fails_loudly():
+    lib = _capi.lib()
+    hps = _capi.hparams_struct(HP.default_hparams())
+    h = lib.ss_create(3, C.byref(hps), 2, 192)
+    assert lib.ss_adam_step(h, 1.0, None) != 0
+    assert lib.ss_g3_forward(h, None, None, None, None, None, 2, 192, 0, None, None) != 0
+    assert b'bound' in lib.ss_last_error()
+    lib.ss_destroy(h)
+
+
+def test_engine_refuses_to_run_without_gpu():
+    from speechsplit_amd.engine import Engine
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(RuntimeError):
+        Engine('G3', HP.default_hparams(), 2)
+
+
+def test_hparams_bag():
+    hp = HP.default_hparams()
+    assert hp.max_len_pad == 192 and hp.dim_f0 == 257 and hp.freq == 8
+    hp2 = hp.copy().parse('max_len_pad=128,batch_size=64')
+    assert hp2.max_len_pad == 128 and hp2.batch_size == 64 and hp.max_len_pad == 192
+    assert 'max_len_pad' in HP.hparams_debug_string()
+    with pytest.raises(ValueError):
+        hp.copy().parse('nope=1')
+
+
+def test_quantizers_match_reference_fixture(gold_dir):
+    z = np.load(os.path.join(gold_dir, 'quantize.npz'))
+    enc, idx = utils.quantize_f0_torch(torch.from_numpy(z['x']))
+    assert np.array_equal(idx.numpy(), z['idx'])
+    assert np.array_equal(enc.argmax(-1).numpy(), z['onehot_argmax'])
+    e2, i2 = utils.quantize_f0_numpy(z['x'][1])
+    assert np.array_equal(i2, z['idx'][1]) and e2.shape == (64, 257)
+    x, pad = utils.pad_seq_to_2(np.ones((1, 100, 80), np.float32), 192)
+    assert x.shape == (1, 192, 80) and pad == 92
+
+
+def test_draws_replay_reference_rng_order():
+    """speechsplit_amd.engine.draw_interp must consume the CPU generator exactly as the reference does
+    (rand(B*7) then randint(19,32,(B*7,1)) per InterpLnr call) -- checked against the fixture generator's replay."""
+    hp = HP.default_hparams()
+    ref = draws_for(77, 6, 4)
+    torch.manual_seed(77)
+    sc, ls = draw_interp(6, 4, hp)
+    for i in range(4):
+        assert np.array_equal(sc[i].numpy(), ref[i][0])
+        assert np.array_equal(ls[i].numpy(), ref[i][1].astype(np.int32))
+
+
+@pytest.mark.parametrize('kind', ['G3', 'G6'])
+def test_module_state_dict_matches_reference(gold_dir, kind):
+    from speechsplit_amd import model
+    ref = json.load(open(os.path.join(gold_dir, f'keys_{kind}.json')))
+    cls = model.Generator_3 if kind == 'G3' else model.Generator_6
+    torch.manual_seed(0)
+    m = cls(HP.default_hparams())
+    sd = m.state_dict()
+    assert list(sd.keys()) == ref['keys']
+    assert [list(v.shape) for v in sd.values()] == ref['shapes']
+    assert [n for n, _ in m.named_parameters()] == ref['params']
+    assert m.train() is m and m.eval() is m
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 192, 337), torch.zeros(1, 192, 80), torch.zeros(1, 82)) if kind == 'G3' else \
+            m(torch.zeros(1, 192, 80), torch.zeros(1, 192, 257))
+    # an optimizer built before .to(device) (solver.py:62-65) must see the same Parameter objects afterwards
+    ids = [id(p) for p in m.parameters()]
+    m.float()
+    assert ids == [id(p) for p in m.parameters()]
+
+
+def test_module_init_follows_reference_distributions(gold_dir):
+    """Initialiser bounds (xavier-uniform gain sqrt(2) for convs, 1 for the head, U(+-1/sqrt(hidden)) for LSTMs,
+    GroupNorm (1, 0)) against statistics of the reference constructed with torch.manual_seed(0)."""
+    from speechsplit_amd import model
+    ref = json.load(open(os.path.join(gold_dir, 'init_seed0_G3.json')))
+    torch.manual_seed(0)
+    m = model.Generator_3(HP.default_hparams())
+    for n, p in m.named_parameters():
+        a = p.detach()
+        r = ref[n]
+        if n.endswith('.1.weight'):
+            assert float(a.min()) == 1.0 == float(a.max())
+        elif n.endswith('.1.bias'):
+            assert float(a.abs().max()) == 0.0
+        else:
+            k = a.numel()
+            if k >= 256:
+                assert abs(float(a.abs().max()) - r['amax']) <= 0.05 * r['amax'] + 1e-3, n  # same uniform bound
+            if k >= 16:
+                assert abs(float(a.double().norm()) - r['l2']) <= (0.03 + 2.0 / k ** 0.5) * r['l2'], n   # same variance
+
+
+def test_collator_and_loader_contract():
+    hp = HP.default_hparams(batch_size=4)
+    np.random.seed(0)
+    loader = data_loader.get_loader(hp, dataset=data_loader.SyntheticUtterances(16, seed=1))
+    mel, emb, f0, ln = next(iter(loader))
+    assert mel.shape == (4, 192, 80) and emb.shape == (4, 82) and f0.shape == (4, 192, 1) and ln.shape == (4,)
+    assert mel.dtype == torch.float32 and ln.dtype == torch.int64
+    assert float(mel.min()) >= 0 and float(mel.max()) <= 1
+    for b in range(4):
+        L = int(ln[b])
+        assert 64 <= L <= 128
+        assert (f0[b, L:] == -1e10).all() and (mel[b, L:] == 0).all()
+    assert len(data_loader.MultiSampler(5, 8)) == 40
+
+
+def test_shard_helpers():
+    lo, hi = dist.shard_range(8, 1, 2)
+    assert (lo, hi) == (4, 8)
+    with pytest.raises(ValueError):
+        dist.shard_range(7, 0, 2)
+    sc = torch.arange(4 * 8 * 7, dtype=torch.float32).view(4, 56)
+    ls = sc.to(torch.int32)
+    a, b = dist.shard_draws(sc, ls, 8, 1, 2)
+    assert a.shape == (4, 28) and torch.equal(a, sc[:, 28:]) and torch.equal(b, ls[:, 28:])
+    batch = (torch.zeros(8, 3), torch.zeros(8, 2), torch.zeros(8, 1), torch.arange(8))
+    assert dist.shard_batch(batch, 0, 4)[3].tolist() == [0, 1]

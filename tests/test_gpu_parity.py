@@ -1,0 +1,325 @@
+"""Parity of the HIP engine (through the C ABI) against the CPU oracle and the reference-generated golden vectors.
+Runs on the GPU box: pytest -m gpu.
+
+Tolerances: index path bit-exact; fp32 values within 1e-4 relative (max-norm per tensor), the bar BASELINE.json's
+north_star states for the mel reconstruction, applied here to outputs, losses, gradients and updated weights.
+
+ReLU kink note: a GroupNorm output that lands within fp32 rounding of 0 can take the other ReLU branch than the
+oracle's, which moves the gradients of that one channel by O(1/T).  Tests that compare every gradient element
+pick seeded inputs whose closest pre-activation is >= 2e-5 away from the kink (the oracle reports the margin).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import interp_np, ref_model, weights as W
+from oracle.gen_fixtures import draws_for, synth_batch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+TOL = 1e-4
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.fixture(scope='module')
+def E():
+    from speechsplit_amd import engine
+    return engine
+
+
+_ENGINES = {}
+
+
+def get_engine(E, kind, T, B=8):
+    key = (kind, T)
+    if key not in _ENGINES or _ENGINES[key].max_batch < B:
+        _ENGINES[key] = E.Engine(kind, W.default_hparams(max_len_pad=T), B, T)
+    return _ENGINES[key]
+
+
+def stack_draws(draws):
+    return np.stack([d[0] for d in draws]), np.stack([d[1] for d in draws])
+
+
+def kink_safe_case(hp, weights, B, T, first_seed, tries=8):
+    """Seeded batch + draws whose GroupNorm outputs keep >= 2e-5 distance from the ReLU kink in the oracle."""
+    P = ref_model.as_params(weights, False)
+    for seed in range(first_seed, first_seed + tries):
+        mel, f0, emb, lens = synth_batch(seed, B, T, 64 if T == 128 else 96)
+        draws = draws_for(seed + 100, B, 4)
+        ref_model.TAP = {}
+        with torch.no_grad():
+            ref_model.g3_loss(P, hp, mel, f0, emb, lens.numpy(), draws)
+        tap, ref_model.TAP = ref_model.TAP, None
+        margin = min(v for k, v in tap.items() if k.startswith('zmin:'))
+        if margin >= 2e-5:
+            return mel, f0, emb, lens, draws
+    raise AssertionError('no kink-safe seed found')
+
+
+# --------------------------------------------------------------------------------------------- kernels
+@pytest.mark.parametrize('shape', [(128, 128, 64), (256, 512, 400), (100, 80, 164), (333, 257, 66), (1024, 512, 2560)])
+@pytest.mark.parametrize('layout', [(False, False), (False, True), (True, True)])
+def test_gemm_layouts(E, shape, layout):
+    M, N, K = shape
+    ta, tb = layout
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    Bm = torch.randn((K, N) if tb else (N, K), generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = (A.t() if ta else A).double() @ (Bm if tb else Bm.t()).double() + bias.double()
+    for ks in (1, 4):
+        c = E.gemm(A.cuda(), Bm.cuda(), bias.cuda(), ta, tb, ks)
+        assert rel(c, ref) < 5e-6, (shape, layout, ks)
+
+
+def test_interp_bit_exact_against_reference(E):
+    z = np.load(os.path.join(GOLD, 'interp.npz'))
+    for i in range(int(z['n'])):
+        pad = int(z[f'c{i}_max_len_pad'])
+        eng = get_engine(E, 'interp', pad, 16)
+        x = torch.from_numpy(z[f'c{i}_x'])
+        y, i0, lam, cnt = eng.interp_forward(x, z[f'c{i}_len_seq'], z[f'c{i}_scales'], z[f'c{i}_len_seg'], want_plan=True)
+        ri0, rlam, rcnt, rn = interp_np.interp_plan(z[f'c{i}_scales'], z[f'c{i}_len_seg'], z[f'c{i}_len_seq'], max_len_pad=pad)
+        assert np.array_equal(y.cpu().numpy(), z[f'c{i}_y']), i            # values: bit-exact vs the reference's output
+        assert np.array_equal(i0.cpu().numpy(), ri0) and np.array_equal(cnt.cpu().numpy(), rcnt)
+        assert np.array_equal(lam.cpu().numpy(), rlam)
+        dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(i))
+        dx = eng.interp_backward(dy, x.shape[1])
+        assert rel(dx, interp_np.interp_backward(dy.numpy(), ri0, rlam, rn, x.shape[1])) < 1e-6
+
+
+def test_interp_module_autograd(E):
+    from speechsplit_amd import model
+    hp = W.default_hparams(max_len_pad=128)
+    m = model.InterpLnr(hp).train()
+    x = torch.randn(3, 128, 20, device='cuda', requires_grad=True)
+    lens = torch.tensor([128, 100, 64])
+    sc, ls = draws_for(5, 3, 1)[0]
+    y = m(x, lens, draws=(sc, ls))
+    ref = interp_np.interp_forward(x.detach().cpu().numpy(), lens.numpy(), sc, ls, max_len_pad=128)
+    assert np.array_equal(y.detach().cpu().numpy(), ref)
+    (y * y).sum().backward()
+    i0, lam, _, nrows = interp_np.interp_plan(sc, ls, lens.numpy(), max_len_pad=128)
+    assert rel(x.grad, interp_np.interp_backward(2 * ref, i0, lam, nrows, 128)) < 1e-6
+    assert m.eval()(x, lens) is x                                         # model.py:382-383
+
+
+# --------------------------------------------------------------------------------------------- config 1 (demo.pkl)
+def test_config1_demo_eval_forward(E):
+    z = np.load(os.path.join(GOLD, 'demo_config1.npz'))
+    hp = W.default_hparams()
+    e3, e6 = get_engine(E, 'G3', 192), get_engine(E, 'G6', 192)
+    e3.load_weights(W.make_weights('G3', hp, int(z['seed_g3'])))
+    e6.load_weights(W.make_weights('G6', hp, int(z['seed_g6'])))
+    for n in range(2):
+        mel = torch.from_numpy(z[f'u{n}_mel_pad'])
+        onehot = torch.from_numpy(interp_np.onehot(z[f'u{n}_qidx'].astype(np.int64)))[None]
+        emb = torch.from_numpy(z[f'u{n}_emb'])
+        out3 = e3.g3_forward(torch.cat((mel, onehot), -1), mel, emb)
+        assert rel(out3, z[f'u{n}_out3']) < TOL
+        assert rel(e3.g3_rhythm(mel), z[f'u{n}_rhythm']) < TOL
+        assert rel(e6.g6_forward(mel, onehot), z[f'u{n}_out6']) < TOL
+
+
+def test_eval_forward_ragged_batch(E):
+    """B not a multiple of the 16-utterance LSTM tile, T below max_len_pad (eval works at any T % 8 == 0)."""
+    hp = W.default_hparams()
+    w = W.make_weights('G3', hp, 5)
+    eng = get_engine(E, 'G3', 192)
+    eng.load_weights(w)
+    P = ref_model.as_params(w, False)
+    g = torch.Generator().manual_seed(3)
+    B, T = 3, 64
+    mel = torch.rand(B, T, 80, generator=g)
+    onehot = torch.nn.functional.one_hot(torch.randint(0, 257, (B, T), generator=g), 257).float()
+    emb = torch.nn.functional.one_hot(torch.tensor([1, 5, 80]), 82).float()
+    x_f0 = torch.cat((mel, onehot), -1)
+    with torch.no_grad():
+        ref = ref_model.generator_3(P, hp, x_f0, mel, emb)
+    assert rel(eng.g3_forward(x_f0, mel, emb), ref) < TOL
+    # the ablation inputs of solver.py:245-251: zeroed pitch / zeroed content are not one-hot rows
+    x0 = torch.cat((mel, torch.zeros_like(onehot)), -1)
+    with torch.no_grad():
+        ref0 = ref_model.generator_3(P, hp, x0, mel, emb)
+    assert rel(eng.g3_forward(x0, mel, emb), ref0) < TOL
+
+
+# --------------------------------------------------------------------------------------------- module-level boundary (B1)
+def test_module_train_step_with_torch_adam(E):
+    """Reference-style usage (solver.py:57-66, 157-172): optimizer built before .to(device), G.train(), G(...),
+    mse_loss, backward, Adam.step -- compared with the oracle doing the same on CPU."""
+    from speechsplit_amd import model
+    B, T = 2, 128
+    hp = W.default_hparams(max_len_pad=T, batch_size=B)
+    w = W.make_weights('G3', hp, 3)
+    mel, f0, emb, lens, draws = kink_safe_case(hp, w, B, T, 31)
+    G = model.Generator_3(hp)
+    G.load_state_dict({**{k: torch.from_numpy(v) for k, v in w.items()}, 'encoder_1.len_org': torch.tensor(T)})
+    opt = torch.optim.Adam(G.parameters(), 1e-4, [0.9, 0.999])
+    G.to('cuda:0')
+    assert G.train() is G
+    st = ref_model.TrainState(w)
+    xi = ref_model.interp(torch.cat((mel, f0), -1), lens.numpy(), draws[0], hp)
+    onehot, _ = ref_model.quantize_f0(xi[:, :, -1])
+    x_in = torch.cat((xi[:, :, :-1], onehot), -1)
+    out = G(x_in.cuda(), mel.cuda(), emb.cuda(), draws=stack_draws(draws[1:4]))
+    loss = torch.nn.functional.mse_loss(mel.cuda(), out, reduction='mean')
+    opt.zero_grad()
+    loss.backward()
+    lo, ro = st.step_g3(hp, mel, f0, emb, lens.numpy(), draws)       # oracle: loss, backward, Adam
+    assert rel(out, ro) < TOL and abs(float(loss) - float(lo)) < 1e-5 * float(lo)
+    for n, p in G.named_parameters():
+        assert rel(p.grad, st.P[n].grad) < TOL, n
+    opt.step()
+    for n, p in G.named_parameters():
+        assert rel(p, st.P[n]) < TOL, n
+    sd = G.state_dict()
+    assert list(sd.keys())[0] == 'encoder_1.len_org' and sd['decoder.lstm.weight_hh_l2_reverse'].shape == (2048, 512)
+    # eval mode: identity resampling, no draws needed
+    with torch.no_grad():
+        oe = G.eval()(x_in.cuda(), mel.cuda(), emb.cuda())
+        re_ = ref_model.generator_3(st.P, hp, x_in, mel, emb)
+    assert rel(oe, re_) < TOL
+
+
+# --------------------------------------------------------------------------------------------- fused training step (B2)
+@pytest.mark.parametrize('tag', ['b2_t128', 'b2_t192', 'b8_t128'])
+def test_fused_train_step_against_reference_fixture(E, tag):
+    rec = json.load(open(os.path.join(GOLD, 'train_steps.json')))[tag]
+    B, T = rec['B'], rec['T']
+    hp = W.default_hparams(max_len_pad=T)
+    eng = get_engine(E, 'G3', T, B)
+    eng.load_weights(W.make_weights('G3', hp, rec['wseed']))
+    eng.adam_m.zero_()
+    eng.adam_v.zero_()
+    eng.set_adam(1e-4, 0.9, 0.999, 1e-8, 0)
+    mel, f0, emb, lens = synth_batch(rec['bseed'], B, T, 64 if T == 128 else 96)
+    nsteps = len(rec['losses'])
+    draws = draws_for(rec['dseed'], B, 4 * nsteps)
+    for it in range(nsteps):
+        loss = eng.g3_train_step(mel, f0, emb, lens, stack_draws(draws[4 * it:4 * it + 4]))
+        assert abs(float(loss) - rec['losses'][it]) <= 2e-5 * rec['losses'][it], (it, float(loss))
+        if it == 0:
+            out = eng.debug_buffer('out', B, T)
+            assert rel(out, np.load(os.path.join(GOLD, f'train_{tag}_out.npy'))) < TOL
+            # index path and resampled values of the outer InterpLnr call: bit-exact
+            assert np.array_equal(eng.debug_buffer('in.mel', B, T).cpu().numpy(), np.load(os.path.join(GOLD, f'train_{tag}_xin_mel.npy')))
+            cls = eng.debug_buffer('in.f0', B, T)[:, :, :257].argmax(-1).cpu().numpy()
+            assert np.array_equal(cls, np.load(os.path.join(GOLD, f'train_{tag}_xin_f0idx.npy')).astype(np.int64))
+            pv = eng.param_views()
+            for n, s in rec['params_after'].items():
+                flat = pv[n].reshape(-1).cpu()
+                for p, v in zip(s['pos'], s['val']):
+                    assert abs(float(flat[p]) - v) <= TOL * s['amax'] + 1e-9, (n, p)
+
+
+def test_fused_train_step_full_gradients(E):
+    B, T = 4, 128
+    hp = W.default_hparams(max_len_pad=T)
+    w = W.make_weights('G3', hp, 9)
+    mel, f0, emb, lens, draws = kink_safe_case(hp, w, B, T, 61)
+    eng = get_engine(E, 'G3', T, B)
+    eng.load_weights(w)
+    loss = eng.g3_train_step(mel, f0, emb, lens, stack_draws(draws), no_adam=True)
+    P = ref_model.as_params(w)
+    lo, _ = ref_model.g3_loss(P, hp, mel, f0, emb, lens.numpy(), draws)
+    lo.backward()
+    assert abs(float(loss) - float(lo)) <= 1e-5 * float(lo)
+    gv = eng.grad_views()
+    for n, p in P.items():
+        assert rel(gv[n], p.grad) < TOL, n
+
+
+def test_g6_train_step(E):
+    rec = json.load(open(os.path.join(GOLD, 'g6_train.json')))
+    B, T = rec['B'], rec['T']
+    hp = W.default_hparams(max_len_pad=T)
+    w = W.make_weights('G6', hp, rec['wseed'])
+    eng = get_engine(E, 'G6', T)
+    eng.load_weights(w)
+    mel, f0, emb, lens = synth_batch(rec['bseed'], B, T, 96)
+    qidx = torch.from_numpy(interp_np.quantize_f0(f0[:, :, 0].numpy()))
+    onehot = torch.nn.functional.one_hot(qidx, 257).float()
+    draws = draws_for(rec['dseed'], B, 3)
+    out = eng.g6_forward(mel, onehot, stack_draws(draws), training=True)
+    assert rel(out, np.load(os.path.join(GOLD, 'g6_train_logits.npy'))) < TOL
+    loss = eng.g6_train_step(mel, onehot, qidx, stack_draws(draws), no_adam=True)
+    assert abs(float(loss) - rec['loss']) <= 1e-5 * rec['loss']
+    gv = eng.grad_views()
+    for n, s in rec['grads'].items():
+        assert abs(float(gv[n].double().norm()) - s['l2']) <= 2e-4 * s['l2'] + 1e-12, n
+
+
+# --------------------------------------------------------------------------------------------- full size (B=64, T=128): properties
+def test_full_size_data_parallel_linearity_and_descent(E):
+    """BASELINE config at full size, where the oracle is too slow to be the checker: (1) the gradient of the
+    64-utterance batch equals the mean of the gradients of its two 32-utterance shards given the matching slices of
+    the draws (the N-rank == 1-rank identity data parallelism relies on); (2) identical draws -> bit-identical
+    resampled inputs; (3) a few Adam steps on a fixed batch reduce the loss."""
+    from speechsplit_amd import dist as D
+    B, T = 64, 128
+    hp = W.default_hparams(max_len_pad=T)
+    eng = get_engine(E, 'G3', T, B)
+    w = W.make_weights('G3', hp, 0)
+    eng.load_weights(w)
+    mel, f0, emb, lens = synth_batch(7, B, T, 64)
+    sc, ls = stack_draws(draws_for(8, B, 4))
+    sc, ls = torch.from_numpy(sc), torch.from_numpy(ls)
+    l_full = float(eng.g3_train_step(mel, f0, emb, lens, (sc, ls), no_adam=True))
+    g_full = eng.grads.clone()
+    xin = eng.debug_buffer('in.mel', B, T)
+    acc = torch.zeros_like(g_full)
+    l_sh = 0.0
+    for r in range(2):
+        b = D.shard_batch((mel, emb, f0, lens), r, 2)
+        d = D.shard_draws(sc, ls, B, r, 2)
+        l_sh += float(eng.g3_train_step(b[0], b[2], b[1], b[3], d, no_adam=True)) / 2
+        acc += eng.grads / 2
+        lo, hi = D.shard_range(B, r, 2)
+        assert torch.equal(eng.debug_buffer('in.mel', B // 2, T), xin[lo:hi])
+    assert abs(l_sh - l_full) <= 1e-5 * l_full
+    gv_f, gv_s = eng.views(g_full), eng.views(acc)
+    for n in gv_f:
+        assert rel(gv_s[n], gv_f[n]) < TOL, n
+    eng.adam_m.zero_()
+    eng.adam_v.zero_()
+    eng.set_adam(1e-3, 0.9, 0.999, 1e-8, 0)
+    losses = [float(eng.g3_train_step(mel, f0, emb, lens, (sc, ls))) for _ in range(6)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_solver_trains_and_checkpoints(E, tmp_path):
+    from types import SimpleNamespace
+    from speechsplit_amd import data_loader, hparams as HP, solver
+    hp = HP.default_hparams(batch_size=4, max_len_pad=128)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    loader = data_loader.get_loader(hp, dataset=data_loader.SyntheticUtterances(16, seed=2))
+    cfg = SimpleNamespace(num_iters=3, g_lr=1e-4, beta1=0.9, beta2=0.999, resume_iters=None, use_tensorboard=False,
+                          device_id=0, log_dir=str(tmp_path), sample_dir=str(tmp_path), model_save_dir=str(tmp_path),
+                          log_step=1, sample_step=1000, model_save_step=3)
+    s = solver.Solver(loader, cfg, hp)
+    s.train()
+    ck = torch.load(os.path.join(str(tmp_path), '3-G.ckpt'), weights_only=False)
+    ref_keys = json.load(open(os.path.join(GOLD, 'keys_G3.json')))['keys']
+    assert list(ck['model'].keys()) == ref_keys
+    assert len(ck['optimizer']['state']) == 86 and float(ck['optimizer']['state'][0]['step']) == 3.0
+    # the optimizer half loads into a stock torch.optim.Adam over the reference's parameter list
+    plist = [torch.nn.Parameter(ck['model'][k].clone()) for k in ref_keys if k != 'encoder_1.len_org']
+    torch.optim.Adam(plist, 1e-4).load_state_dict(ck['optimizer'])
+    cfg2 = SimpleNamespace(**{**vars(cfg), 'resume_iters': 3, 'num_iters': 1})
+    s2 = solver.Solver(loader, cfg2, hp)
+    s2.restore_model(3)
+    assert s2.step_count == 3
+    for (n, a), (_, b) in zip(s.G.state_dict().items(), s2.G.state_dict().items()):
+        assert torch.equal(a.cpu(), b.cpu()), n
+    assert torch.equal(s.eng.adam_v, s2.eng.adam_v)
