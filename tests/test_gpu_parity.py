@@ -4,9 +4,12 @@ Runs on the GPU box: pytest -m gpu.
 Tolerances: index path bit-exact; fp32 values within 1e-4 relative (max-norm per tensor), the bar BASELINE.json's
 north_star states for the mel reconstruction, applied here to outputs, losses, gradients and updated weights.
 
-ReLU kink note: a GroupNorm output that lands within fp32 rounding of 0 can take the other ReLU branch than the
-oracle's, which moves the gradients of that one channel by O(1/T).  Tests that compare every gradient element
-pick seeded inputs whose closest pre-activation is >= 2e-5 away from the kink (the oracle reports the margin).
+ReLU kink note: a GroupNorm output that lands within fp32 rounding (~1e-6) of 0 can take the other ReLU branch
+than the oracle's (any two fp32 implementations disagree there), which moves the gradients of that channel and of
+the conv layers below it in the same stream by O(1/T).  At B*T*C ~ 1e6 pre-activations such an element exists in
+roughly every other case.  Element-wise gradient tests therefore (a) run on a small shape with seeded inputs whose
+closest pre-activation is >= 1e-5 from the kink (the oracle reports the margin), and (b) at larger shapes hold every
+tensor to 1e-4 except conv-trunk tensors at or below a layer where the oracle reports an ambiguous element.
 """
 import json
 import os
@@ -49,20 +52,39 @@ def stack_draws(draws):
     return np.stack([d[0] for d in draws]), np.stack([d[1] for d in draws])
 
 
-def kink_safe_case(hp, weights, B, T, first_seed, tries=8):
-    """Seeded batch + draws whose GroupNorm outputs keep >= 2e-5 distance from the ReLU kink in the oracle."""
+def kink_margins(P, hp, mel, f0, emb, lens, draws):
+    ref_model.TAP = {}
+    with torch.no_grad():
+        ref_model.g3_loss(P, hp, mel, f0, emb, lens.numpy(), draws)
+    tap, ref_model.TAP = ref_model.TAP, None
+    return {k[5:]: v for k, v in tap.items() if k.startswith('zmin:')}
+
+
+def kink_safe_case(hp, weights, B, T, first_seed, tries=100, margin=1e-5):
+    """Seeded batch + draws whose GroupNorm outputs all keep >= margin distance from the ReLU kink in the oracle."""
     P = ref_model.as_params(weights, False)
     for seed in range(first_seed, first_seed + tries):
-        mel, f0, emb, lens = synth_batch(seed, B, T, 64 if T == 128 else 96)
+        mel, f0, emb, lens = synth_batch(seed, B, T, 64 if T <= 128 else 96)
         draws = draws_for(seed + 100, B, 4)
-        ref_model.TAP = {}
-        with torch.no_grad():
-            ref_model.g3_loss(P, hp, mel, f0, emb, lens.numpy(), draws)
-        tap, ref_model.TAP = ref_model.TAP, None
-        margin = min(v for k, v in tap.items() if k.startswith('zmin:'))
-        if margin >= 2e-5:
+        if min(kink_margins(P, hp, mel, f0, emb, lens, draws).values()) >= margin:
             return mel, f0, emb, lens, draws
     raise AssertionError('no kink-safe seed found')
+
+
+def grad_tolerances(names, margins, loose=3e-2, margin=1e-5):
+    """Per-parameter tolerance: TOL everywhere, `loose` only for conv-trunk tensors at or below an ambiguous layer."""
+    tol = {}
+    for n in names:
+        t = TOL
+        for stream, pre in (('c1', 'encoder_1.convolutions_1.'), ('c2', 'encoder_1.convolutions_2.')):
+            if n.startswith(pre):
+                layer = int(n[len(pre)])
+                if any(margins.get(f'enc1.{stream}_{i}.conv', 1.0) < margin for i in range(layer, 3)):
+                    t = loose
+        if n.startswith('encoder_2.convolutions.') and margins.get('enc2.c.conv', 1.0) < margin:
+            t = loose
+        tol[n] = t
+    return tol
 
 
 # --------------------------------------------------------------------------------------------- kernels
@@ -158,10 +180,10 @@ def test_module_train_step_with_torch_adam(E):
     """Reference-style usage (solver.py:57-66, 157-172): optimizer built before .to(device), G.train(), G(...),
     mse_loss, backward, Adam.step -- compared with the oracle doing the same on CPU."""
     from speechsplit_amd import model
-    B, T = 2, 128
+    B, T = 2, 64                    # small on purpose (kink note above); max_len_pad=64 also exercises the truncation
     hp = W.default_hparams(max_len_pad=T, batch_size=B)
     w = W.make_weights('G3', hp, 3)
-    mel, f0, emb, lens, draws = kink_safe_case(hp, w, B, T, 31)
+    mel, f0, emb, lens, draws = kink_safe_case(hp, w, B, T, 41)
     G = model.Generator_3(hp)
     G.load_state_dict({**{k: torch.from_numpy(v) for k, v in w.items()}, 'encoder_1.len_org': torch.tensor(T)})
     opt = torch.optim.Adam(G.parameters(), 1e-4, [0.9, 0.999])
@@ -222,21 +244,31 @@ def test_fused_train_step_against_reference_fixture(E, tag):
                     assert abs(float(flat[p]) - v) <= TOL * s['amax'] + 1e-9, (n, p)
 
 
-def test_fused_train_step_full_gradients(E):
-    B, T = 4, 128
+@pytest.mark.parametrize('case', [(2, 64, 9, 46, True), (4, 128, 9, 61, False), (5, 192, 4, 70, False)])
+def test_fused_train_step_full_gradients(E, case):
+    """Every element of all 86 gradients against the oracle's autograd."""
+    B, T, wseed, bseed, want_safe = case
     hp = W.default_hparams(max_len_pad=T)
-    w = W.make_weights('G3', hp, 9)
-    mel, f0, emb, lens, draws = kink_safe_case(hp, w, B, T, 61)
-    eng = get_engine(E, 'G3', T, B)
+    w = W.make_weights('G3', hp, wseed)
+    if want_safe:
+        mel, f0, emb, lens, draws = kink_safe_case(hp, w, B, T, bseed)
+    else:
+        mel, f0, emb, lens = synth_batch(bseed, B, T, 64 if T == 128 else 96)
+        draws = draws_for(bseed + 100, B, 4)
+    eng = get_engine(E, 'G3', T, 8)
     eng.load_weights(w)
     loss = eng.g3_train_step(mel, f0, emb, lens, stack_draws(draws), no_adam=True)
     P = ref_model.as_params(w)
+    margins = kink_margins(P, hp, mel, f0, emb, lens, draws)
     lo, _ = ref_model.g3_loss(P, hp, mel, f0, emb, lens.numpy(), draws)
     lo.backward()
     assert abs(float(loss) - float(lo)) <= 1e-5 * float(lo)
     gv = eng.grad_views()
+    tol = grad_tolerances(list(P), margins)
+    if want_safe:
+        assert all(t == TOL for t in tol.values())
     for n, p in P.items():
-        assert rel(gv[n], p.grad) < TOL, n
+        assert rel(gv[n], p.grad) < tol[n], (n, tol[n])
 
 
 def test_g6_train_step(E):
