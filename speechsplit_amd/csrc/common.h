@@ -34,6 +34,7 @@ struct GemmDesc {
     int M, N, K;
     int batch;
     int flags;
+    int diag;               // timing experiments only (gemm_f32.hip g_gemm_diag); 0 in production
     int ksplit;             // >1: split the reduction over blockIdx.z, atomically accumulate into C (C pre-zeroed or ACCUM)
 };
 

@@ -17,6 +17,11 @@
 
 using namespace ss;
 
+namespace ss {
+extern int g_lstm_nw, g_lstm_g, g_lstm_mode, g_gemm_bk, g_gemm_want, g_gemm_diag;
+int g_overlap = 1;     // 1: weight-gradient GEMMs on the side stream
+}
+
 namespace {
 
 thread_local std::string g_err;
@@ -107,6 +112,12 @@ struct ss_engine {
     InterpPlan plan[4];
     AdamState* adam = nullptr;
     std::map<std::string, std::pair<float*, long>> dbg;   // name -> (ptr, cols)
+    // weight-gradient GEMMs of a BLSTM layer run on this side stream while the next layer's recurrence (latency-bound,
+    // one launch per time step) proceeds on the caller's stream
+    hipStream_t side = nullptr;
+    hipEvent_t ev[8] = {};
+    int ev_next = 0;
+    bool side_used = false;
 
     long carve(int B, int T, bool assign);
 };
@@ -344,6 +355,16 @@ int pick_ksplit(int M, int N, long K) {
 }
 
 #define GEMM(d) HIPCHK(launch_gemm(d, s))
+#define GEMM_ON(d, st) HIPCHK(launch_gemm(d, st))
+
+// make `to` wait for everything enqueued on `from` so far
+int fork_join(ss_engine* e, hipStream_t from, hipStream_t to) {
+    hipEvent_t ev = e->ev[e->ev_next];
+    e->ev_next = (e->ev_next + 1) & 7;
+    HIPCHK(hipEventRecord(ev, from));
+    HIPCHK(hipStreamWaitEvent(to, ev, 0));
+    return 0;
+}
 
 // ---- convolution block -------------------------------------------------------------------------------------
 int conv_pack_all(ss_engine* e, ConvBlk& cb, hipStream_t s) {
@@ -468,39 +489,14 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
         } else {
             HIPCHK(lstm_small_bwd(dG, wf, wb, dcur, lb.csave[l], B, T, H, s));
         }
-        for (int dir = 0; dir < 2; ++dir) {
-            const LstmDir& pd = lb.pd[l * 2 + dir];
-            const float* dGd = dG + dir * 4L * H;
-            // dW_ih[n][k] = sum_r dG[r][n] * X[r][k]
-            GemmDesc a{};
-            a.A = {dGd, 8L * H, 0, 0, 0};
-            a.B = {xi.p, xi.ld, 0, 0, 0};
-            a.C = e->G + pd.wih;
-            a.ldc = In;
-            a.M = 4 * H;
-            a.N = In;
-            a.K = (int)R;
-            a.batch = 1;
-            a.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM;
-            a.ksplit = pick_ksplit(a.M, a.N, a.K);
-            GEMM(a);
-            // dW_hh[n][k] = sum_r dG[r][n] * h_prev[r][k];  h_prev = out one row earlier (fwd) / later (reverse)
-            GemmDesc h{};
-            h.A = {dir == 0 ? dGd + 8L * H : dGd, 8L * H, 0, 0, 0};
-            h.B = {dir == 0 ? lb.out[l] : lb.out[l] + 2L * H + H, 2L * H, 0, 0, 0};
-            h.C = e->G + pd.whh;
-            h.ldc = H;
-            h.M = 4 * H;
-            h.N = H;
-            h.K = (int)(R - 1);
-            h.batch = 1;
-            h.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM;
-            h.ksplit = pick_ksplit(h.M, h.N, h.K);
-            GEMM(h);
-            HIPCHK(colsum_acc(dGd, 8L * H, (int)R, 4 * H, e->G + pd.bih, s));
-            HIPCHK(hipMemcpyAsync(e->G + pd.bhh, e->G + pd.bih, 4L * H * 4, hipMemcpyDeviceToDevice, s));
-        }
+        // input gradient first (the next layer's recurrence needs it), on the caller's stream
         Slab dxi = l == 0 ? dx : Slab{lb.dmid[l & 1], 2L * H};
+        hipStream_t ws = s;
+        if (e->side && g_overlap) {
+            CHK(fork_join(e, s, e->side));        // dG of this layer is complete
+            ws = e->side;
+            e->side_used = true;
+        }
         if (dxi.p) {
             for (int dir = 0; dir < 2; ++dir) {
                 const LstmDir& pd = lb.pd[l * 2 + dir];
@@ -517,6 +513,38 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
                 g.ksplit = 1;
                 GEMM(g);
             }
+        }
+        for (int dir = 0; dir < 2; ++dir) {
+            const LstmDir& pd = lb.pd[l * 2 + dir];
+            const float* dGd = dG + dir * 4L * H;
+            // dW_ih[n][k] = sum_r dG[r][n] * X[r][k]
+            GemmDesc a{};
+            a.A = {dGd, 8L * H, 0, 0, 0};
+            a.B = {xi.p, xi.ld, 0, 0, 0};
+            a.C = e->G + pd.wih;
+            a.ldc = In;
+            a.M = 4 * H;
+            a.N = In;
+            a.K = (int)R;
+            a.batch = 1;
+            a.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM;
+            a.ksplit = pick_ksplit(a.M, a.N, a.K);
+            GEMM_ON(a, ws);
+            // dW_hh[n][k] = sum_r dG[r][n] * h_prev[r][k];  h_prev = out one row earlier (fwd) / later (reverse)
+            GemmDesc h{};
+            h.A = {dir == 0 ? dGd + 8L * H : dGd, 8L * H, 0, 0, 0};
+            h.B = {dir == 0 ? lb.out[l] : lb.out[l] + 2L * H + H, 2L * H, 0, 0, 0};
+            h.C = e->G + pd.whh;
+            h.ldc = H;
+            h.M = 4 * H;
+            h.N = H;
+            h.K = (int)(R - 1);
+            h.batch = 1;
+            h.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM;
+            h.ksplit = pick_ksplit(h.M, h.N, h.K);
+            GEMM_ON(h, ws);
+            HIPCHK(colsum_acc(dGd, 8L * H, (int)R, 4 * H, e->G + pd.bih, ws));
+            HIPCHK(hipMemcpyAsync(e->G + pd.bhh, e->G + pd.bih, 4L * H * 4, hipMemcpyDeviceToDevice, ws));
         }
         dcur = dxi.p;
     }
@@ -680,6 +708,10 @@ int backward_core(ss_engine* e, hipStream_t s) {
             HIPCHK(hipMemcpyAsync(e->d_xf, e->d_act, R * CE * 4, hipMemcpyDeviceToDevice, s));
         }
     }
+    if (e->side_used) {                           // every gradient is complete on the caller's stream from here on
+        CHK(fork_join(e, e->side, s));
+        e->side_used = false;
+    }
     return 0;
 }
 
@@ -750,7 +782,16 @@ ss_engine* ss_create(int kind, const ss_hparams* hp, int max_batch, int max_fram
     return e;
 }
 
-void ss_destroy(ss_engine* e) { delete e; }
+void ss_destroy(ss_engine* e) {
+    if (!e) return;
+    if (e->side) {
+        (void)hipStreamSynchronize(e->side);
+        for (auto& ev : e->ev)
+            if (ev) (void)hipEventDestroy(ev);
+        (void)hipStreamDestroy(e->side);
+    }
+    delete e;
+}
 
 int ss_num_params(const ss_engine* e) { return (int)e->params.size(); }
 
@@ -791,6 +832,10 @@ int ss_bind(ss_engine* e, float* params, float* grads, float* m, float* v, void*
     e->have_fwd = false;
     HIPCHK(hipMemsetAsync(e->ws, 0, ws_bytes, S(stream)));
     e->carve(e->maxB, e->maxT, true);
+    if (!e->side && e->kind != SS_INTERP_ONLY) {
+        HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+        for (auto& ev : e->ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
     AdamState st{};
     st.lr = 1e-4;
     st.beta1 = 0.9;
@@ -976,6 +1021,43 @@ int ss_op_gemm(const float* a, long lda, const float* b, long ldb, float* c, lon
     d.ksplit = ksplit < 1 ? 1 : ksplit;
     d.flags = (flags & 1 ? GEMM_TA : 0) | (flags & 2 ? GEMM_TB : 0) | (d.ksplit > 1 ? GEMM_ACCUM : 0);
     HIPCHK(launch_gemm(d, S(stream)));
+    return 0;
+}
+
+int ss_tune(const char* key, int value) {
+    const std::string k = key ? key : "";
+    if (k == "lstm_nw" && (value == 4 || value == 8 || value == 16)) g_lstm_nw = value;
+    else if (k == "lstm_g" && value >= 0 && value <= 16) g_lstm_g = value;
+    else if (k == "lstm_mode" && value >= 0 && value <= 4) g_lstm_mode = value;
+    else if (k == "overlap" && (value == 0 || value == 1)) g_overlap = value;
+    else if (k == "gemm_bk" && (value == 16 || value == 32)) g_gemm_bk = value;
+    else if (k == "gemm_want" && value >= 1) g_gemm_want = value;
+    else if (k == "gemm_diag" && value >= 0 && value < 64) g_gemm_diag = value;
+    else return fail("ss_tune: unknown key or bad value: " + k);
+    return 0;
+}
+
+int ss_op_lstm_fwd(float* gates, const float* whh_f, const float* whh_b, float* out, float* csave, int B, int T, int H,
+                   void* stream) {
+    hipStream_t s = S(stream);
+    if (H > 32) {
+        for (int st = 0; st < T; ++st) HIPCHK(lstm_step_fwd(gates, whh_f, whh_b, out, csave, B, T, H, st, s));
+    } else {
+        HIPCHK(lstm_small_fwd(gates, whh_f, whh_b, out, csave, B, T, H, s));
+    }
+    return 0;
+}
+
+int ss_op_lstm_bwd(float* gates, const float* whh_f, const float* whh_b, float* whhT_scratch, const float* d_out,
+                   const float* csave, float* dc_scratch, int B, int T, int H, void* stream) {
+    hipStream_t s = S(stream);
+    if (H > 32) {
+        HIPCHK(transpose2d(whh_f, 4 * H, H, whhT_scratch, s));
+        HIPCHK(transpose2d(whh_b, 4 * H, H, whhT_scratch + 4L * H * H, s));
+        for (int st = 0; st < T; ++st) HIPCHK(lstm_step_bwd(gates, whhT_scratch, d_out, csave, dc_scratch, B, T, H, st, s));
+    } else {
+        HIPCHK(lstm_small_bwd(gates, whh_f, whh_b, d_out, csave, B, T, H, s));
+    }
     return 0;
 }
 

@@ -15,9 +15,13 @@
 
 namespace ss {
 
+int g_gemm_bk = 16;        // k-tile depth of the vectorised GEMM instances (16 or 32), ss_tune("gemm_bk")
+int g_gemm_want = 1024;
+int g_gemm_diag = 0;       // diagnostics only (timing experiments, wrong results): 1 no barrier, 2 no global loads / LDS stores in the loop,
+                          // 4 no LDS fragment reads, 8 s_setprio around the MFMA cluster     // minimum number of tiles before the largest tile is chosen, ss_tune("gemm_want")
+
 namespace {
 
-constexpr int BK = 16;
 constexpr int PADL = 4;
 
 template <bool VEC>
@@ -42,7 +46,7 @@ __device__ __forceinline__ f32x4 load4(const Operand& op, const float* base, int
     return v;
 }
 
-template <int BM, int BN, bool TA, bool TB, bool VEC>
+template <int BM, int BN, int BK, bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDesc d) {
     __shared__ __attribute__((aligned(16))) float As[2][BK][BM + PADL];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + PADL];
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDesc d) {
     const int ks = blockIdx.z - batch * d.ksplit;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
 
-    const int ktiles = (d.K + BK - 1) / BK;
+    const int ktiles = (d.K + BK - 1) / BK;   // split-K boundaries are multiples of BK
     const int tiles_per_split = (ktiles + d.ksplit - 1) / d.ksplit;
     const int kbeg = ks * tiles_per_split * BK;
     int kend = kbeg + tiles_per_split * BK;
@@ -68,18 +72,95 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDesc d) {
     const float* Bb = d.B.p + (long)batch * d.B.bstride;
 
     f32x4 ra[NA], rb[NB];
-    auto gload = [&](int k0) {
+    // Vectorised instances walk K with per-slot pointers set up once (no divisions in the loop): a K-contiguous operand
+    // advances `within` inside its K segment (conv taps) and hops by segstride at a segment end; a reduction-major
+    // operand advances by BK rows.  The scalar instances (unaligned / odd strides) keep the generic addressing.
+    const float* pa[NA];
+    const float* pb[NB];
+    int wa[NA], wb[NB];          // position inside the current K segment (K-contiguous operands)
+    bool oka[NA], okb[NB];       // the fixed coordinate (row for K-contiguous, column for reduction-major) is in range
+    if (VEC) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int f = tid + i * 256;
-            if (!TA) ra[i] = load4<VEC>(d.A, Ab, m0 + (f >> 2), k0 + (f & 3) * 4, d.M, kend);
-            else     ra[i] = load4<VEC>(d.A, Ab, k0 + f / (BM / 4), m0 + (f % (BM / 4)) * 4, kend, d.M);
+            if (!TA) {
+                const int r = m0 + f / (BK / 4), c = kbeg + (f % (BK / 4)) * 4;
+                oka[i] = r < d.M;
+                const int sg = d.A.seglen ? c / d.A.seglen : 0;
+                wa[i] = d.A.seglen ? c - sg * d.A.seglen : c;
+                pa[i] = Ab + (long)(oka[i] ? r : 0) * d.A.ld + (long)sg * d.A.segstride + wa[i];
+            } else {
+                const int c = m0 + (f % (BM / 4)) * 4;
+                oka[i] = c < d.M;
+                const int cc = oka[i] ? c : 0;
+                const int sg = d.A.seglen ? cc / d.A.seglen : 0;
+                wa[i] = c;
+                pa[i] = Ab + (long)(kbeg + f / (BM / 4)) * d.A.ld + (long)sg * d.A.segstride + (d.A.seglen ? cc - sg * d.A.seglen : cc);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int f = tid + i * 256;
-            if (!TB) rb[i] = load4<VEC>(d.B, Bb, n0 + (f >> 2), k0 + (f & 3) * 4, d.N, kend);
-            else     rb[i] = load4<VEC>(d.B, Bb, k0 + f / (BN / 4), n0 + (f % (BN / 4)) * 4, kend, d.N);
+            if (!TB) {
+                const int r = n0 + f / (BK / 4), c = kbeg + (f % (BK / 4)) * 4;
+                okb[i] = r < d.N;
+                const int sg = d.B.seglen ? c / d.B.seglen : 0;
+                wb[i] = d.B.seglen ? c - sg * d.B.seglen : c;
+                pb[i] = Bb + (long)(okb[i] ? r : 0) * d.B.ld + (long)sg * d.B.segstride + wb[i];
+            } else {
+                const int c = n0 + (f % (BN / 4)) * 4;
+                okb[i] = c < d.N;
+                const int cc = okb[i] ? c : 0;
+                const int sg = d.B.seglen ? cc / d.B.seglen : 0;
+                wb[i] = c;
+                pb[i] = Bb + (long)(kbeg + f / (BN / 4)) * d.B.ld + (long)sg * d.B.segstride + (d.B.seglen ? cc - sg * d.B.seglen : cc);
+            }
+        }
+    }
+    // one operand slot: load 4 consecutive elements (zero beyond the edges), then advance the slot to the next k-tile
+    auto fetch = [&](const Operand& op, const float*& p, int& w, bool ok, bool T, int kpos /*k of this slot in this tile*/,
+                     int cmax /*column limit of a reduction-major operand*/) -> f32x4 {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (!T) {
+            if (ok && kpos < kend) {
+                if (kpos + 3 < kend) v = *reinterpret_cast<const f32x4*>(p);
+                else
+                    for (int j = 0; j < 4; ++j)
+                        if (kpos + j < kend) v[j] = p[j];
+            }
+            p += BK;
+            if (op.seglen) {
+                w += BK;
+                while (w >= op.seglen) {
+                    w -= op.seglen;
+                    p += op.segstride - op.seglen;
+                }
+            }
+        } else {
+            if (ok && kpos < kend) {
+                if (w + 3 < cmax) v = *reinterpret_cast<const f32x4*>(p);
+                else
+                    for (int j = 0; j < 4; ++j)
+                        if (w + j < cmax) v[j] = p[j];
+            }
+            p += (long)BK * op.ld;
+        }
+        return v;
+    };
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int f = tid + i * 256;
+            if (VEC) ra[i] = fetch(d.A, pa[i], wa[i], oka[i], TA, TA ? k0 + f / (BM / 4) : k0 + (f % (BK / 4)) * 4, d.M);
+            else if (!TA) ra[i] = load4<false>(d.A, Ab, m0 + f / (BK / 4), k0 + (f % (BK / 4)) * 4, d.M, kend);
+            else ra[i] = load4<false>(d.A, Ab, k0 + f / (BM / 4), m0 + (f % (BM / 4)) * 4, kend, d.M);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int f = tid + i * 256;
+            if (VEC) rb[i] = fetch(d.B, pb[i], wb[i], okb[i], TB, TB ? k0 + f / (BN / 4) : k0 + (f % (BK / 4)) * 4, d.N);
+            else if (!TB) rb[i] = load4<false>(d.B, Bb, n0 + f / (BK / 4), k0 + (f % (BK / 4)) * 4, d.N, kend);
+            else rb[i] = load4<false>(d.B, Bb, k0 + f / (BN / 4), n0 + (f % (BN / 4)) * 4, kend, d.N);
         }
     };
     auto sstore = [&](int buf) {
@@ -87,7 +168,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDesc d) {
         for (int i = 0; i < NA; ++i) {
             const int f = tid + i * 256;
             if (!TA) {
-                const int m = f >> 2, kq = (f & 3) * 4;
+                const int m = f / (BK / 4), kq = (f % (BK / 4)) * 4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) As[buf][kq + j][m] = ra[i][j];
             } else {
@@ -98,7 +179,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDesc d) {
         for (int i = 0; i < NB; ++i) {
             const int f = tid + i * 256;
             if (!TB) {
-                const int n = f >> 2, kq = (f & 3) * 4;
+                const int n = f / (BK / 4), kq = (f % (BK / 4)) * 4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) Bs[buf][kq + j][n] = rb[i][j];
             } else {
@@ -121,24 +202,51 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDesc d) {
     }
     __syncthreads();
     const int kh = lane >> 5, l31 = lane & 31;
+    const int diag = d.diag;
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);
+        const int buf = (diag & 2) ? 0 : (kt & 1);
+        if (kt + 1 < nk && !(diag & 2) && !(diag & 32)) gload(kbeg + (kt + 1) * BK);
+        // fragments of k-step kk+2 are requested before the MFMAs of k-step kk are issued
+        float a[2][MI], b[2][NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a[0][mi] = As[buf][kh][wm * (BM / 2) + mi * 32 + l31];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b[0][ni] = Bs[buf][kh][wn * (BN / 2) + ni * 32 + l31];
+        if (diag & 8) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float a[MI], b[NI];
+            const int cur = (kk >> 1) & 1;
+            if (kk + 2 < BK) {
+                if (diag & 4) {
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) a[mi] = As[buf][kk + kh][wm * (BM / 2) + mi * 32 + l31];
+                    for (int mi = 0; mi < MI; ++mi) a[cur ^ 1][mi] = a[cur][mi] + 1.0f;
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) b[ni] = Bs[buf][kk + kh][wn * (BN / 2) + ni * 32 + l31];
+                    for (int ni = 0; ni < NI; ++ni) b[cur ^ 1][ni] = b[cur][ni] + 1.0f;
+                } else {
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) a[cur ^ 1][mi] = As[buf][kk + 2 + kh][wm * (BM / 2) + mi * 32 + l31];
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) b[cur ^ 1][ni] = Bs[buf][kk + 2 + kh][wn * (BN / 2) + ni * 32 + l31];
+                }
+            }
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][mi], b[cur][ni], acc[mi][ni], 0, 0, 0);
         }
-        if (kt + 1 < nk) sstore(buf ^ 1);
-        __syncthreads();
+        if (diag & 8) __builtin_amdgcn_s_setprio(0);
+        if (kt + 1 < nk && !(diag & 2)) {
+            if (diag & 16) {          // keep the loaded registers alive without writing LDS
+#pragma unroll
+                for (int i = 0; i < NA; ++i) asm volatile("" ::"v"(ra[i]));
+#pragma unroll
+                for (int i = 0; i < NB; ++i) asm volatile("" ::"v"(rb[i]));
+            } else {
+                sstore(buf ^ 1);
+            }
+        }
+        if (!(diag & 1)) __syncthreads();
     }
 
     float* Cb = d.C + (long)batch * d.cstride;
@@ -171,8 +279,9 @@ bool vec_ok(const Operand& o) {
 template <int BM, int BN, bool TA, bool TB>
 hipError_t launch_cfg(const GemmDesc& d, bool vec, hipStream_t s) {
     dim3 grid(cdiv(d.N, BN), cdiv(d.M, BM), d.batch * d.ksplit);
-    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, true>), grid, dim3(256), 0, s, d);
-    else     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, false>), grid, dim3(256), 0, s, d);
+    if (!vec) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 16, TA, TB, false>), grid, dim3(256), 0, s, d);
+    else if (g_gemm_bk == 32) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 32, TA, TB, true>), grid, dim3(256), 0, s, d);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 16, TA, TB, true>), grid, dim3(256), 0, s, d);
     return hipGetLastError();
 }
 
@@ -180,7 +289,7 @@ template <bool TA, bool TB>
 hipError_t launch_layout(const GemmDesc& d, bool vec, hipStream_t s) {
     // Largest tile that still gives every CU work; the 64x64 tile otherwise.
     auto tiles = [&](int bm, int bn) { return (long)cdiv(d.M, bm) * cdiv(d.N, bn) * d.batch * d.ksplit; };
-    const long want = 256;
+    const long want = g_gemm_want;
     if (d.N > 64 && d.M > 64 && tiles(128, 128) >= want) return launch_cfg<128, 128, TA, TB>(d, vec, s);
     if (d.M > 64 && tiles(128, 64) >= want) return launch_cfg<128, 64, TA, TB>(d, vec, s);
     return launch_cfg<64, 64, TA, TB>(d, vec, s);
@@ -190,6 +299,7 @@ hipError_t launch_layout(const GemmDesc& d, bool vec, hipStream_t s) {
 
 hipError_t launch_gemm(const GemmDesc& din, hipStream_t s) {
     GemmDesc d = din;
+    d.diag = g_gemm_diag;
     if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return hipSuccess;
     if (d.ksplit < 1) d.ksplit = 1;
     if (d.ksplit > 1 && !(d.flags & GEMM_ACCUM)) return hipErrorInvalidValue;   // split-K needs a zeroed / live C

@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks on the GPU box: A/B the tuning knobs of the step-LSTM and GEMM kernels in ONE process
+(interleaved rounds, HIP events on the launch stream), each variant first checked against a PyTorch fp32 reference.
+Writes gpurun_out/kbench.txt.   Usage: python tools/kbench.py [lstm] [gemm] [step]"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from speechsplit_amd import _capi                     # noqa: E402
+from speechsplit_amd import engine as E               # noqa: E402
+
+OUT = os.path.join(ROOT, 'gpurun_out')
+os.makedirs(OUT, exist_ok=True)
+LOG = open(os.path.join(OUT, 'kbench.txt'), 'a')
+lib = _capi.lib()
+
+
+def say(*a):
+    s = ' '.join(str(x) for x in a)
+    print(s, flush=True)
+    LOG.write(s + '\n')
+    LOG.flush()
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def S():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def tune(k, v):
+    _capi.check(lib.ss_tune(k.encode(), int(v)))
+
+
+def timeit(fn, iters=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+def lstm_ref(xproj, whh, B, T, H):
+    """xproj [B,T,2,4H] (bias included), whh [2,4H,H] -> out [B,T,2H], gates [B,T,2,4H] activated, c [B,T,2H] (double)."""
+    out = torch.zeros(B, T, 2 * H, dtype=torch.float64, device=xproj.device)
+    cs = torch.zeros_like(out)
+    ga = torch.zeros(B, T, 2, 4 * H, dtype=torch.float64, device=xproj.device)
+    x = xproj.double()
+    w = whh.double()
+    for d in range(2):
+        h = torch.zeros(B, H, dtype=torch.float64, device=xproj.device)
+        c = torch.zeros_like(h)
+        for t in (range(T) if d == 0 else range(T - 1, -1, -1)):
+            a = x[:, t, d] + h @ w[d].t()
+            i, f, g, o = a.split(H, 1)
+            i, f, g, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)
+            c = f * c + i * g
+            h = o * torch.tanh(c)
+            out[:, t, d * H:(d + 1) * H] = h
+            cs[:, t, d * H:(d + 1) * H] = c
+            ga[:, t, d] = torch.cat((i, f, g, o), 1)
+    return out, ga, cs
+
+
+def bench_lstm(B=64, T=128, H=512):
+    dev = 'cuda'
+    g = torch.Generator(device='cpu').manual_seed(0)
+    TP = T + 4
+    xproj = (torch.randn(B, T, 2, 4 * H, generator=g) * 0.5).to(dev)
+    whh = (torch.rand(2, 4 * H, H, generator=g) * 2 - 1).to(dev) / H ** 0.5
+    d_out = (torch.randn(B, T, 2 * H, generator=g) * 0.1).to(dev)
+    ref_out, ref_ga, ref_c = lstm_ref(xproj[:4, :16], whh, 4, 16, H)          # small slice for the correctness check
+
+    def slabs(Bx, Tx, xp):
+        gates = torch.zeros(Bx, Tx + 4, 8 * H, device=dev)
+        gates[:, 2:2 + Tx] = xp.reshape(Bx, Tx, 8 * H)
+        return gates, torch.zeros(Bx, Tx + 4, 2 * H, device=dev), torch.zeros(Bx, Tx + 4, 2 * H, device=dev)
+
+    whhT = torch.empty(2, H, 4 * H, device=dev)
+    dc = torch.empty(2, B, H, device=dev)
+    dpad = torch.zeros(B, TP, 2 * H, device=dev)
+    dpad[:, 2:2 + T] = d_out
+    results = []
+    for nw, gs in [(4, (4, 8)), (8, (2, 4)), (16, (1, 2))]:
+        for gi in gs:
+            tune('lstm_nw', nw)
+            tune('lstm_g', gi)
+            # correctness (fwd) on the small slice
+            gs_, o_, c_ = slabs(4, 16, xproj[:4, :16].contiguous())
+            _capi.check(lib.ss_op_lstm_fwd(P(gs_), P(whh[0]), P(whh[1]), P(o_), P(c_), 4, 16, H, S()))
+            err = float((o_[:, 2:18].double() - ref_out).abs().max())
+            gates, out, cs = slabs(B, T, xproj)
+            xp_keep = gates.clone()
+
+            def fwd():
+                gates.copy_(xp_keep)
+                _capi.check(lib.ss_op_lstm_fwd(P(gates), P(whh[0]), P(whh[1]), P(out), P(cs), B, T, H, S()))
+
+            def copy_only():
+                gates.copy_(xp_keep)
+            tf = timeit(fwd)[0] - timeit(copy_only)[0]
+            ga_keep = gates.clone()
+
+            def bwd():
+                gates.copy_(ga_keep)
+                _capi.check(lib.ss_op_lstm_bwd(P(gates), P(whh[0]), P(whh[1]), P(whhT), P(dpad), P(cs), P(dc), B, T, H, S()))
+            tb = timeit(bwd)[0] - timeit(copy_only)[0]
+            results.append((nw, gi, tf, tb, err))
+            say(f'lstm H{H} B{B} T{T} nw{nw} g{gi}: fwd {tf / T:.2f} us/step  bwd {tb / T:.2f} us/step  (fwd err {err:.1e})')
+    # bwd grouping variants
+    for nw, gi in [(4, 16), (8, 8), (8, 16), (16, 4), (16, 8)]:
+        tune('lstm_nw', nw)
+        tune('lstm_g', gi)
+        gates, out, cs = slabs(B, T, xproj)
+        xp_keep = gates.clone()
+        gates.copy_(xp_keep)
+        _capi.check(lib.ss_op_lstm_fwd(P(gates), P(whh[0]), P(whh[1]), P(out), P(cs), B, T, H, S()))
+        ga_keep = gates.clone()
+
+        def bwd():
+            gates.copy_(ga_keep)
+            _capi.check(lib.ss_op_lstm_bwd(P(gates), P(whh[0]), P(whh[1]), P(whhT), P(dpad), P(cs), P(dc), B, T, H, S()))
+
+        def copy_only():
+            gates.copy_(ga_keep)
+        tb = timeit(bwd)[0] - timeit(copy_only)[0]
+        say(f'lstm bwd nw{nw} g{gi}: {tb / T:.2f} us/step')
+
+
+def bench_gemm():
+    dev = 'cuda'
+    shapes = [  # (name, M, N, K, ta, tb, ksplit)
+        ('proj   NT 8192x2048x1024', 8192, 2048, 1024, False, False, 1),
+        ('conv   NT 8192x512x2560 ', 8192, 512, 2560, False, False, 1),
+        ('dX     NN 8448x1024x2048', 8448, 1024, 2048, False, True, 1),
+        ('dW_ih  TN 2048x1024x8448', 2048, 1024, 8448, True, True, 4),
+        ('dW_hh  TN 2048x512x8447 ', 2048, 512, 8447, True, True, 8),
+        ('convdW TN 512x2560x8444 ', 512, 2560, 8444, True, True, 6),
+        ('head   NT 8192x80x1024  ', 8192, 80, 1024, False, False, 1),
+    ]
+    for name, M, N, K, ta, tb, ks in shapes:
+        A = torch.randn((K, M) if ta else (M, K), device=dev)
+        Bm = torch.randn((K, N) if tb else (N, K), device=dev)
+        c = torch.zeros(M, N, device=dev)
+        ref = ((A.t() if ta else A).double() @ (Bm if tb else Bm.t()).double())
+        for bk in (16, 32):
+            for want in (256, 1024):
+                tune('gemm_bk', bk)
+                tune('gemm_want', want)
+                c.zero_()
+                E.gemm(A, Bm, None, ta, tb, ks, out=c)
+                err = float((c.double() - ref).abs().max() / ref.abs().max())
+                t, tmin = timeit(lambda: E.gemm(A, Bm, None, ta, tb, ks, out=c), iters=7)
+                say(f'gemm {name} ks{ks} bk{bk} want{want}: {t:8.1f} us  {2.0 * M * N * K / t / 1e6:6.1f} TF  (min {tmin:.1f} us, err {err:.1e})')
+    tune('gemm_bk', 16)
+    tune('gemm_want', 256)
+
+
+def bench_gemm_diag():
+    dev = 'cuda'
+    for name, M, N, K, ta, tb, ks in [('proj NT 8192x2048x1024', 8192, 2048, 1024, False, False, 1),
+                                      ('conv NT 8192x512x2560', 8192, 512, 2560, False, False, 1),
+                                      ('dW_ih TN 2048x1024x8448', 2048, 1024, 8448, True, True, 4)]:
+        A = torch.randn((K, M) if ta else (M, K), device=dev)
+        Bm = torch.randn((K, N) if tb else (N, K), device=dev)
+        c = torch.zeros(M, N, device=dev)
+        for diag, what in [(0, 'baseline'), (16, 'gload, no sstore'), (32, 'sstore, no gload'), (2, 'no gload/sstore'),
+                           (6, 'no gload, no LDS reads'), (0, 'baseline again')]:
+            tune('gemm_diag', diag)
+            t, tmin = timeit(lambda: E.gemm(A, Bm, None, ta, tb, ks, out=c), iters=7)
+            say(f'gemm {name} diag {diag:2d} ({what}): {t:8.1f} us  {2.0 * M * N * K / t / 1e6:6.1f} TF')
+    tune('gemm_diag', 0)
+
+
+def bench_step():
+    from oracle import weights as W
+    from oracle.gen_fixtures import synth_batch
+    B, T = 64, 128
+    hp = W.default_hparams(max_len_pad=T)
+    eng = E.Engine('G3', hp, B, T)
+    eng.load_weights(W.make_weights('G3', hp, 0))
+    mel, f0, emb, lens = [t.cuda() for t in synth_batch(1, B, T, 64)]
+    sc, ls = E.draw_interp(B, 4, hp)
+    sc, ls = sc.cuda(), ls.cuda()
+    tune('gemm_bk', 16)
+    tune('lstm_nw', 8)
+    tune('lstm_g', 4)
+    for rnd in range(2):
+        for ov, want in [(0, 256), (1, 256), (0, 1024), (1, 1024)]:
+            tune('overlap', ov)
+            tune('gemm_want', want)
+            t, tmin = timeit(lambda: eng.g3_train_step(mel, f0, emb, lens, (sc, ls)), iters=10, warm=3)
+            say(f'train step overlap{ov} want{want}: {t / 1e3:.3f} ms  ({B / t * 1e6:.0f} utt/s) min {tmin / 1e3:.3f}, loss {float(eng.loss):.6f}')
+
+
+def bench_lstm_modes(B=64, T=128, H=512):
+    dev = 'cuda'
+    gates = torch.zeros(B, T + 4, 8 * H, device=dev)
+    out = torch.zeros(B, T + 4, 2 * H, device=dev)
+    cs = torch.zeros(B, T + 4, 2 * H, device=dev)
+    whh = torch.randn(2, 4 * H, H, device=dev) / H ** 0.5
+    names = {0: 'full', 1: 'loads, no MFMA', 2: 'MFMA, no operand loads', 3: 'empty kernel', 4: 'loads+MFMA, no epilogue'}
+    for nw, g in [(4, 4), (8, 4), (16, 2)]:
+        tune('lstm_nw', nw)
+        tune('lstm_g', g)
+        for mode in (0, 1, 2, 3, 4):
+            tune('lstm_mode', mode)
+            t = timeit(lambda: _capi.check(lib.ss_op_lstm_fwd(P(gates), P(whh[0]), P(whh[1]), P(out), P(cs), B, T, H, S())))[0]
+            say(f'lstm fwd nw{nw} g{g} mode {mode} ({names[mode]}): {t / T:.2f} us/step')
+    tune('lstm_mode', 0)
+    # host launch rate: an empty kernel launched 128 times is also the floor of the eager path
+    e = torch.zeros(1, device=dev)
+    t = timeit(lambda: [e.add_(1) for _ in range(128)])[0]
+    say(f'torch tiny kernel x128: {t / 128:.2f} us each')
+
+
+if __name__ == '__main__':
+    want = sys.argv[1:] or ['lstm', 'gemm', 'step']
+    say('====', ' '.join(want), torch.cuda.get_device_name(0))
+    if 'lstm' in want:
+        bench_lstm()
+    if 'modes' in want:
+        bench_lstm_modes()
+    if 'gemm' in want:
+        bench_gemm()
+    if 'gdiag' in want:
+        bench_gemm_diag()
+    if 'step' in want:
+        bench_step()
