@@ -105,14 +105,15 @@ int ss_op_gemm(const float* a_dev, long lda, const float* b_dev, long ldb, float
                int M, int N, int K, int flags, int ksplit, void* stream);
 /* One bidirectional LSTM recurrence on haloed slabs (speechsplit_amd/csrc/kernels.h): gates [B,T+4,8H] holds
  * x.W_ih^T + b on entry and the activated gates on exit; out / csave [B,T+4,2H]; whh_* [4H,H].  H <= 32 runs the
- * single-launch kernel, H in {64,128,256,512} one launch per time step. */
-int ss_op_lstm_fwd(float* gates_dev, const float* whh_f_dev, const float* whh_b_dev, float* out_dev, float* csave_dev, int B,
-                   int T, int H, void* stream);
-/* BPTT of the same: d_out [B,T+4,2H]; gates is replaced by the pre-activation gradients.  Scratch: whhT [2,H,4H],
- * dc [2,B,H] (only used when H > 32). */
-int ss_op_lstm_bwd(float* gates_dev, const float* whh_f_dev, const float* whh_b_dev, float* whhT_scratch_dev,
-                   const float* d_out_dev, const float* csave_dev, float* dc_scratch_dev, int B, int T, int H, void* stream);
-/* tuning knobs (process-global): "lstm_nw" 4|8|16, "lstm_g" 0..16, "gemm_bk" 16|32, "gemm_want" >= 1 */
+ * single-launch kernel, H in {64,128,256,512} one launch per time step and needs scratch of at least
+ * 8*H*H + 4*ceil16(B)*H floats (forward) / 8*H*H + 16*ceil16(B)*H + 2*B*H floats (backward). */
+int ss_op_lstm_fwd(float* gates_dev, const float* whh_f_dev, const float* whh_b_dev, float* out_dev, float* csave_dev,
+                   float* scratch_dev, long scratch_floats, int B, int T, int H, void* stream);
+/* BPTT of the same: d_out [B,T+4,2H]; gates is replaced by the pre-activation gradients. */
+int ss_op_lstm_bwd(float* gates_dev, const float* whh_f_dev, const float* whh_b_dev, const float* d_out_dev,
+                   const float* csave_dev, float* scratch_dev, long scratch_floats, int B, int T, int H, void* stream);
+/* tuning knobs (process-global): "lstm_nw" 4|8|16, "lstm_g" 0..16, "gemm_bk" 16|32, "gemm_want" >= 1,
+ * "overlap" 0|1, "graph" 0|1; "lstm_mode" / "gemm_diag" are timing experiments that produce wrong results */
 int ss_tune(const char* key, int value);
 /* named internal slab of the last call ("enc1.xf2", "dec.out2", ...); layout [B, T+4, C], frame t at row t+2 */
 int ss_debug_buffer(ss_engine* e, const char* name, float** ptr_dev, long* rows, long* cols);

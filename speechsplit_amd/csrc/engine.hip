@@ -20,6 +20,9 @@ using namespace ss;
 namespace ss {
 extern int g_lstm_nw, g_lstm_g, g_lstm_mode, g_gemm_bk, g_gemm_want, g_gemm_diag;
 int g_overlap = 1;     // 1: weight-gradient GEMMs on the side stream
+int g_graph = 0;       // 1: the fused training step is captured into a hipGraph and replayed (measured: no gain while the
+                       // step is GPU-bound at batch 64; useful when the host is the bottleneck)
+int g_tune_epoch = 0;  // bumped by ss_tune: captured graphs bake the knobs in, so they are dropped when it changes
 }
 
 namespace {
@@ -64,7 +67,9 @@ struct LstmBlk {
     std::vector<LstmDir> pd;               // [L*2]
     std::vector<float*> gates, out, csave; // per layer
     float* bsum = nullptr;                 // [L][2][4H]
-    float* whhT = nullptr;                 // [2][H][4H]   (step kernels only)
+    float* wfrag = nullptr;                // fragment-major W_hh / W_hh^T (step kernels only), 2*4H*H floats
+    float* hf = nullptr;                   // ping-pong fragment-major h(t):  2 x [2][ceil(B/16)*16][H]
+    float* gf = nullptr;                   // ping-pong fragment-major da(t): 2 x [2][ceil(B/16)*16][4H]
     float* dc = nullptr;                   // [2][B][H]
     float* dmid[2] = {nullptr, nullptr};   // gradient slabs of inner layer outputs [B,TP,2H]
     bool big() const { return H > 32; }
@@ -115,6 +120,20 @@ struct ss_engine {
     // weight-gradient GEMMs of a BLSTM layer run on this side stream while the next layer's recurrence (latency-bound,
     // one launch per time step) proceeds on the caller's stream
     hipStream_t side = nullptr;
+    hipStream_t cap = nullptr;            // graphs are captured and replayed here (a legacy default stream cannot capture)
+    hipEvent_t ev_io[2] = {};             // caller stream <-> cap ordering
+    // captured training steps (hipGraph), keyed by geometry / flags / grad_scale; inputs are staged into engine-owned
+    // buffers so a replay does not depend on the caller's tensor addresses
+    struct StepGraph {
+        int B, T, flags;
+        float gs;
+        hipGraph_t g;
+        hipGraphExec_t x;
+    };
+    std::vector<StepGraph> graphs;
+    int graph_epoch = 0;
+    float *stg_mel = nullptr, *stg_f0 = nullptr, *stg_emb = nullptr, *stg_sc = nullptr, *stg_loss = nullptr;
+    int *stg_len = nullptr, *stg_ls = nullptr;
     hipEvent_t ev[8] = {};
     int ev_next = 0;
     bool side_used = false;
@@ -254,7 +273,10 @@ long ss_engine::carve(int B, int T, bool assign) {
         }
         lb.bsum = (float*)take((long)lb.L * 2 * 4 * lb.H * 4);
         if (lb.big()) {
-            lb.whhT = (float*)take(2L * lb.H * 4 * lb.H * 4);
+            const long B16 = ((B + 15) / 16) * 16;
+            lb.wfrag = (float*)take(2L * lb.H * 4 * lb.H * 4);
+            lb.hf = (float*)take(2L * 2 * B16 * lb.H * 4);
+            lb.gf = (float*)take(2L * 2 * B16 * 4 * lb.H * 4);
             lb.dc = (float*)take(2L * B * lb.H * 4);
         }
         if (lb.L > 1) {
@@ -305,6 +327,16 @@ long ss_engine::carve(int B, int T, bool assign) {
     out_slab = slab("out", head_out);
     d_out_slab = slab("d_out", head_out);
     loss_part = (float*)take(((long)B * T + 8L * B) * 4);
+    {
+        const long S7 = hp.max_len_seq / hp.min_len_seg + 1;
+        stg_mel = (float*)take((long)B * T * hp.dim_freq * 4);
+        stg_f0 = (float*)take((long)B * T * 4);
+        stg_emb = (float*)take((long)B * hp.dim_spk_emb * 4);
+        stg_sc = (float*)take(4L * B * S7 * 4);
+        stg_ls = (int*)take(4L * B * S7 * 4);
+        stg_len = (int*)take((long)B * 4);
+        stg_loss = (float*)take(256);
+    }
     qidx = (int*)take((long)B * TP * 4);
     for (int i = 0; i < 4; ++i) {
         plan[i].S = hp.max_len_seq / hp.min_len_seg + 1;     // model.py:365
@@ -324,6 +356,15 @@ namespace {
 
 hipStream_t S(void* s) { return (hipStream_t)s; }
 
+void drop_graphs(ss_engine* e) {
+    if (!e->graphs.empty() && e->cap) (void)hipStreamSynchronize(e->cap);   // never destroy an executable graph in flight
+    for (auto& g : e->graphs) {
+        (void)hipGraphExecDestroy(g.x);
+        (void)hipGraphDestroy(g.g);
+    }
+    e->graphs.clear();
+}
+
 int geometry(ss_engine* e, int B, int T, hipStream_t s) {
     if (!e->ws) return fail("engine is not bound (call ss_bind first)");
     if (B < 1 || B > e->maxB || T < 1 || T > e->maxT) return fail("batch / frames outside the limits given to ss_create");
@@ -342,6 +383,7 @@ int geometry(ss_engine* e, int B, int T, hipStream_t s) {
     e->curB = B;
     e->curT = T;
     e->have_fwd = false;
+    drop_graphs(e);
     return 0;
 }
 
@@ -463,7 +505,12 @@ int lstm_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
         const float* wf = e->P + lb.pd[l * 2].whh;
         const float* wb = e->P + lb.pd[l * 2 + 1].whh;
         if (lb.big()) {
-            for (int st = 0; st < T; ++st) HIPCHK(lstm_step_fwd(lb.gates[l], wf, wb, lb.out[l], lb.csave[l], B, T, H, st, s));
+            const long half = 2L * (((B + 15) / 16) * 16) * H;
+            HIPCHK(lstm_pack_w(wf, wb, lb.wfrag, H, 0, s));
+            HIPCHK(hipMemsetAsync(lb.hf, 0, 2 * half * 4, s));
+            for (int st = 0; st < T; ++st)
+                HIPCHK(lstm_step_fwd(lb.gates[l], lb.wfrag, lb.hf + (st & 1) * half, lb.hf + ((st & 1) ^ 1) * half, lb.out[l],
+                                     lb.csave[l], B, T, H, st, s));
         } else {
             HIPCHK(lstm_small_fwd(lb.gates[l], wf, wb, lb.out[l], lb.csave[l], B, T, H, s));
         }
@@ -483,9 +530,12 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
         const float* wf = e->P + lb.pd[l * 2].whh;
         const float* wb = e->P + lb.pd[l * 2 + 1].whh;
         if (lb.big()) {
-            HIPCHK(transpose2d(wf, 4 * H, H, lb.whhT, s));
-            HIPCHK(transpose2d(wb, 4 * H, H, lb.whhT + 4L * H * H, s));
-            for (int st = 0; st < T; ++st) HIPCHK(lstm_step_bwd(dG, lb.whhT, dcur, lb.csave[l], lb.dc, B, T, H, st, s));
+            const long half = 2L * (((B + 15) / 16) * 16) * 4 * H;
+            HIPCHK(lstm_pack_w(wf, wb, lb.wfrag, H, 1, s));
+            HIPCHK(hipMemsetAsync(lb.gf, 0, 2 * half * 4, s));
+            for (int st = 0; st < T; ++st)
+                HIPCHK(lstm_step_bwd(dG, lb.wfrag, lb.gf + (st & 1) * half, lb.gf + ((st & 1) ^ 1) * half, dcur, lb.csave[l],
+                                     lb.dc, B, T, H, st, s));
         } else {
             HIPCHK(lstm_small_bwd(dG, wf, wb, dcur, lb.csave[l], B, T, H, s));
         }
@@ -784,11 +834,18 @@ ss_engine* ss_create(int kind, const ss_hparams* hp, int max_batch, int max_fram
 
 void ss_destroy(ss_engine* e) {
     if (!e) return;
+    drop_graphs(e);
     if (e->side) {
         (void)hipStreamSynchronize(e->side);
         for (auto& ev : e->ev)
             if (ev) (void)hipEventDestroy(ev);
         (void)hipStreamDestroy(e->side);
+        if (e->cap) {
+            (void)hipStreamSynchronize(e->cap);
+            for (auto& ev : e->ev_io)
+                if (ev) (void)hipEventDestroy(ev);
+            (void)hipStreamDestroy(e->cap);
+        }
     }
     delete e;
 }
@@ -835,6 +892,8 @@ int ss_bind(ss_engine* e, float* params, float* grads, float* m, float* v, void*
     if (!e->side && e->kind != SS_INTERP_ONLY) {
         HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
         for (auto& ev : e->ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIPCHK(hipStreamCreateWithFlags(&e->cap, hipStreamNonBlocking));
+        for (auto& ev : e->ev_io) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
     AdamState st{};
     st.lr = 1e-4;
@@ -939,14 +998,10 @@ int ss_g6_backward(ss_engine* e, const float* d_out, void* stream) {
     return backward_core(e, s);
 }
 
-int ss_g3_train_step(ss_engine* e, const float* mel, const float* f0, const float* emb, const int* len_org,
-                     const float* scales, const int* len_seg, int B, int T, float grad_scale, int flags, float* loss,
-                     void* stream) {
-    if (e->kind != SS_GENERATOR_3) return fail("ss_g3_train_step on a Generator_6 engine");
-    hipStream_t s = S(stream);
+static int g3_step_body(ss_engine* e, const float* mel, const float* f0, const float* emb, const int* len_org,
+                        const float* scales, const int* len_seg, int B, int T, float grad_scale, int flags, float* loss,
+                        hipStream_t s) {
     const ss_hparams& h = e->hp;
-    if (T != h.max_len_pad) return fail("training needs T == max_len_pad (model.py:105,157,370)");
-    CHK(geometry(e, B, T, s));
     const long TP = T + 2 * HALO;
     // solver.py:160-163: resample [mel | f0] with the utterance lengths, re-quantise the f0 channel
     HIPCHK(interp_plan(e->plan[0], scales, len_seg, len_org, 0, B, s));
@@ -960,7 +1015,55 @@ int ss_g3_train_step(ss_engine* e, const float* mel, const float* f0, const floa
     HIPCHK(mse_loss(e->out_slab + HALO * C, C, TP * C, e->org + HALO * C, C, TP * C, e->d_out_slab + HALO * C, C, TP * C, B, T,
                     C, 1.0f, e->loss_part, loss, s));                                       // solver.py:166
     CHK(backward_core(e, s));                                                               // solver.py:170-171
-    if (!(flags & SS_STEP_NO_ADAM)) CHK(ss_adam_step(e, grad_scale, stream));              // solver.py:172
+    if (!(flags & SS_STEP_NO_ADAM)) CHK(ss_adam_step(e, grad_scale, (void*)s));             // solver.py:172
+    return 0;
+}
+
+int ss_g3_train_step(ss_engine* e, const float* mel, const float* f0, const float* emb, const int* len_org,
+                     const float* scales, const int* len_seg, int B, int T, float grad_scale, int flags, float* loss,
+                     void* stream) {
+    if (e->kind != SS_GENERATOR_3) return fail("ss_g3_train_step on a Generator_6 engine");
+    hipStream_t s = S(stream);
+    const ss_hparams& h = e->hp;
+    if (T != h.max_len_pad) return fail("training needs T == max_len_pad (model.py:105,157,370)");
+    CHK(geometry(e, B, T, s));
+    if (e->graph_epoch != g_tune_epoch) {
+        drop_graphs(e);
+        e->graph_epoch = g_tune_epoch;
+    }
+    if (!g_graph) return g3_step_body(e, mel, f0, emb, len_org, scales, len_seg, B, T, grad_scale, flags, loss, s);
+
+    // stage the caller's inputs, then replay (or first capture) the step on engine-owned addresses.  All of it runs on
+    // the engine's capture stream, ordered after the caller's stream and before whatever the caller enqueues next.
+    hipStream_t c = e->cap;
+    HIPCHK(hipEventRecord(e->ev_io[0], s));
+    HIPCHK(hipStreamWaitEvent(c, e->ev_io[0], 0));
+    const long S7 = e->plan[0].S;
+    HIPCHK(hipMemcpyAsync(e->stg_mel, mel, (long)B * T * h.dim_freq * 4, hipMemcpyDeviceToDevice, c));
+    HIPCHK(hipMemcpyAsync(e->stg_f0, f0, (long)B * T * 4, hipMemcpyDeviceToDevice, c));
+    HIPCHK(hipMemcpyAsync(e->stg_emb, emb, (long)B * h.dim_spk_emb * 4, hipMemcpyDeviceToDevice, c));
+    HIPCHK(hipMemcpyAsync(e->stg_len, len_org, (long)B * 4, hipMemcpyDeviceToDevice, c));
+    HIPCHK(hipMemcpyAsync(e->stg_sc, scales, 4L * B * S7 * 4, hipMemcpyDeviceToDevice, c));
+    HIPCHK(hipMemcpyAsync(e->stg_ls, len_seg, 4L * B * S7 * 4, hipMemcpyDeviceToDevice, c));
+    ss_engine::StepGraph* sg = nullptr;
+    for (auto& g : e->graphs)
+        if (g.B == B && g.T == T && g.flags == flags && g.gs == grad_scale) sg = &g;
+    if (!sg) {
+        ss_engine::StepGraph ng{B, T, flags, grad_scale, nullptr, nullptr};
+        HIPCHK(hipStreamBeginCapture(c, hipStreamCaptureModeRelaxed));
+        const int rc = g3_step_body(e, e->stg_mel, e->stg_f0, e->stg_emb, e->stg_len, e->stg_sc, e->stg_ls, B, T, grad_scale,
+                                    flags, e->stg_loss, c);
+        const hipError_t ce = hipStreamEndCapture(c, &ng.g);
+        if (rc != 0) return rc;
+        if (ce != hipSuccess) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+        HIPCHK(hipGraphInstantiate(&ng.x, ng.g, nullptr, nullptr, 0));
+        e->graphs.push_back(ng);
+        sg = &e->graphs.back();
+    }
+    HIPCHK(hipGraphLaunch(sg->x, c));
+    if (loss) HIPCHK(hipMemcpyAsync(loss, e->stg_loss, 4, hipMemcpyDeviceToDevice, c));
+    HIPCHK(hipEventRecord(e->ev_io[1], c));
+    HIPCHK(hipStreamWaitEvent(s, e->ev_io[1], 0));
     return 0;
 }
 
@@ -1030,31 +1133,44 @@ int ss_tune(const char* key, int value) {
     else if (k == "lstm_g" && value >= 0 && value <= 16) g_lstm_g = value;
     else if (k == "lstm_mode" && value >= 0 && value <= 4) g_lstm_mode = value;
     else if (k == "overlap" && (value == 0 || value == 1)) g_overlap = value;
+    else if (k == "graph" && (value == 0 || value == 1)) g_graph = value;
     else if (k == "gemm_bk" && (value == 16 || value == 32)) g_gemm_bk = value;
     else if (k == "gemm_want" && value >= 1) g_gemm_want = value;
     else if (k == "gemm_diag" && value >= 0 && value < 64) g_gemm_diag = value;
     else return fail("ss_tune: unknown key or bad value: " + k);
+    ++g_tune_epoch;
     return 0;
 }
 
-int ss_op_lstm_fwd(float* gates, const float* whh_f, const float* whh_b, float* out, float* csave, int B, int T, int H,
-                   void* stream) {
+int ss_op_lstm_fwd(float* gates, const float* whh_f, const float* whh_b, float* out, float* csave, float* scratch,
+                   long scratch_floats, int B, int T, int H, void* stream) {
     hipStream_t s = S(stream);
     if (H > 32) {
-        for (int st = 0; st < T; ++st) HIPCHK(lstm_step_fwd(gates, whh_f, whh_b, out, csave, B, T, H, st, s));
+        const long half = 2L * (((B + 15) / 16) * 16) * H, wn = 2L * 4 * H * H;
+        if (!scratch || scratch_floats < wn + 2 * half) return fail("ss_op_lstm_fwd: scratch too small");
+        float* hf = scratch + wn;
+        HIPCHK(lstm_pack_w(whh_f, whh_b, scratch, H, 0, s));
+        HIPCHK(hipMemsetAsync(hf, 0, 2 * half * 4, s));
+        for (int st = 0; st < T; ++st)
+            HIPCHK(lstm_step_fwd(gates, scratch, hf + (st & 1) * half, hf + ((st & 1) ^ 1) * half, out, csave, B, T, H, st, s));
     } else {
         HIPCHK(lstm_small_fwd(gates, whh_f, whh_b, out, csave, B, T, H, s));
     }
     return 0;
 }
 
-int ss_op_lstm_bwd(float* gates, const float* whh_f, const float* whh_b, float* whhT_scratch, const float* d_out,
-                   const float* csave, float* dc_scratch, int B, int T, int H, void* stream) {
+int ss_op_lstm_bwd(float* gates, const float* whh_f, const float* whh_b, const float* d_out, const float* csave,
+                   float* scratch, long scratch_floats, int B, int T, int H, void* stream) {
     hipStream_t s = S(stream);
     if (H > 32) {
-        HIPCHK(transpose2d(whh_f, 4 * H, H, whhT_scratch, s));
-        HIPCHK(transpose2d(whh_b, 4 * H, H, whhT_scratch + 4L * H * H, s));
-        for (int st = 0; st < T; ++st) HIPCHK(lstm_step_bwd(gates, whhT_scratch, d_out, csave, dc_scratch, B, T, H, st, s));
+        const long half = 2L * (((B + 15) / 16) * 16) * 4 * H, wn = 2L * 4 * H * H;
+        if (!scratch || scratch_floats < wn + 2 * half + 2L * B * H) return fail("ss_op_lstm_bwd: scratch too small");
+        float* gf = scratch + wn;
+        float* dc = gf + 2 * half;
+        HIPCHK(lstm_pack_w(whh_f, whh_b, scratch, H, 1, s));
+        HIPCHK(hipMemsetAsync(gf, 0, 2 * half * 4, s));
+        for (int st = 0; st < T; ++st)
+            HIPCHK(lstm_step_bwd(gates, scratch, gf + (st & 1) * half, gf + ((st & 1) ^ 1) * half, d_out, csave, dc, B, T, H, st, s));
     } else {
         HIPCHK(lstm_small_bwd(gates, whh_f, whh_b, d_out, csave, B, T, H, s));
     }

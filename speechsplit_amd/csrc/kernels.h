@@ -86,10 +86,16 @@ hipError_t lstm_small_bwd(float* gates, const float* whh_f, const float* whh_b, 
                           int B, int T, int H, hipStream_t s);
 
 // ---------------------------------------------------------------- lstm_step.hip  (hidden % 64 == 0: one launch per time step)
-hipError_t lstm_step_fwd(float* gates, const float* whh_f, const float* whh_b, float* out, float* csave, int B, int T,
-                         int H, int step, hipStream_t s);
-// whhT: [2][H][4H] (transposed recurrent weights).  dc: [2][B][H] running cell-state gradient (zeroed before step 0).
-hipError_t lstm_step_bwd(float* gates, const float* whhT, const float* d_out, const float* csave, float* dc, int B, int T,
-                         int H, int step, hipStream_t s);
+// MFMA operands are streamed from fragment-major copies (see lstm_step.hip):
+//   wfrag  [2][H/16][4][H/16][64][4]   W_hh for the forward step        (lstm_pack_w, transposed = 0)
+//   wfragT [2][H/16][4H/16][64][4]     W_hh^T for the backward step     (lstm_pack_w, transposed = 1)
+//   hf     [2 ping-pong][2][ceil(B/16)][H/16][64][4]    h(t)   written by the forward epilogue, zero before step 0
+//   gf     [2 ping-pong][2][ceil(B/16)][4H/16][64][4]   da(t)  written by the backward epilogue, zero before step 0
+hipError_t lstm_pack_w(const float* whh_f, const float* whh_b, float* frag, int H, int transposed, hipStream_t s);
+hipError_t lstm_step_fwd(float* gates, const float* wfrag, const float* hf_cur, float* hf_next, float* out, float* csave,
+                         int B, int T, int H, int step, hipStream_t s);
+// dc: [2][B][H] running cell-state gradient (no initialisation needed).
+hipError_t lstm_step_bwd(float* gates, const float* wfragT, const float* gf_cur, float* gf_next, const float* d_out,
+                         const float* csave, float* dc, int B, int T, int H, int step, hipStream_t s);
 
 }  // namespace ss

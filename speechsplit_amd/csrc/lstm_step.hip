@@ -17,14 +17,18 @@
 // not by the 1.7 us of MFMA work: the loads are issued in groups of G chunks, one group ahead of the MFMAs that
 // consume them (NW and G are tuning knobs, ss_tune("lstm_nw" / "lstm_g")).
 //
-// h(t-1) and c(t-1) are read from the haloed output / cell slabs themselves (row t-1, or the all-zero halo row at
-// the first step), so there is no separate state buffer and no branch for the initial state.
+// Both MFMA operands are streamed from "fragment-major" copies: the exact 1 KiB (64 lanes x 16 B) a wave-instruction
+// consumes is contiguous in memory, so every load instruction touches 8 full 128-byte lines instead of 16 half-used
+// ones (the step is bound by L1/L2 line throughput per CU, measured: loads 4.5 us of an 8 us step).  W_hh is
+// re-laid once per layer and training step (lstm_pack_w); h(t) / da(t) are written in that form by the epilogue of
+// the step that produces them, into a ping-pong pair (zero-filled before step 0 = zero initial state).
+// c(t-1) is read from the haloed cell slab itself (row t-1, or the all-zero halo row at the first step).
 #include "common.h"
 #include "kernels.h"
 
 namespace ss {
 
-int g_lstm_nw = 8;    // waves per workgroup in the step kernels (4, 8 or 16)
+int g_lstm_nw = 16;   // waves per workgroup in the step kernels (4, 8 or 16)
 int g_lstm_g = 0;     // chunks per load group (0 = default for the chosen NW)
 int g_lstm_mode = 0;  // diagnostics only: 1 = skip MFMAs, 2 = skip operand loads, 3 = empty kernel, 4 = skip epilogue
 
@@ -36,9 +40,10 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 
 // grid = (H/16, ceil(B/16), 2), block = 64*NW
 template <int H, int NW, int G>
-__global__ __launch_bounds__(64 * NW) void lstm_step_fwd_kernel(float* __restrict__ gates, const float* __restrict__ whh_f,
-                                                                const float* __restrict__ whh_b, float* __restrict__ out,
-                                                                float* __restrict__ csave, int B, int T, int step, int mode) {
+__global__ __launch_bounds__(64 * NW) void lstm_step_fwd_kernel(float* __restrict__ gates, const float* __restrict__ wfrag,
+                                                                const float* __restrict__ hf_cur, float* __restrict__ hf_next,
+                                                                float* __restrict__ out, float* __restrict__ csave, int B,
+                                                                int T, int step, int mode) {
     __shared__ float red[NW][4][16][16];
     if (mode == 3) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -46,17 +51,17 @@ __global__ __launch_bounds__(64 * NW) void lstm_step_fwd_kernel(float* __restric
     const int TP = T + 2 * HALO;
     const int tau = HALO + (dir == 0 ? step : T - 1 - step);
     const int tau_prev = dir == 0 ? tau - 1 : tau + 1;
-    const float* whh = dir ? whh_b : whh_f;
-    const int li = lane & 15, lk = (lane >> 4) * 4;
+    const int li = lane & 15;
     constexpr int kw = H / NW;                              // K range of this wave
     constexpr int nchunk = kw / 16;
+    constexpr int NC = H / 16;                              // chunks along K
     static_assert(kw % 16 == 0 && nchunk % G == 0, "bad NW / G for this H");
-    int bA = b0 + li;
-    if (bA > B - 1) bA = B - 1;
-    const float* Ap = out + ((long)bA * TP + tau_prev) * (2 * H) + dir * H + w * kw + lk;
+    const int nbt = gridDim.y;
+    // fragment-major operands: [dir][btile][chunk][lane][4] and [dir][jtile][gate][chunk][lane][4]
+    const float* Ap = hf_cur + (((long)dir * nbt + blockIdx.y) * NC + w * nchunk) * 256 + lane * 4;
     const float* Bp[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) Bp[g] = whh + (long)(g * H + j0 + li) * H + w * kw + lk;
+    for (int g = 0; g < 4; ++g) Bp[g] = wfrag + ((((long)dir * (H / 16) + blockIdx.x) * 4 + g) * NC + w * nchunk) * 256 + lane * 4;
 
     // operands of the cell update (first 256 threads), requested before the contraction
     const int bi = (tid >> 4) & 15, jj = tid & 15;
@@ -83,9 +88,9 @@ __global__ __launch_bounds__(64 * NW) void lstm_step_fwd_kernel(float* __restric
 #pragma unroll
                 for (int g = 0; g < 4; ++g) bv[buf][i][g] = f32x4{1.f, 2.f, 3.f, 4.f};
             } else {
-                a[buf][i] = ld4(Ap + (c0 + i) * 16);
+                a[buf][i] = ld4(Ap + (c0 + i) * 256);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) bv[buf][i][g] = ld4(Bp[g] + (c0 + i) * 16);
+                for (int g = 0; g < 4; ++g) bv[buf][i][g] = ld4(Bp[g] + (c0 + i) * 256);
             }
         }
     };
@@ -138,12 +143,15 @@ __global__ __launch_bounds__(64 * NW) void lstm_step_fwd_kernel(float* __restric
         grow[3 * H] = go;
         csave[o] = c;
         out[o] = h;
+        // h(t) in MFMA-operand order for the next step: chunk = this workgroup's hidden tile
+        hf_next[(((long)dir * nbt + blockIdx.y) * NC + blockIdx.x) * 256 + ((jj >> 2) * 16 + bi) * 4 + (jj & 3)] = h;
     }
 }
 
 // grid = (H/16, ceil(B/16), 2), block = 64*NW
 template <int H, int NW, int G>
-__global__ __launch_bounds__(64 * NW) void lstm_step_bwd_kernel(float* __restrict__ gates, const float* __restrict__ whhT,
+__global__ __launch_bounds__(64 * NW) void lstm_step_bwd_kernel(float* __restrict__ gates, const float* __restrict__ wfragT,
+                                                                const float* __restrict__ gf_cur, float* __restrict__ gf_next,
                                                                 const float* __restrict__ d_out,
                                                                 const float* __restrict__ csave, float* __restrict__ dcs,
                                                                 int B, int T, int step) {
@@ -152,16 +160,16 @@ __global__ __launch_bounds__(64 * NW) void lstm_step_bwd_kernel(float* __restric
     const int dir = blockIdx.z, j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
     const int TP = T + 2 * HALO;
     const int tau = HALO + (dir == 0 ? T - 1 - step : step);
-    const int tau_next = dir == 0 ? tau + 1 : tau - 1;       // processed by the previous backward step (halo at step 0)
     const int tau_prev = dir == 0 ? tau - 1 : tau + 1;       // previous in forward order (c(t-1))
-    const int li = lane & 15, lk = (lane >> 4) * 4;
+    const int li = lane & 15;
     constexpr int kw = 4 * H / NW;                           // K = 4H split over the waves
     constexpr int nchunk = kw / 16;
+    constexpr int NC = 4 * H / 16;
     static_assert(kw % 16 == 0 && nchunk % G == 0, "bad NW / G for this H");
-    int bA = b0 + li;
-    if (bA > B - 1) bA = B - 1;
-    const float* Ap = gates + ((long)bA * TP + tau_next) * (8 * H) + dir * 4 * H + w * kw + lk;
-    const float* Bp = whhT + ((long)dir * H + j0 + li) * (4 * H) + w * kw + lk;
+    const int nbt = gridDim.y;
+    // da(t+1) of the previous backward step and W_hh^T, both fragment-major
+    const float* Ap = gf_cur + (((long)dir * nbt + blockIdx.y) * NC + w * nchunk) * 256 + lane * 4;
+    const float* Bp = wfragT + (((long)dir * (H / 16) + blockIdx.x) * NC + w * nchunk) * 256 + lane * 4;
 
     const int bi = (tid >> 4) & 15, jj = tid & 15;
     const int b = b0 + bi, j = j0 + jj;
@@ -186,8 +194,8 @@ __global__ __launch_bounds__(64 * NW) void lstm_step_bwd_kernel(float* __restric
     auto load_group = [&](int buf, int c0) {
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-            a[buf][i] = ld4(Ap + (c0 + i) * 16);
-            v[buf][i] = ld4(Bp + (c0 + i) * 16);
+            a[buf][i] = ld4(Ap + (c0 + i) * 256);
+            v[buf][i] = ld4(Bp + (c0 + i) * 256);
         }
     };
     load_group(0, 0);
@@ -216,35 +224,80 @@ __global__ __launch_bounds__(64 * NW) void lstm_step_bwd_kernel(float* __restric
         const float d_o = dh * tc;
         const float dc = dc_rec + dh * go * (1.0f - tc * tc);
         *dcp = dc * gf;
-        grow[0] = dc * gg * gi * (1.0f - gi);
-        grow[H] = dc * cp * gf * (1.0f - gf);
-        grow[2 * H] = dc * gi * (1.0f - gg * gg);
-        grow[3 * H] = d_o * go * (1.0f - go);
+        float da[4];
+        da[0] = dc * gg * gi * (1.0f - gi);
+        da[1] = dc * cp * gf * (1.0f - gf);
+        da[2] = dc * gi * (1.0f - gg * gg);
+        da[3] = d_o * go * (1.0f - go);
+        float* gfp = gf_next + ((long)dir * nbt + blockIdx.y) * NC * 256 + ((jj >> 2) * 16 + bi) * 4 + (jj & 3);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            grow[g * H] = da[g];                                     // slab copy: operand of the weight-gradient GEMMs
+            gfp[(long)(g * (H / 16) + blockIdx.x) * 256] = da[g];    // fragment-major copy: operand of the next step
+        }
+    }
+}
+
+// W_hh [4H][H] of both directions -> forward fragments [dir][jtile][gate][chunk][lane][4] (transposed == 0)
+//                                 or backward fragments [dir][jtile][chunk over 4H][lane][4] of W_hh^T (transposed == 1)
+__global__ __launch_bounds__(256) void lstm_pack_w_kernel(const float* __restrict__ whh_f, const float* __restrict__ whh_b,
+                                                          float* __restrict__ frag, int H, int transposed) {
+    const long n = 2L * 4 * H * H;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int q = (int)(i & 3), lane = (int)((i >> 2) & 63);
+        const int li = lane & 15, kg = lane >> 4;
+        long rest = i >> 8;
+        float v;
+        if (!transposed) {
+            const int NC = H / 16;
+            const int c = (int)(rest % NC);
+            rest /= NC;
+            const int g = (int)(rest & 3);
+            rest >>= 2;
+            const int jt = (int)(rest % (H / 16));
+            const int dir = (int)(rest / (H / 16));
+            const float* w = dir ? whh_b : whh_f;
+            v = w[(long)(g * H + jt * 16 + li) * H + c * 16 + kg * 4 + q];
+        } else {
+            const int NC = 4 * H / 16;
+            const int c = (int)(rest % NC);
+            rest /= NC;
+            const int jt = (int)(rest % (H / 16));
+            const int dir = (int)(rest / (H / 16));
+            const float* w = dir ? whh_b : whh_f;
+            v = w[(long)(c * 16 + kg * 4 + q) * H + jt * 16 + li];
+        }
+        frag[i] = v;
     }
 }
 
 template <int H, int NW, int G>
-hipError_t fwd_l(float* gates, const float* whh_f, const float* whh_b, float* out, float* csave, int B, int T, int step,
-                 hipStream_t s) {
-    hipLaunchKernelGGL((lstm_step_fwd_kernel<H, NW, G>), dim3(H / 16, cdiv(B, 16), 2), dim3(64 * NW), 0, s, gates, whh_f,
-                       whh_b, out, csave, B, T, step, g_lstm_mode);
+hipError_t fwd_l(float* gates, const float* wfrag, const float* hf_cur, float* hf_next, float* out, float* csave, int B, int T,
+                 int step, hipStream_t s) {
+    hipLaunchKernelGGL((lstm_step_fwd_kernel<H, NW, G>), dim3(H / 16, cdiv(B, 16), 2), dim3(64 * NW), 0, s, gates, wfrag, hf_cur,
+                       hf_next, out, csave, B, T, step, g_lstm_mode);
     return hipGetLastError();
 }
 template <int H, int NW, int G>
-hipError_t bwd_l(float* gates, const float* whhT, const float* d_out, const float* csave, float* dc, int B, int T, int step,
-                 hipStream_t s) {
-    hipLaunchKernelGGL((lstm_step_bwd_kernel<H, NW, G>), dim3(H / 16, cdiv(B, 16), 2), dim3(64 * NW), 0, s, gates, whhT, d_out,
-                       csave, dc, B, T, step);
+hipError_t bwd_l(float* gates, const float* wfragT, const float* gf_cur, float* gf_next, const float* d_out, const float* csave,
+                 float* dc, int B, int T, int step, hipStream_t s) {
+    hipLaunchKernelGGL((lstm_step_bwd_kernel<H, NW, G>), dim3(H / 16, cdiv(B, 16), 2), dim3(64 * NW), 0, s, gates, wfragT, gf_cur,
+                       gf_next, d_out, csave, dc, B, T, step);
     return hipGetLastError();
 }
 
 }  // namespace
 
-#define FWD_ARGS gates, whh_f, whh_b, out, csave, B, T, step, s
-#define BWD_ARGS gates, whhT, d_out, csave, dc, B, T, step, s
+#define FWD_ARGS gates, wfrag, hf_cur, hf_next, out, csave, B, T, step, s
+#define BWD_ARGS gates, wfragT, gf_cur, gf_next, d_out, csave, dc, B, T, step, s
 
-hipError_t lstm_step_fwd(float* gates, const float* whh_f, const float* whh_b, float* out, float* csave, int B, int T,
-                         int H, int step, hipStream_t s) {
+hipError_t lstm_pack_w(const float* whh_f, const float* whh_b, float* frag, int H, int transposed, hipStream_t s) {
+    hipLaunchKernelGGL(lstm_pack_w_kernel, dim3(2048), dim3(256), 0, s, whh_f, whh_b, frag, H, transposed);
+    return hipGetLastError();
+}
+
+hipError_t lstm_step_fwd(float* gates, const float* wfrag, const float* hf_cur, float* hf_next, float* out, float* csave,
+                         int B, int T, int H, int step, hipStream_t s) {
     const int nw = g_lstm_nw, g = g_lstm_g;
     switch (H) {
         case 64: return fwd_l<64, 4, 1>(FWD_ARGS);
@@ -262,8 +315,8 @@ hipError_t lstm_step_fwd(float* gates, const float* whh_f, const float* whh_b, f
     }
 }
 
-hipError_t lstm_step_bwd(float* gates, const float* whhT, const float* d_out, const float* csave, float* dc, int B, int T,
-                         int H, int step, hipStream_t s) {
+hipError_t lstm_step_bwd(float* gates, const float* wfragT, const float* gf_cur, float* gf_next, const float* d_out,
+                         const float* csave, float* dc, int B, int T, int H, int step, hipStream_t s) {
     const int nw = g_lstm_nw, g = g_lstm_g;
     switch (H) {
         case 64: return bwd_l<64, 4, 2>(BWD_ARGS);

@@ -90,8 +90,7 @@ def bench_lstm(B=64, T=128, H=512):
         gates[:, 2:2 + Tx] = xp.reshape(Bx, Tx, 8 * H)
         return gates, torch.zeros(Bx, Tx + 4, 2 * H, device=dev), torch.zeros(Bx, Tx + 4, 2 * H, device=dev)
 
-    whhT = torch.empty(2, H, 4 * H, device=dev)
-    dc = torch.empty(2, B, H, device=dev)
+    scratch = torch.zeros(8 * H * H + 16 * B * H + 2 * B * H + 1024, device=dev)
     dpad = torch.zeros(B, TP, 2 * H, device=dev)
     dpad[:, 2:2 + T] = d_out
     results = []
@@ -101,14 +100,14 @@ def bench_lstm(B=64, T=128, H=512):
             tune('lstm_g', gi)
             # correctness (fwd) on the small slice
             gs_, o_, c_ = slabs(4, 16, xproj[:4, :16].contiguous())
-            _capi.check(lib.ss_op_lstm_fwd(P(gs_), P(whh[0]), P(whh[1]), P(o_), P(c_), 4, 16, H, S()))
+            _capi.check(lib.ss_op_lstm_fwd(P(gs_), P(whh[0]), P(whh[1]), P(o_), P(c_), P(scratch), scratch.numel(), 4, 16, H, S()))
             err = float((o_[:, 2:18].double() - ref_out).abs().max())
             gates, out, cs = slabs(B, T, xproj)
             xp_keep = gates.clone()
 
             def fwd():
                 gates.copy_(xp_keep)
-                _capi.check(lib.ss_op_lstm_fwd(P(gates), P(whh[0]), P(whh[1]), P(out), P(cs), B, T, H, S()))
+                _capi.check(lib.ss_op_lstm_fwd(P(gates), P(whh[0]), P(whh[1]), P(out), P(cs), P(scratch), scratch.numel(), B, T, H, S()))
 
             def copy_only():
                 gates.copy_(xp_keep)
@@ -117,7 +116,7 @@ def bench_lstm(B=64, T=128, H=512):
 
             def bwd():
                 gates.copy_(ga_keep)
-                _capi.check(lib.ss_op_lstm_bwd(P(gates), P(whh[0]), P(whh[1]), P(whhT), P(dpad), P(cs), P(dc), B, T, H, S()))
+                _capi.check(lib.ss_op_lstm_bwd(P(gates), P(whh[0]), P(whh[1]), P(dpad), P(cs), P(scratch), scratch.numel(), B, T, H, S()))
             tb = timeit(bwd)[0] - timeit(copy_only)[0]
             results.append((nw, gi, tf, tb, err))
             say(f'lstm H{H} B{B} T{T} nw{nw} g{gi}: fwd {tf / T:.2f} us/step  bwd {tb / T:.2f} us/step  (fwd err {err:.1e})')
@@ -128,12 +127,12 @@ def bench_lstm(B=64, T=128, H=512):
         gates, out, cs = slabs(B, T, xproj)
         xp_keep = gates.clone()
         gates.copy_(xp_keep)
-        _capi.check(lib.ss_op_lstm_fwd(P(gates), P(whh[0]), P(whh[1]), P(out), P(cs), B, T, H, S()))
+        _capi.check(lib.ss_op_lstm_fwd(P(gates), P(whh[0]), P(whh[1]), P(out), P(cs), P(scratch), scratch.numel(), B, T, H, S()))
         ga_keep = gates.clone()
 
         def bwd():
             gates.copy_(ga_keep)
-            _capi.check(lib.ss_op_lstm_bwd(P(gates), P(whh[0]), P(whh[1]), P(whhT), P(dpad), P(cs), P(dc), B, T, H, S()))
+            _capi.check(lib.ss_op_lstm_bwd(P(gates), P(whh[0]), P(whh[1]), P(dpad), P(cs), P(scratch), scratch.numel(), B, T, H, S()))
 
         def copy_only():
             gates.copy_(ga_keep)
@@ -197,14 +196,14 @@ def bench_step():
     sc, ls = E.draw_interp(B, 4, hp)
     sc, ls = sc.cuda(), ls.cuda()
     tune('gemm_bk', 16)
-    tune('lstm_nw', 8)
-    tune('lstm_g', 4)
+    tune('gemm_want', 1024)
     for rnd in range(2):
-        for ov, want in [(0, 256), (1, 256), (0, 1024), (1, 1024)]:
+        for gr, ov, nw in [(0, 1, 16), (1, 1, 16), (1, 0, 16), (1, 1, 8)]:
+            tune('graph', gr)
             tune('overlap', ov)
-            tune('gemm_want', want)
+            tune('lstm_nw', nw)
             t, tmin = timeit(lambda: eng.g3_train_step(mel, f0, emb, lens, (sc, ls)), iters=10, warm=3)
-            say(f'train step overlap{ov} want{want}: {t / 1e3:.3f} ms  ({B / t * 1e6:.0f} utt/s) min {tmin / 1e3:.3f}, loss {float(eng.loss):.6f}')
+            say(f'train step graph{gr} overlap{ov} nw{nw}: {t / 1e3:.3f} ms  ({B / t * 1e6:.0f} utt/s) min {tmin / 1e3:.3f}, loss {float(eng.loss):.6f}')
 
 
 def bench_lstm_modes(B=64, T=128, H=512):
@@ -213,13 +212,14 @@ def bench_lstm_modes(B=64, T=128, H=512):
     out = torch.zeros(B, T + 4, 2 * H, device=dev)
     cs = torch.zeros(B, T + 4, 2 * H, device=dev)
     whh = torch.randn(2, 4 * H, H, device=dev) / H ** 0.5
+    scratch = torch.zeros(8 * H * H + 16 * B * H + 2 * B * H + 1024, device=dev)
     names = {0: 'full', 1: 'loads, no MFMA', 2: 'MFMA, no operand loads', 3: 'empty kernel', 4: 'loads+MFMA, no epilogue'}
     for nw, g in [(4, 4), (8, 4), (16, 2)]:
         tune('lstm_nw', nw)
         tune('lstm_g', g)
         for mode in (0, 1, 2, 3, 4):
             tune('lstm_mode', mode)
-            t = timeit(lambda: _capi.check(lib.ss_op_lstm_fwd(P(gates), P(whh[0]), P(whh[1]), P(out), P(cs), B, T, H, S())))[0]
+            t = timeit(lambda: _capi.check(lib.ss_op_lstm_fwd(P(gates), P(whh[0]), P(whh[1]), P(out), P(cs), P(scratch), scratch.numel(), B, T, H, S())))[0]
             say(f'lstm fwd nw{nw} g{g} mode {mode} ({names[mode]}): {t / T:.2f} us/step')
     tune('lstm_mode', 0)
     # host launch rate: an empty kernel launched 128 times is also the floor of the eager path
