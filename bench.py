@@ -114,9 +114,9 @@ def main():
         if world == 1:
             eng.g3_train_step(mel, f0, emb, lens, (sc, ls))
         else:
-            eng.g3_train_step(mel, f0, emb, lens, (sc, ls), no_adam=True)
-            dist.all_reduce(eng.grads)                       # RCCL sum over xGMI; mean taken inside the Adam kernel
-            eng.adam_step(grad_scale=1.0 / world)
+            # RCCL sum over xGMI in two buckets (decoder+head first, overlapped with the encoder backward);
+            # the mean is taken inside the Adam kernel
+            eng.dp_train_step(mel, f0, emb, lens, (sc, ls), world)
 
     def barrier():
         torch.cuda.synchronize()

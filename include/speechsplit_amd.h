@@ -35,6 +35,9 @@ typedef struct ss_hparams {
 #define SS_INTERP_ONLY 0 /* model.py:355 a bare InterpLnr module: no parameters, ss_interp_* only (arenas may be NULL) */
 
 #define SS_STEP_NO_ADAM 1 /* ss_*_train_step: stop after backward (data-parallel: all-reduce grads, then ss_adam_step) */
+#define SS_STEP_SPLIT_BACKWARD 2 /* ss_g3_train_step: return once the head + decoder gradients (arena offsets >=
+                                    ss_grad_split(), 80 % of the bytes, produced first) are complete, so their all-reduce
+                                    overlaps the encoder backward that ss_train_finish() then enqueues */
 
 const char* ss_last_error(void);
 int ss_abi_version(void);
@@ -84,6 +87,11 @@ int ss_g3_train_step(ss_engine* e, const float* mel_dev, const float* f0_dev, co
 int ss_g6_train_step(ss_engine* e, const float* mel_dev, const float* f0_onehot_dev, const int* target_idx_dev,
                      const float* scales_dev, const int* len_seg_dev, int B, int T, float grad_scale, int flags,
                      float* loss_dev, void* stream);
+
+/* second half of a SS_STEP_SPLIT_BACKWARD step: encoder backward (+ Adam unless SS_STEP_NO_ADAM) */
+int ss_train_finish(ss_engine* e, float grad_scale, int flags, void* stream);
+/* first arena offset (floats) of the decoder + head parameters; [0, split) is the encoder */
+long ss_grad_split(const ss_engine* e);
 
 /* torch.optim.Adam(G.parameters(), lr, [beta1, beta2]) (solver.py:62,172).  `step` = updates already applied. */
 int ss_set_adam(ss_engine* e, double lr, double beta1, double beta2, double eps, long step, void* stream);

@@ -20,6 +20,8 @@ using namespace ss;
 namespace ss {
 extern int g_lstm_nw, g_lstm_g, g_lstm_mode, g_gemm_bk, g_gemm_want, g_gemm_diag;
 int g_overlap = 1;     // 1: weight-gradient GEMMs on the side stream
+int g_split = 0;       // 1: decoder recurrences run as two batch-half chains on two streams (GEMMs of one half fill the
+                       //    machine while the other half sits in its latency-bound time loop)
 int g_graph = 0;       // 1: the fused training step is captured into a hipGraph and replayed (measured: no gain while the
                        // step is GPU-bound at batch 64; useful when the host is the bottleneck)
 int g_tune_epoch = 0;  // bumped by ss_tune: captured graphs bake the knobs in, so they are dropped when it changes
@@ -67,10 +69,10 @@ struct LstmBlk {
     std::vector<LstmDir> pd;               // [L*2]
     std::vector<float*> gates, out, csave; // per layer
     float* bsum = nullptr;                 // [L][2][4H]
-    float* wfrag = nullptr;                // fragment-major W_hh / W_hh^T (step kernels only), 2*4H*H floats
-    float* hf = nullptr;                   // ping-pong fragment-major h(t):  2 x [2][ceil(B/16)*16][H]
-    float* gf = nullptr;                   // ping-pong fragment-major da(t): 2 x [2][ceil(B/16)*16][4H]
-    float* dc = nullptr;                   // [2][B][H]
+    std::vector<float*> wfrag;             // per layer: fragment-major W_hh (forward) / W_hh^T (backward), 2*4H*H floats
+    float* hf[2] = {nullptr, nullptr};     // per batch-half chain: ping-pong fragment-major h(t),  2 x [2][ceil16(B)][H]
+    float* gf[2] = {nullptr, nullptr};     // per chain: ping-pong fragment-major da(t), 2 x [2][ceil16(B)][4H]
+    float* dc[2] = {nullptr, nullptr};     // per chain: [2][B][H]
     float* dmid[2] = {nullptr, nullptr};   // gradient slabs of inner layer outputs [B,TP,2H]
     bool big() const { return H > 32; }
     int in_of(int l) const { return l == 0 ? In : 2 * H; }
@@ -120,6 +122,7 @@ struct ss_engine {
     // weight-gradient GEMMs of a BLSTM layer run on this side stream while the next layer's recurrence (latency-bound,
     // one launch per time step) proceeds on the caller's stream
     hipStream_t side = nullptr;
+    hipStream_t side2 = nullptr;          // second batch-half chain of the decoder recurrences
     hipStream_t cap = nullptr;            // graphs are captured and replayed here (a legacy default stream cannot capture)
     hipEvent_t ev_io[2] = {};             // caller stream <-> cap ordering
     // captured training steps (hipGraph), keyed by geometry / flags / grad_scale; inputs are staged into engine-owned
@@ -134,7 +137,7 @@ struct ss_engine {
     int graph_epoch = 0;
     float *stg_mel = nullptr, *stg_f0 = nullptr, *stg_emb = nullptr, *stg_sc = nullptr, *stg_loss = nullptr;
     int *stg_len = nullptr, *stg_ls = nullptr;
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[16] = {};
     int ev_next = 0;
     bool side_used = false;
 
@@ -274,10 +277,13 @@ long ss_engine::carve(int B, int T, bool assign) {
         lb.bsum = (float*)take((long)lb.L * 2 * 4 * lb.H * 4);
         if (lb.big()) {
             const long B16 = ((B + 15) / 16) * 16;
-            lb.wfrag = (float*)take(2L * lb.H * 4 * lb.H * 4);
-            lb.hf = (float*)take(2L * 2 * B16 * lb.H * 4);
-            lb.gf = (float*)take(2L * 2 * B16 * 4 * lb.H * 4);
-            lb.dc = (float*)take(2L * B * lb.H * 4);
+            lb.wfrag.assign(lb.L, nullptr);
+            for (int l = 0; l < lb.L; ++l) lb.wfrag[l] = (float*)take(2L * lb.H * 4 * lb.H * 4);
+            for (int c = 0; c < 2; ++c) {
+                lb.hf[c] = (float*)take(2L * 2 * B16 * lb.H * 4);
+                lb.gf[c] = (float*)take(2L * 2 * B16 * 4 * lb.H * 4);
+                lb.dc[c] = (float*)take(2L * B * lb.H * 4);
+            }
         }
         if (lb.L > 1) {
             lb.dmid[0] = slab((name + ".dmid0").c_str(), 2L * lb.H);
@@ -402,7 +408,7 @@ int pick_ksplit(int M, int N, long K) {
 // make `to` wait for everything enqueued on `from` so far
 int fork_join(ss_engine* e, hipStream_t from, hipStream_t to) {
     hipEvent_t ev = e->ev[e->ev_next];
-    e->ev_next = (e->ev_next + 1) & 7;
+    e->ev_next = (e->ev_next + 1) & 15;
     HIPCHK(hipEventRecord(ev, from));
     HIPCHK(hipStreamWaitEvent(to, ev, 0));
     return 0;
@@ -478,7 +484,76 @@ int conv_block_bwd(ss_engine* e, ConvBlk& cb, Slab dy, Slab x, Slab dx, hipStrea
 }
 
 // ---- BLSTM block -------------------------------------------------------------------------------------------
+struct Chain {
+    int b0, nb;
+    hipStream_t st;
+};
+
+int make_chains(ss_engine* e, int B, hipStream_t s, Chain ch[2]) {
+    if (g_split && e->side2 && B >= 32) {
+        const int bA = ((B / 2 + 15) / 16) * 16;
+        ch[0] = {0, bA, s};
+        ch[1] = {bA, B - bA, e->side2};
+        return 2;
+    }
+    ch[0] = {0, B, s};
+    return 1;
+}
+
+// Decoder-size BLSTM (one launch per time step).  The batch is cut in two halves that run as independent chains on
+// two streams through ALL layers: every operator is per-utterance, so nothing couples them until the head.
+int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
+    const int B = e->curB, T = e->curT, H = lb.H;
+    const long TP = T + 2 * HALO;
+    Chain ch[2];
+    const int nch = make_chains(e, B, s, ch);
+    for (int l = 0; l < lb.L; ++l) {
+        for (int dir = 0; dir < 2; ++dir) {
+            const LstmDir& pd = lb.pd[l * 2 + dir];
+            HIPCHK(add_vec(e->P + pd.bih, e->P + pd.bhh, lb.bsum + ((long)l * 2 + dir) * 4 * H, 4 * H, s));
+        }
+        HIPCHK(lstm_pack_w(e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.wfrag[l], H, 0, s));
+    }
+    if (nch == 2) CHK(fork_join(e, s, ch[1].st));
+    for (int l = 0; l < lb.L; ++l) {
+        const int In = lb.in_of(l);
+        Slab xi = l == 0 ? x : Slab{lb.out[l - 1], 2L * H};
+        for (int c = 0; c < nch; ++c) {
+            const long r0 = (long)ch[c].b0 * TP;
+            for (int dir = 0; dir < 2; ++dir) {
+                const LstmDir& pd = lb.pd[l * 2 + dir];
+                GemmDesc d{};
+                d.A = {xi.p + (r0 + HALO) * xi.ld, xi.ld, TP * xi.ld, 0, 0};
+                d.B = {e->P + pd.wih, In, 0, 0, 0};
+                d.C = lb.gates[l] + (r0 + HALO) * 8L * H + dir * 4L * H;
+                d.ldc = 8L * H;
+                d.cstride = TP * 8L * H;
+                d.bias = lb.bsum + ((long)l * 2 + dir) * 4 * H;
+                d.M = T;
+                d.N = 4 * H;
+                d.K = In;
+                d.batch = ch[c].nb;
+                d.ksplit = 1;
+                GEMM_ON(d, ch[c].st);
+            }
+            const long half = 2L * (((ch[c].nb + 15) / 16) * 16) * H;
+            HIPCHK(hipMemsetAsync(lb.hf[c], 0, 2 * half * 4, ch[c].st));
+        }
+        for (int st = 0; st < T; ++st)
+            for (int c = 0; c < nch; ++c) {
+                const long r0 = (long)ch[c].b0 * TP;
+                const long half = 2L * (((ch[c].nb + 15) / 16) * 16) * H;
+                HIPCHK(lstm_step_fwd(lb.gates[l] + r0 * 8L * H, lb.wfrag[l], lb.hf[c] + (st & 1) * half,
+                                     lb.hf[c] + ((st & 1) ^ 1) * half, lb.out[l] + r0 * 2L * H, lb.csave[l] + r0 * 2L * H,
+                                     ch[c].nb, T, H, st, ch[c].st));
+            }
+    }
+    if (nch == 2) CHK(fork_join(e, ch[1].st, s));
+    return 0;
+}
+
 int lstm_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
+    if (lb.big()) return lstm_big_fwd(e, lb, x, s);
     const int B = e->curB, T = e->curT, H = lb.H;
     const long TP = T + 2 * HALO;
     for (int l = 0; l < lb.L; ++l) {
@@ -502,18 +577,71 @@ int lstm_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
             d.ksplit = 1;
             GEMM(d);
         }
-        const float* wf = e->P + lb.pd[l * 2].whh;
-        const float* wb = e->P + lb.pd[l * 2 + 1].whh;
-        if (lb.big()) {
-            const long half = 2L * (((B + 15) / 16) * 16) * H;
-            HIPCHK(lstm_pack_w(wf, wb, lb.wfrag, H, 0, s));
-            HIPCHK(hipMemsetAsync(lb.hf, 0, 2 * half * 4, s));
-            for (int st = 0; st < T; ++st)
-                HIPCHK(lstm_step_fwd(lb.gates[l], lb.wfrag, lb.hf + (st & 1) * half, lb.hf + ((st & 1) ^ 1) * half, lb.out[l],
-                                     lb.csave[l], B, T, H, st, s));
-        } else {
-            HIPCHK(lstm_small_fwd(lb.gates[l], wf, wb, lb.out[l], lb.csave[l], B, T, H, s));
-        }
+        HIPCHK(lstm_small_fwd(lb.gates[l], e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.out[l], lb.csave[l], B, T, H,
+                              s));
+    }
+    return 0;
+}
+
+// d_top: gradient slab of the last layer's output [B,TP,2H]; x: forward input; dx: input-gradient view or null
+// weight / bias gradients of one layer from its finished pre-activation gradient slab (full batch, flat over all rows)
+int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, hipStream_t ws) {
+    const int B = e->curB, T = e->curT, H = lb.H;
+    const long TP = T + 2 * HALO, R = (long)B * TP;
+    const int In = lb.in_of(l);
+    float* dG = lb.gates[l];
+    for (int dir = 0; dir < 2; ++dir) {
+        const LstmDir& pd = lb.pd[l * 2 + dir];
+        const float* dGd = dG + dir * 4L * H;
+        // dW_ih[n][k] = sum_r dG[r][n] * X[r][k]
+        GemmDesc a{};
+        a.A = {dGd, 8L * H, 0, 0, 0};
+        a.B = {xi.p, xi.ld, 0, 0, 0};
+        a.C = e->G + pd.wih;
+        a.ldc = In;
+        a.M = 4 * H;
+        a.N = In;
+        a.K = (int)R;
+        a.batch = 1;
+        a.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM;
+        a.ksplit = pick_ksplit(a.M, a.N, a.K);
+        GEMM_ON(a, ws);
+        // dW_hh[n][k] = sum_r dG[r][n] * h_prev[r][k];  h_prev = out one row earlier (fwd) / later (reverse)
+        GemmDesc h{};
+        h.A = {dir == 0 ? dGd + 8L * H : dGd, 8L * H, 0, 0, 0};
+        h.B = {dir == 0 ? lb.out[l] : lb.out[l] + 2L * H + H, 2L * H, 0, 0, 0};
+        h.C = e->G + pd.whh;
+        h.ldc = H;
+        h.M = 4 * H;
+        h.N = H;
+        h.K = (int)(R - 1);
+        h.batch = 1;
+        h.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM;
+        h.ksplit = pick_ksplit(h.M, h.N, h.K);
+        GEMM_ON(h, ws);
+        HIPCHK(colsum_acc(dGd, 8L * H, (int)R, 4 * H, e->G + pd.bih, ws));
+        HIPCHK(hipMemcpyAsync(e->G + pd.bhh, e->G + pd.bih, 4L * H * 4, hipMemcpyDeviceToDevice, ws));
+    }
+    return 0;
+}
+
+// input gradient of one layer for the slab rows [r0, r0 + nr):  dX = dG . W_ih  (both directions accumulate)
+int lstm_input_grad(ss_engine* e, LstmBlk& lb, int l, Slab dxi, long r0, long nr, hipStream_t st) {
+    const int H = lb.H, In = lb.in_of(l);
+    for (int dir = 0; dir < 2; ++dir) {
+        const LstmDir& pd = lb.pd[l * 2 + dir];
+        GemmDesc g{};
+        g.A = {lb.gates[l] + r0 * 8L * H + dir * 4L * H, 8L * H, 0, 0, 0};
+        g.B = {e->P + pd.wih, In, 0, 0, 0};
+        g.C = dxi.p + r0 * dxi.ld;
+        g.ldc = dxi.ld;
+        g.M = (int)nr;
+        g.N = In;
+        g.K = 4 * H;
+        g.batch = 1;
+        g.flags = GEMM_TB | (dir ? GEMM_ACCUM : 0);
+        g.ksplit = 1;
+        GEMM_ON(g, st);
     }
     return 0;
 }
@@ -523,80 +651,58 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
     const int B = e->curB, T = e->curT, H = lb.H;
     const long TP = T + 2 * HALO, R = (long)B * TP;
     const float* dcur = d_top;
+    Chain ch[2];
+    ch[0] = {0, B, s};
+    const int nch = lb.big() ? make_chains(e, B, s, ch) : 1;
+    if (lb.big()) {
+        for (int l = 0; l < lb.L; ++l)
+            HIPCHK(lstm_pack_w(e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.wfrag[l], H, 1, s));
+        if (nch == 2) CHK(fork_join(e, s, ch[1].st));
+    }
     for (int l = lb.L - 1; l >= 0; --l) {
-        const int In = lb.in_of(l);
         Slab xi = l == 0 ? x : Slab{lb.out[l - 1], 2L * H};
-        float* dG = lb.gates[l];
-        const float* wf = e->P + lb.pd[l * 2].whh;
-        const float* wb = e->P + lb.pd[l * 2 + 1].whh;
-        if (lb.big()) {
-            const long half = 2L * (((B + 15) / 16) * 16) * 4 * H;
-            HIPCHK(lstm_pack_w(wf, wb, lb.wfrag, H, 1, s));
-            HIPCHK(hipMemsetAsync(lb.gf, 0, 2 * half * 4, s));
-            for (int st = 0; st < T; ++st)
-                HIPCHK(lstm_step_bwd(dG, lb.wfrag, lb.gf + (st & 1) * half, lb.gf + ((st & 1) ^ 1) * half, dcur, lb.csave[l],
-                                     lb.dc, B, T, H, st, s));
-        } else {
-            HIPCHK(lstm_small_bwd(dG, wf, wb, dcur, lb.csave[l], B, T, H, s));
-        }
-        // input gradient first (the next layer's recurrence needs it), on the caller's stream
         Slab dxi = l == 0 ? dx : Slab{lb.dmid[l & 1], 2L * H};
+        float* dG = lb.gates[l];
         hipStream_t ws = s;
+        if (lb.big()) {
+            for (int c = 0; c < nch; ++c) {
+                const long half = 2L * (((ch[c].nb + 15) / 16) * 16) * 4 * H;
+                HIPCHK(hipMemsetAsync(lb.gf[c], 0, 2 * half * 4, ch[c].st));
+            }
+            for (int st = 0; st < T; ++st)
+                for (int c = 0; c < nch; ++c) {
+                    const long r0 = (long)ch[c].b0 * TP;
+                    const long half = 2L * (((ch[c].nb + 15) / 16) * 16) * 4 * H;
+                    HIPCHK(lstm_step_bwd(dG + r0 * 8L * H, lb.wfrag[l], lb.gf[c] + (st & 1) * half, lb.gf[c] + ((st & 1) ^ 1) * half,
+                                         dcur + r0 * 2L * H, lb.csave[l] + r0 * 2L * H, lb.dc[c], ch[c].nb, T, H, st, ch[c].st));
+                }
+        } else {
+            HIPCHK(lstm_small_bwd(dG, e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, dcur, lb.csave[l], B, T, H, s));
+        }
+        // the pre-activation gradients of this layer are complete once every chain has passed this point
         if (e->side && g_overlap) {
-            CHK(fork_join(e, s, e->side));        // dG of this layer is complete
+            for (int c = 0; c < nch; ++c) CHK(fork_join(e, ch[c].st, e->side));
             ws = e->side;
             e->side_used = true;
+        } else if (nch == 2) {
+            CHK(fork_join(e, ch[1].st, s));        // weight gradients run on s and need both halves
         }
-        if (dxi.p) {
-            for (int dir = 0; dir < 2; ++dir) {
-                const LstmDir& pd = lb.pd[l * 2 + dir];
-                GemmDesc g{};
-                g.A = {dG + dir * 4L * H, 8L * H, 0, 0, 0};
-                g.B = {e->P + pd.wih, In, 0, 0, 0};
-                g.C = dxi.p;
-                g.ldc = dxi.ld;
-                g.M = (int)R;
-                g.N = In;
-                g.K = 4 * H;
-                g.batch = 1;
-                g.flags = GEMM_TB | (dir ? GEMM_ACCUM : 0);
-                g.ksplit = 1;
-                GEMM(g);
-            }
-        }
-        for (int dir = 0; dir < 2; ++dir) {
-            const LstmDir& pd = lb.pd[l * 2 + dir];
-            const float* dGd = dG + dir * 4L * H;
-            // dW_ih[n][k] = sum_r dG[r][n] * X[r][k]
-            GemmDesc a{};
-            a.A = {dGd, 8L * H, 0, 0, 0};
-            a.B = {xi.p, xi.ld, 0, 0, 0};
-            a.C = e->G + pd.wih;
-            a.ldc = In;
-            a.M = 4 * H;
-            a.N = In;
-            a.K = (int)R;
-            a.batch = 1;
-            a.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM;
-            a.ksplit = pick_ksplit(a.M, a.N, a.K);
-            GEMM_ON(a, ws);
-            // dW_hh[n][k] = sum_r dG[r][n] * h_prev[r][k];  h_prev = out one row earlier (fwd) / later (reverse)
-            GemmDesc h{};
-            h.A = {dir == 0 ? dGd + 8L * H : dGd, 8L * H, 0, 0, 0};
-            h.B = {dir == 0 ? lb.out[l] : lb.out[l] + 2L * H + H, 2L * H, 0, 0, 0};
-            h.C = e->G + pd.whh;
-            h.ldc = H;
-            h.M = 4 * H;
-            h.N = H;
-            h.K = (int)(R - 1);
-            h.batch = 1;
-            h.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM;
-            h.ksplit = pick_ksplit(h.M, h.N, h.K);
-            GEMM_ON(h, ws);
-            HIPCHK(colsum_acc(dGd, 8L * H, (int)R, 4 * H, e->G + pd.bih, ws));
-            HIPCHK(hipMemcpyAsync(e->G + pd.bhh, e->G + pd.bih, 4L * H * 4, hipMemcpyDeviceToDevice, ws));
-        }
+        // input gradient first (the next layer's recurrence needs it), per chain on its own rows
+        if (dxi.p)
+            for (int c = 0; c < nch; ++c)
+                CHK(lstm_input_grad(e, lb, l, dxi, (long)ch[c].b0 * TP, nch == 2 ? (long)ch[c].nb * TP : R, ch[c].st));
+        CHK(lstm_weight_grads(e, lb, l, xi, ws));
         dcur = dxi.p;
+    }
+    if (nch == 2) CHK(fork_join(e, ch[1].st, s));
+    return 0;
+}
+
+// every gradient enqueued on the side stream so far is complete on `s` after this
+int join_side(ss_engine* e, hipStream_t s) {
+    if (e->side_used) {
+        CHK(fork_join(e, e->side, s));
+        e->side_used = false;
     }
     return 0;
 }
@@ -679,14 +785,10 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
 }
 
 // gradient of the loss w.r.t. the head output is in d_out_slab (halo rows zero)
-int backward_core(ss_engine* e, hipStream_t s) {
+int backward_decoder(ss_engine* e, hipStream_t s) {
     if (!e->have_fwd) return fail("backward without a preceding forward");
     const int B = e->curB, T = e->curT;
     const long TP = T + 2 * HALO, R = (long)B * TP;
-    const int CE = e->CE;
-    const bool g3 = e->kind == SS_GENERATOR_3;
-    const bool training = e->fwd_training;
-    const ss_hparams& h = e->hp;
     HIPCHK(hipMemsetAsync(e->G, 0, e->arena * 4, s));
     // head
     const long HD = 2L * e->ld.H;
@@ -719,6 +821,18 @@ int backward_core(ss_engine* e, hipStream_t s) {
         GEMM(g);
     }
     CHK(lstm_bwd(e, e->ld, e->d_top, Slab{e->dec_in, e->dec_in_dim}, Slab{e->d_dec_in, e->dec_in_dim}, s));
+    return 0;
+}
+
+// everything below the decoder input: code gradients, encoder BLSTMs, conv trunks.  Touches only gradient-arena
+// offsets below the decoder's, so a data-parallel caller can all-reduce the decoder range meanwhile.
+int backward_encoder(ss_engine* e, hipStream_t s) {
+    const int B = e->curB, T = e->curT;
+    const long TP = T + 2 * HALO, R = (long)B * TP;
+    const int CE = e->CE;
+    const bool g3 = e->kind == SS_GENERATOR_3;
+    const bool training = e->fwd_training;
+    const ss_hparams& h = e->hp;
     CodeSrc src[3];
     int n = 0;
     if (g3) {
@@ -758,11 +872,13 @@ int backward_core(ss_engine* e, hipStream_t s) {
             HIPCHK(hipMemcpyAsync(e->d_xf, e->d_act, R * CE * 4, hipMemcpyDeviceToDevice, s));
         }
     }
-    if (e->side_used) {                           // every gradient is complete on the caller's stream from here on
-        CHK(fork_join(e, e->side, s));
-        e->side_used = false;
-    }
+    CHK(join_side(e, s));
     return 0;
+}
+
+int backward_core(ss_engine* e, hipStream_t s) {
+    CHK(backward_decoder(e, s));
+    return backward_encoder(e, s);
 }
 
 }  // namespace
@@ -840,6 +956,10 @@ void ss_destroy(ss_engine* e) {
         for (auto& ev : e->ev)
             if (ev) (void)hipEventDestroy(ev);
         (void)hipStreamDestroy(e->side);
+        if (e->side2) {
+            (void)hipStreamSynchronize(e->side2);
+            (void)hipStreamDestroy(e->side2);
+        }
         if (e->cap) {
             (void)hipStreamSynchronize(e->cap);
             for (auto& ev : e->ev_io)
@@ -892,6 +1012,7 @@ int ss_bind(ss_engine* e, float* params, float* grads, float* m, float* v, void*
     if (!e->side && e->kind != SS_INTERP_ONLY) {
         HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
         for (auto& ev : e->ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIPCHK(hipStreamCreateWithFlags(&e->side2, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&e->cap, hipStreamNonBlocking));
         for (auto& ev : e->ev_io) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
@@ -1014,6 +1135,10 @@ static int g3_step_body(ss_engine* e, const float* mel, const float* f0, const f
     const int C = e->head_out;
     HIPCHK(mse_loss(e->out_slab + HALO * C, C, TP * C, e->org + HALO * C, C, TP * C, e->d_out_slab + HALO * C, C, TP * C, B, T,
                     C, 1.0f, e->loss_part, loss, s));                                       // solver.py:166
+    if (flags & SS_STEP_SPLIT_BACKWARD) {         // data parallel: stop once the decoder + head gradients are complete
+        CHK(backward_decoder(e, s));
+        return join_side(e, s);
+    }
     CHK(backward_core(e, s));                                                               // solver.py:170-171
     if (!(flags & SS_STEP_NO_ADAM)) CHK(ss_adam_step(e, grad_scale, (void*)s));             // solver.py:172
     return 0;
@@ -1031,7 +1156,7 @@ int ss_g3_train_step(ss_engine* e, const float* mel, const float* f0, const floa
         drop_graphs(e);
         e->graph_epoch = g_tune_epoch;
     }
-    if (!g_graph) return g3_step_body(e, mel, f0, emb, len_org, scales, len_seg, B, T, grad_scale, flags, loss, s);
+    if (!g_graph || (flags & SS_STEP_SPLIT_BACKWARD)) return g3_step_body(e, mel, f0, emb, len_org, scales, len_seg, B, T, grad_scale, flags, loss, s);
 
     // stage the caller's inputs, then replay (or first capture) the step on engine-owned addresses.  All of it runs on
     // the engine's capture stream, ordered after the caller's stream and before whatever the caller enqueues next.
@@ -1065,6 +1190,20 @@ int ss_g3_train_step(ss_engine* e, const float* mel, const float* f0, const floa
     HIPCHK(hipEventRecord(e->ev_io[1], c));
     HIPCHK(hipStreamWaitEvent(s, e->ev_io[1], 0));
     return 0;
+}
+
+int ss_train_finish(ss_engine* e, float grad_scale, int flags, void* stream) {
+    hipStream_t s = S(stream);
+    if (!e->have_fwd) return fail("ss_train_finish without a preceding ss_*_train_step(SS_STEP_SPLIT_BACKWARD)");
+    CHK(backward_encoder(e, s));
+    if (!(flags & SS_STEP_NO_ADAM)) CHK(ss_adam_step(e, grad_scale, stream));
+    return 0;
+}
+
+long ss_grad_split(const ss_engine* e) {
+    for (const auto& p : e->params)
+        if (p.name.rfind("decoder.", 0) == 0) return p.offset;
+    return e->arena;
 }
 
 int ss_g6_train_step(ss_engine* e, const float* mel, const float* f0_onehot, const int* target_idx, const float* scales,
@@ -1134,6 +1273,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "lstm_mode" && value >= 0 && value <= 4) g_lstm_mode = value;
     else if (k == "overlap" && (value == 0 || value == 1)) g_overlap = value;
     else if (k == "graph" && (value == 0 || value == 1)) g_graph = value;
+    else if (k == "split" && (value == 0 || value == 1)) g_split = value;
     else if (k == "gemm_bk" && (value == 16 || value == 32)) g_gemm_bk = value;
     else if (k == "gemm_want" && value >= 1) g_gemm_want = value;
     else if (k == "gemm_diag" && value >= 0 && value < 64) g_gemm_diag = value;

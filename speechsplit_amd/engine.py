@@ -127,13 +127,38 @@ class Engine:
         _capi.check(self.lib.ss_g3_rhythm(self.h, _ptr(x_org), B, T, _ptr(codes), _stream()))
         return codes
 
-    def g3_train_step(self, mel, f0, emb, len_org, draws, grad_scale=1.0, no_adam=False):
+    def g3_train_step(self, mel, f0, emb, len_org, draws, grad_scale=1.0, no_adam=False, split_backward=False):
+        """solver.py:160-172 fused.  split_backward: return after the decoder + head gradients (arena offsets >=
+        self.grad_split) are complete; train_finish() then runs the encoder backward (data-parallel overlap)."""
         B, T, _ = mel.shape
         mel, f0, emb, len_org = self._f(mel), self._f(f0), self._f(emb), self._i(len_org)
         sc, ls = self._draws(draws)
         assert sc.shape[0] == 4 and ls.shape[0] == 4
+        flags = (1 if no_adam else 0) | (2 if split_backward else 0)
         _capi.check(self.lib.ss_g3_train_step(self.h, _ptr(mel), _ptr(f0), _ptr(emb), _ptr(len_org), _ptr(sc), _ptr(ls),
-                                              B, T, float(grad_scale), 1 if no_adam else 0, _ptr(self.loss), _stream()))
+                                              B, T, float(grad_scale), flags, _ptr(self.loss), _stream()))
+        return self.loss
+
+    def train_finish(self, grad_scale=1.0, no_adam=True):
+        _capi.check(self.lib.ss_train_finish(self.h, float(grad_scale), 1 if no_adam else 0, _stream()))
+
+    @property
+    def grad_split(self):
+        return int(self.lib.ss_grad_split(self.h))
+
+    def dp_train_step(self, mel, f0, emb, len_org, draws, world, group=None):
+        """One data-parallel step on this rank's shard: the all-reduce of the decoder + head gradients (80 % of the
+        bytes, finished first by backward) runs on the process group's stream while the encoder backward executes;
+        the encoder range follows, then every rank applies the same Adam update with the 1/world mean folded in."""
+        import torch.distributed as dist
+        self.g3_train_step(mel, f0, emb, len_org, draws, no_adam=True, split_backward=True)
+        k = self.grad_split
+        h1 = dist.all_reduce(self.grads[k:], op=dist.ReduceOp.SUM, group=group, async_op=True)
+        self.train_finish(no_adam=True)
+        h2 = dist.all_reduce(self.grads[:k], op=dist.ReduceOp.SUM, group=group, async_op=True)
+        h1.wait()
+        h2.wait()
+        self.adam_step(1.0 / world)
         return self.loss
 
     # ------------------------------------------------------------------ Generator_6

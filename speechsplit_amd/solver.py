@@ -117,11 +117,11 @@ class Solver(object):
             x_real_org, emb_org, f0_org, len_org = _dist.shard_batch(batch, self.rank, self.world)
             draws = _dist.shard_draws(draws[0], draws[1], Bg, self.rank, self.world)
         to = dict(device=self.device, non_blocking=True)
-        loss = self.eng.g3_train_step(x_real_org.to(**to), f0_org.to(**to), emb_org.to(**to), len_org.to(**to), draws,
-                                      no_adam=self.world > 1)
         if self.world > 1:
-            scale = _dist.allreduce_mean_(self.eng.grads, self.world)
-            self.eng.adam_step(scale)
+            loss = self.eng.dp_train_step(x_real_org.to(**to), f0_org.to(**to), emb_org.to(**to), len_org.to(**to), draws,
+                                          self.world)
+        else:
+            loss = self.eng.g3_train_step(x_real_org.to(**to), f0_org.to(**to), emb_org.to(**to), len_org.to(**to), draws)
         self.step_count += 1
         return loss
 

@@ -355,3 +355,54 @@ def test_solver_trains_and_checkpoints(E, tmp_path):
     for (n, a), (_, b) in zip(s.G.state_dict().items(), s2.G.state_dict().items()):
         assert torch.equal(a.cpu(), b.cpu()), n
     assert torch.equal(s.eng.adam_v, s2.eng.adam_v)
+
+
+def test_split_backward_equals_fused(E):
+    """SS_STEP_SPLIT_BACKWARD + ss_train_finish (the data-parallel schedule) produces the same gradients as the one-call
+    step, and the decoder range is already final when the first call returns."""
+    B, T = 4, 128
+    hp = W.default_hparams(max_len_pad=T)
+    eng = get_engine(E, 'G3', T, 8)
+    eng.load_weights(W.make_weights('G3', hp, 2))
+    mel, f0, emb, lens = synth_batch(17, B, T, 64)
+    d = stack_draws(draws_for(18, B, 4))
+    eng.g3_train_step(mel, f0, emb, lens, d, no_adam=True)
+    ref = eng.grads.clone()
+    eng.g3_train_step(mel, f0, emb, lens, d, no_adam=True, split_backward=True)
+    k = eng.grad_split
+    names = [n for n, o, s in eng.table if o >= k]
+    assert names[0] == 'decoder.lstm.weight_ih_l0' and names[-1].endswith('linear_layer.bias')
+    assert rel(eng.grads[k:], ref[k:]) < 1e-5
+    assert float(eng.grads[:k].abs().max()) == 0.0            # encoder gradients not produced yet
+    eng.train_finish(no_adam=True)
+    assert rel(eng.grads[:k], ref[:k]) < 1e-5
+
+
+def test_dp_step_on_a_one_rank_rccl_group(E):
+    """The data-parallel schedule end to end (split backward, two async RCCL all-reduces, Adam with the mean folded in)
+    on a world of one: must equal the plain fused step."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))
+    try:
+        B, T = 4, 128
+        hp = W.default_hparams(max_len_pad=T)
+        w = W.make_weights('G3', hp, 6)
+        mel, f0, emb, lens = synth_batch(27, B, T, 64)
+        d = stack_draws(draws_for(28, B, 4))
+        res = []
+        for dp in (False, True):
+            eng = get_engine(E, 'G3', T, 8)
+            eng.load_weights(w)
+            eng.adam_m.zero_()
+            eng.adam_v.zero_()
+            eng.set_adam(1e-4, 0.9, 0.999, 1e-8, 0)
+            loss = eng.dp_train_step(mel, f0, emb, lens, d, 1) if dp else eng.g3_train_step(mel, f0, emb, lens, d)
+            torch.cuda.synchronize()
+            res.append((float(loss), eng.params.clone()))
+        assert res[0][0] == res[1][0]
+        assert rel(res[1][1], res[0][1]) < 1e-6
+    finally:
+        dist.destroy_process_group()

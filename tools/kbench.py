@@ -198,12 +198,15 @@ def bench_step():
     tune('gemm_bk', 16)
     tune('gemm_want', 1024)
     for rnd in range(2):
-        for gr, ov, nw in [(0, 1, 16), (1, 1, 16), (1, 0, 16), (1, 1, 8)]:
-            tune('graph', gr)
+        for sp, ov, gr in [(0, 1, 0), (1, 1, 0), (1, 1, 1), (0, 1, 1)]:
+            tune('split', sp)
             tune('overlap', ov)
-            tune('lstm_nw', nw)
+            tune('graph', gr)
             t, tmin = timeit(lambda: eng.g3_train_step(mel, f0, emb, lens, (sc, ls)), iters=10, warm=3)
-            say(f'train step graph{gr} overlap{ov} nw{nw}: {t / 1e3:.3f} ms  ({B / t * 1e6:.0f} utt/s) min {tmin / 1e3:.3f}, loss {float(eng.loss):.6f}')
+            say(f'train step split{sp} overlap{ov} graph{gr}: {t / 1e3:.3f} ms  ({B / t * 1e6:.0f} utt/s) min {tmin / 1e3:.3f}, loss {float(eng.loss):.6f}')
+    tune('split', 1)
+    tune('overlap', 1)
+    tune('graph', 0)
 
 
 def bench_lstm_modes(B=64, T=128, H=512):
