@@ -15,10 +15,10 @@
 
 namespace ss {
 
-int g_gemm_bk = 16;        // k-tile depth of the vectorised GEMM instances (16 or 32), ss_tune("gemm_bk")
+int g_gemm_bk = 16;        // (unused: BK = 32 measured slower; kept so ss_tune("gemm_bk") stays valid)
 int g_gemm_want = 1024;
-int g_gemm_diag = 0;       // diagnostics only (timing experiments, wrong results): 1 no barrier, 2 no global loads / LDS stores in the loop,
-                          // 4 no LDS fragment reads, 8 s_setprio around the MFMA cluster     // minimum number of tiles before the largest tile is chosen, ss_tune("gemm_want")
+int g_gemm_diag = 0;       // A/B experiments: bit 0 = XCD-aware tile order off, bit 1 = two-tile register prefetch
+                          // (measured slower: 146 VGPRs cost a resident workgroup per CU)     // minimum number of tiles before the largest tile is chosen, ss_tune("gemm_want")
 
 namespace {
 
@@ -46,7 +46,7 @@ __device__ __forceinline__ f32x4 load4(const Operand& op, const float* base, int
     return v;
 }
 
-template <int BM, int BN, int BK, bool TA, bool TB, bool VEC>
+template <int BM, int BN, int BK, bool TA, bool TB, bool VEC, int PF>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDesc d) {
     __shared__ __attribute__((aligned(16))) float As[2][BK][BM + PADL];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + PADL];
@@ -57,9 +57,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDesc d) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int batch = blockIdx.z / d.ksplit;
-    const int ks = blockIdx.z - batch * d.ksplit;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so the linear block id
+    // is remapped to give every XCD a contiguous run of tiles (consecutive n-tiles of the same m-tiles share operand panels)
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int total = gx * gy * gridDim.z;
+        if (!(d.diag & 1) && (total & 7) == 0) {
+            const int lin = bx + gx * (by + gy * bz);
+            const int rem = (lin & 7) * (total >> 3) + (lin >> 3);
+            bx = rem % gx;
+            by = (rem / gx) % gy;
+            bz = rem / (gx * gy);
+        }
+    }
+    const int batch = bz / d.ksplit;
+    const int ks = bz - batch * d.ksplit;
+    const int m0 = by * BM, n0 = bx * BN;
 
     const int ktiles = (d.K + BK - 1) / BK;   // split-K boundaries are multiples of BK
     const int tiles_per_split = (ktiles + d.ksplit - 1) / d.ksplit;
@@ -71,7 +85,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDesc d) {
     const float* Ab = d.A.p + (long)batch * d.A.bstride;
     const float* Bb = d.B.p + (long)batch * d.B.bstride;
 
-    f32x4 ra[NA], rb[NB];
     // Vectorised instances walk K with per-slot pointers set up once (no divisions in the loop): a K-contiguous operand
     // advances `within` inside its K segment (conv taps) and hops by segstride at a segment end; a reduction-major
     // operand advances by BK rows.  The scalar instances (unaligned / odd strides) keep the generic addressing.
@@ -147,7 +160,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDesc d) {
         }
         return v;
     };
-    auto gload = [&](int k0) {
+    auto gload = [&](f32x4(&ra)[NA], f32x4(&rb)[NB], int k0) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int f = tid + i * 256;
@@ -163,7 +176,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDesc d) {
             else rb[i] = load4<false>(d.B, Bb, k0 + f / (BN / 4), n0 + (f % (BN / 4)) * 4, kend, d.N);
         }
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](f32x4(&ra)[NA], f32x4(&rb)[NB], int buf) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int f = tid + i * 256;
@@ -196,38 +209,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDesc d) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    if (nk > 0) {
-        gload(kbeg);
-        sstore(0);
-    }
-    __syncthreads();
     const int kh = lane >> 5, l31 = lane & 31;
-    const int diag = d.diag;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = (diag & 2) ? 0 : (kt & 1);
-        if (kt + 1 < nk && !(diag & 2) && !(diag & 32)) gload(kbeg + (kt + 1) * BK);
+    auto compute = [&](int buf) {
         // fragments of k-step kk+2 are requested before the MFMAs of k-step kk are issued
         float a[2][MI], b[2][NI];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) a[0][mi] = As[buf][kh][wm * (BM / 2) + mi * 32 + l31];
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) b[0][ni] = Bs[buf][kh][wn * (BN / 2) + ni * 32 + l31];
-        if (diag & 8) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const int cur = (kk >> 1) & 1;
             if (kk + 2 < BK) {
-                if (diag & 4) {
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) a[cur ^ 1][mi] = a[cur][mi] + 1.0f;
+                for (int mi = 0; mi < MI; ++mi) a[cur ^ 1][mi] = As[buf][kk + 2 + kh][wm * (BM / 2) + mi * 32 + l31];
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) b[cur ^ 1][ni] = b[cur][ni] + 1.0f;
-                } else {
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) a[cur ^ 1][mi] = As[buf][kk + 2 + kh][wm * (BM / 2) + mi * 32 + l31];
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) b[cur ^ 1][ni] = Bs[buf][kk + 2 + kh][wn * (BN / 2) + ni * 32 + l31];
-                }
+                for (int ni = 0; ni < NI; ++ni) b[cur ^ 1][ni] = Bs[buf][kk + 2 + kh][wn * (BN / 2) + ni * 32 + l31];
             }
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
@@ -235,18 +232,42 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDesc d) {
                 for (int ni = 0; ni < NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][mi], b[cur][ni], acc[mi][ni], 0, 0, 0);
         }
-        if (diag & 8) __builtin_amdgcn_s_setprio(0);
-        if (kt + 1 < nk && !(diag & 2)) {
-            if (diag & 16) {          // keep the loaded registers alive without writing LDS
-#pragma unroll
-                for (int i = 0; i < NA; ++i) asm volatile("" ::"v"(ra[i]));
-#pragma unroll
-                for (int i = 0; i < NB; ++i) asm volatile("" ::"v"(rb[i]));
-            } else {
-                sstore(buf ^ 1);
-            }
+    };
+
+    f32x4 ra0[NA], rb0[NB];
+    if (PF == 1) {
+        // tile kt+1 is fetched while tile kt is multiplied
+        if (nk > 0) {
+            gload(ra0, rb0, kbeg);
+            sstore(ra0, rb0, 0);
         }
-        if (!(diag & 1)) __syncthreads();
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) gload(ra0, rb0, kbeg + (kt + 1) * BK);
+            compute(buf);
+            if (kt + 1 < nk) sstore(ra0, rb0, buf ^ 1);
+            __syncthreads();
+        }
+    } else {
+        // two register sets: tile kt+2 is requested while tile kt is multiplied and tile kt+1 (requested one tile
+        // earlier) is written to LDS, so a global load has two full tiles of MFMA time to land
+        f32x4 ra1[NA], rb1[NB];
+        if (nk > 0) gload(ra0, rb0, kbeg);
+        if (nk > 1) gload(ra1, rb1, kbeg + BK);
+        if (nk > 0) sstore(ra0, rb0, 0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {
+            if (kt + 2 < nk) gload(ra0, rb0, kbeg + (kt + 2) * BK);
+            compute(0);
+            if (kt + 1 < nk) sstore(ra1, rb1, 1);
+            __syncthreads();
+            if (kt + 1 >= nk) break;
+            if (kt + 3 < nk) gload(ra1, rb1, kbeg + (kt + 3) * BK);
+            compute(1);
+            if (kt + 2 < nk) sstore(ra0, rb0, 0);
+            __syncthreads();
+        }
     }
 
     float* Cb = d.C + (long)batch * d.cstride;
@@ -279,9 +300,9 @@ bool vec_ok(const Operand& o) {
 template <int BM, int BN, bool TA, bool TB>
 hipError_t launch_cfg(const GemmDesc& d, bool vec, hipStream_t s) {
     dim3 grid(cdiv(d.N, BN), cdiv(d.M, BM), d.batch * d.ksplit);
-    if (!vec) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 16, TA, TB, false>), grid, dim3(256), 0, s, d);
-    else if (g_gemm_bk == 32) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 32, TA, TB, true>), grid, dim3(256), 0, s, d);
-    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 16, TA, TB, true>), grid, dim3(256), 0, s, d);
+    if (!vec) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 16, TA, TB, false, 1>), grid, dim3(256), 0, s, d);
+    else if (g_gemm_diag & 2) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 16, TA, TB, true, 2>), grid, dim3(256), 0, s, d);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, 16, TA, TB, true, 1>), grid, dim3(256), 0, s, d);
     return hipGetLastError();
 }
 

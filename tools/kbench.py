@@ -171,17 +171,22 @@ def bench_gemm():
 
 def bench_gemm_diag():
     dev = 'cuda'
-    for name, M, N, K, ta, tb, ks in [('proj NT 8192x2048x1024', 8192, 2048, 1024, False, False, 1),
-                                      ('conv NT 8192x512x2560', 8192, 512, 2560, False, False, 1),
-                                      ('dW_ih TN 2048x1024x8448', 2048, 1024, 8448, True, True, 4)]:
+    shapes = [('proj   NT 8192x2048x1024', 8192, 2048, 1024, False, False, 1), ('conv   NT 8192x512x2560', 8192, 512, 2560, False, False, 1),
+              ('dX     NN 8448x1024x2048', 8448, 1024, 2048, False, True, 1), ('dW_ih  TN 2048x1024x8448', 2048, 1024, 8448, True, True, 4),
+              ('dW_hh  TN 2048x512x8447', 2048, 512, 8447, True, True, 8)]
+    for name, M, N, K, ta, tb, ks in shapes:
         A = torch.randn((K, M) if ta else (M, K), device=dev)
         Bm = torch.randn((K, N) if tb else (N, K), device=dev)
         c = torch.zeros(M, N, device=dev)
-        for diag, what in [(0, 'baseline'), (16, 'gload, no sstore'), (32, 'sstore, no gload'), (2, 'no gload/sstore'),
-                           (6, 'no gload, no LDS reads'), (0, 'baseline again')]:
-            tune('gemm_diag', diag)
-            t, tmin = timeit(lambda: E.gemm(A, Bm, None, ta, tb, ks, out=c), iters=7)
-            say(f'gemm {name} diag {diag:2d} ({what}): {t:8.1f} us  {2.0 * M * N * K / t / 1e6:6.1f} TF')
+        ref = ((A.t() if ta else A).double() @ (Bm if tb else Bm.t()).double())
+        for rnd in range(2):
+            for diag, what in [(1, 'linear order, prefetch 1'), (3, 'linear order, prefetch 2'), (0, 'XCD order, prefetch 1'), (2, 'XCD order, prefetch 2')]:
+                tune('gemm_diag', diag)
+                c.zero_()
+                E.gemm(A, Bm, None, ta, tb, ks, out=c)
+                err = float((c.double() - ref).abs().max() / ref.abs().max())
+                t, tmin = timeit(lambda: E.gemm(A, Bm, None, ta, tb, ks, out=c), iters=7)
+                say(f'gemm {name} [{what:26s}]: {t:8.1f} us  {2.0 * M * N * K / t / 1e6:6.1f} TF  err {err:.1e}')
     tune('gemm_diag', 0)
 
 
@@ -198,15 +203,13 @@ def bench_step():
     tune('gemm_bk', 16)
     tune('gemm_want', 1024)
     for rnd in range(2):
-        for sp, ov, gr in [(0, 1, 0), (1, 1, 0), (1, 1, 1), (0, 1, 1)]:
-            tune('split', sp)
-            tune('overlap', ov)
-            tune('graph', gr)
+        for gd, want in [(1, 1024), (0, 1024), (0, 512), (0, 256)]:
+            tune('gemm_diag', gd)
+            tune('gemm_want', want)
             t, tmin = timeit(lambda: eng.g3_train_step(mel, f0, emb, lens, (sc, ls)), iters=10, warm=3)
-            say(f'train step split{sp} overlap{ov} graph{gr}: {t / 1e3:.3f} ms  ({B / t * 1e6:.0f} utt/s) min {tmin / 1e3:.3f}, loss {float(eng.loss):.6f}')
-    tune('split', 1)
-    tune('overlap', 1)
-    tune('graph', 0)
+            say(f'train step gemm_diag{gd} want{want}: {t / 1e3:.3f} ms  ({B / t * 1e6:.0f} utt/s) min {tmin / 1e3:.3f}, loss {float(eng.loss):.6f}')
+    tune('gemm_diag', 0)
+    tune('gemm_want', 1024)
 
 
 def bench_lstm_modes(B=64, T=128, H=512):
