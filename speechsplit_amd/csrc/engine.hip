@@ -20,6 +20,8 @@ using namespace ss;
 namespace ss {
 extern int g_lstm_nw, g_lstm_g, g_lstm_mode, g_gemm_bk, g_gemm_want, g_gemm_diag;
 int g_overlap = 1;     // 1: weight-gradient GEMMs on the side stream
+int g_side_prio = 0;   // 1: create the side stream with the lowest priority (read at ss_bind).  Measured: 2.3x SLOWER
+                       //    (35 ms vs 14.8 ms per step): the low-priority queue starves behind 768 tiny step launches.
 int g_split = 0;       // 1: decoder recurrences run as two batch-half chains on two streams (GEMMs of one half fill the
                        //    machine while the other half sits in its latency-bound time loop)
 int g_graph = 0;       // 1: the fused training step is captured into a hipGraph and replayed (measured: no gain while the
@@ -1010,7 +1012,11 @@ int ss_bind(ss_engine* e, float* params, float* grads, float* m, float* v, void*
     HIPCHK(hipMemsetAsync(e->ws, 0, ws_bytes, S(stream)));
     e->carve(e->maxB, e->maxT, true);
     if (!e->side && e->kind != SS_INTERP_ONLY) {
-        HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+        {   // filler work (weight-gradient GEMMs) yields to the latency-critical recurrence on the caller's stream
+            int least = 0, greatest = 0;
+            HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIPCHK(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, g_side_prio ? least : 0));
+        }
         for (auto& ev : e->ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         HIPCHK(hipStreamCreateWithFlags(&e->side2, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&e->cap, hipStreamNonBlocking));
@@ -1274,6 +1280,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "overlap" && (value == 0 || value == 1)) g_overlap = value;
     else if (k == "graph" && (value == 0 || value == 1)) g_graph = value;
     else if (k == "split" && (value == 0 || value == 1)) g_split = value;
+    else if (k == "side_prio" && (value == 0 || value == 1)) g_side_prio = value;
     else if (k == "gemm_bk" && (value == 16 || value == 32)) g_gemm_bk = value;
     else if (k == "gemm_want" && value >= 1) g_gemm_want = value;
     else if (k == "gemm_diag" && value >= 0 && value < 4) g_gemm_diag = value;

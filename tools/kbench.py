@@ -195,21 +195,20 @@ def bench_step():
     from oracle.gen_fixtures import synth_batch
     B, T = 64, 128
     hp = W.default_hparams(max_len_pad=T)
-    eng = E.Engine('G3', hp, B, T)
-    eng.load_weights(W.make_weights('G3', hp, 0))
     mel, f0, emb, lens = [t.cuda() for t in synth_batch(1, B, T, 64)]
     sc, ls = E.draw_interp(B, 4, hp)
     sc, ls = sc.cuda(), ls.cuda()
-    tune('gemm_bk', 16)
-    tune('gemm_want', 1024)
-    for rnd in range(2):
-        for gd, want in [(1, 1024), (0, 1024), (0, 512), (0, 256)]:
-            tune('gemm_diag', gd)
-            tune('gemm_want', want)
+    engs = {}
+    for prio in (0, 1):
+        tune('side_prio', prio)
+        engs[prio] = E.Engine('G3', hp, B, T)
+        engs[prio].load_weights(W.make_weights('G3', hp, 0))
+    for rnd in range(3):
+        for prio in (0, 1):
+            eng = engs[prio]
             t, tmin = timeit(lambda: eng.g3_train_step(mel, f0, emb, lens, (sc, ls)), iters=10, warm=3)
-            say(f'train step gemm_diag{gd} want{want}: {t / 1e3:.3f} ms  ({B / t * 1e6:.0f} utt/s) min {tmin / 1e3:.3f}, loss {float(eng.loss):.6f}')
-    tune('gemm_diag', 0)
-    tune('gemm_want', 1024)
+            say(f'train step side_prio{prio}: {t / 1e3:.3f} ms  ({B / t * 1e6:.0f} utt/s) min {tmin / 1e3:.3f}, loss {float(eng.loss):.6f}')
+    tune('side_prio', 1)
 
 
 def bench_lstm_modes(B=64, T=128, H=512):
