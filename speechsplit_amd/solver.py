@@ -2,8 +2,8 @@
 
 Same constructor (``Solver(vcc_loader, config, hparams)``), same ``config`` attributes, same ``train()`` loop
 structure, log line and checkpoint files; the six statements of the step body (solver.py:157-172) are ONE C-ABI
-call into the HIP engine (``ss_g3_train_step``).  Out of scope here, as in SURVEY.md section 2: tensorboard, the
-matplotlib ablation plots and the demo.pkl validation block (solver.py:206-269).
+call into the HIP engine (``ss_g3_train_step``).  The demo.pkl validation block (solver.py:206-227) and
+the ablation forwards (solver.py:245-251) are ``validate``; tensorboard and the matplotlib plots are out of scope.
 
 Data parallelism is new (the reference is single-device): under ``torchrun`` each rank takes its shard of every
 batch and of the resampling draws, gradients are summed with one RCCL all-reduce over the flat arena, and every
@@ -19,6 +19,8 @@ from . import dist as _dist
 from .engine import draw_interp
 from .model import Generator_3 as Generator
 from .model import InterpLnr
+from .staging import DevicePrefetcher
+from .utils import pad_seq_to_2, quantize_f0_numpy
 
 
 class Solver(object):
@@ -125,9 +127,39 @@ class Solver(object):
         self.step_count += 1
         return loss
 
+    # ---- validation on demo.pkl-style data (solver.py:206-227) and the ablation forwards of solver.py:245-251 (no plots)
+    def validate(self, validation_pt, ablations=False):
+        """validation_pt: list of [speaker, emb f32[1,82], (mel f32[L,80], f0 f32[L], L, uid)] (assets/demo.pkl layout).
+        Returns (mean sum-reduced MSE, per-utterance dict of outputs).  G stays in eval mode afterwards, as in the reference."""
+        import numpy as np
+        self.G = self.G.eval()
+        losses, outs = [], {}
+        with torch.no_grad():
+            for val_sub in validation_pt:
+                emb = torch.from_numpy(np.asarray(val_sub[1], np.float32)).to(self.device)
+                mel, f0, L = val_sub[2][0], val_sub[2][1], val_sub[2][2]
+                x_real_pad, _ = pad_seq_to_2(mel[np.newaxis, :, :], 192)                                   # solver.py:213
+                f0_pad = np.pad(f0, (0, 192 - L), 'constant', constant_values=(0, 0))                      # :215
+                onehot = torch.from_numpy(quantize_f0_numpy(f0_pad)[0][np.newaxis]).to(self.device)        # :216-218
+                x_real = torch.from_numpy(x_real_pad.astype(np.float32)).to(self.device)
+                x_f0 = torch.cat((x_real, onehot), dim=-1)
+                out = self.G(x_f0, x_real, emb)                                                            # :221
+                losses.append(float(torch.nn.functional.mse_loss(x_real, out, reduction='sum')))           # :222
+                rec = {'out': out}
+                if ablations:                                                                              # :245-251
+                    rec['woF'] = self.G(torch.cat((x_real, torch.zeros_like(onehot)), -1), x_real, emb)
+                    rec['woR'] = self.G(x_f0, torch.zeros_like(x_real), emb)
+                    rec['woC'] = self.G(torch.cat((torch.zeros_like(x_real), onehot), -1), x_real, emb)
+                outs[val_sub[0]] = rec
+        return float(np.mean(losses)), outs
+
     def train(self):
         data_loader = self.vcc_loader
-        data_iter = iter(data_loader)
+        data_iter = DevicePrefetcher(data_loader, self.device)       # next batch staged H2D while this step runs
+        validation_pt = getattr(self, 'validation_pt', None)
+        if validation_pt is None and os.path.exists('assets/demo.pkl'):   # solver.py:16
+            import pickle
+            validation_pt = pickle.load(open('assets/demo.pkl', 'rb'))
         start_iters = 0
         if self.resume_iters:
             print('Resuming ...')
@@ -140,11 +172,7 @@ class Solver(object):
         keys = ['G/loss_id']
         start_time = time.time()
         for i in range(start_iters, self.num_iters):
-            try:
-                batch = next(data_iter)
-            except StopIteration:
-                data_iter = iter(data_loader)
-                batch = next(data_iter)
+            batch = next(data_iter)
             self.G = self.G.train()
             loss_dev = self.train_on_batch(batch)
             if (i + 1) % self.log_step == 0:
@@ -163,3 +191,6 @@ class Solver(object):
             if (i + 1) % self.model_save_step == 0 and self.rank == 0:
                 self.save_model(i + 1)
                 print('Saved model checkpoints into {}...'.format(self.model_save_dir))
+            if (i + 1) % self.sample_step == 0 and validation_pt is not None and self.rank == 0:
+                val_loss, _ = self.validate(validation_pt)
+                print('Validation loss: {}'.format(val_loss))

@@ -406,3 +406,34 @@ def test_dp_step_on_a_one_rank_rccl_group(E):
         assert rel(res[1][1], res[0][1]) < 1e-6
     finally:
         dist.destroy_process_group()
+
+
+def test_solver_validation_path_and_prefetcher(E, tmp_path):
+    """Solver.validate reproduces solver.py:206-227 on demo.pkl-shaped entries (built from the committed config-1 vectors):
+    the sum-reduced MSE equals the one computed from the reference's own outputs; the ablation forwards run."""
+    from types import SimpleNamespace
+    from speechsplit_amd import data_loader, hparams as HP, solver, staging
+    z = np.load(os.path.join(GOLD, 'demo_config1.npz'))
+    hp = HP.default_hparams(batch_size=2)
+    cfg = SimpleNamespace(num_iters=1, g_lr=1e-4, beta1=0.9, beta2=0.999, resume_iters=None, use_tensorboard=False, device_id=0,
+                          log_dir=str(tmp_path), sample_dir=str(tmp_path), model_save_dir=str(tmp_path), log_step=1,
+                          sample_step=1, model_save_step=100)
+    loader = data_loader.get_loader(hp, dataset=data_loader.SyntheticUtterances(8, seed=3))
+    s = solver.Solver(loader, cfg, hp)
+    s.G.load_state_dict({**{k: torch.from_numpy(v) for k, v in W.make_weights('G3', hp, int(z['seed_g3'])).items()},
+                         'encoder_1.len_org': torch.tensor(192)})
+    val = []
+    for n in range(2):
+        L = int(z[f'u{n}_len'])
+        val.append([f'u{n}', z[f'u{n}_emb'], (z[f'u{n}_mel_pad'][0, :L], z[f'u{n}_f0_pad'][:L], L, 'x')])
+    loss, outs = s.validate(val, ablations=True)
+    ref = np.mean([float(((z[f'u{n}_mel_pad'] - z[f'u{n}_out3']) ** 2).sum()) for n in range(2)])
+    assert abs(loss - ref) <= 1e-4 * ref
+    for n in range(2):
+        assert rel(outs[f'u{n}']['out'], z[f'u{n}_out3']) < TOL
+        assert set(outs[f'u{n}']) == {'out', 'woF', 'woR', 'woC'}
+    pf = staging.DevicePrefetcher(loader, 'cuda:0')
+    mel, emb, f0, ln = next(pf)
+    assert mel.is_cuda and mel.shape == (2, 192, 80) and ln.dtype == torch.int64
+    s.validation_pt = val
+    s.train()                       # one iteration + validation print through the prefetcher
