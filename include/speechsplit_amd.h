@@ -107,6 +107,9 @@ int ss_interp_forward(ss_engine* e, const float* x_dev, const int* len_seq_dev, 
 /* adjoint of the last ss_interp_forward: dy [B,P,C] -> dx [B,T,C] */
 int ss_interp_backward(ss_engine* e, const float* dy_dev, int B, int T, int C, float* dx_dev, void* stream);
 
+/* Synchronise `stream` and report asynchronous failures (a persistent recurrence kernel whose bounded wait expired). */
+int ss_check(ss_engine* e, void* stream);
+
 /* ---- test / profiling hooks ---- */
 /* C[M,N] = A . B^T style fp32 MFMA GEMM used by every contraction on the path (flags: 1 = A stored [K,M], 2 = B stored [K,N]) */
 int ss_op_gemm(const float* a_dev, long lda, const float* b_dev, long ldb, float* c_dev, long ldc, const float* bias_dev,
@@ -121,7 +124,7 @@ int ss_op_lstm_fwd(float* gates_dev, const float* whh_f_dev, const float* whh_b_
 int ss_op_lstm_bwd(float* gates_dev, const float* whh_f_dev, const float* whh_b_dev, const float* d_out_dev,
                    const float* csave_dev, float* scratch_dev, long scratch_floats, int B, int T, int H, void* stream);
 /* tuning knobs (process-global): "lstm_nw" 4|8|16, "lstm_g" 0..16, "gemm_bk" 16|32, "gemm_want" >= 1,
- * "overlap" 0|1, "graph" 0|1; "lstm_mode" / "gemm_diag" are timing experiments that produce wrong results */
+ * "overlap" 0|1, "graph" 0|1, "persist" 0|1, "split" 0|1; "lstm_mode" / "gemm_diag" are timing experiments that produce wrong results */
 int ss_tune(const char* key, int value);
 /* named internal slab of the last call ("enc1.xf2", "dec.out2", ...); layout [B, T+4, C], frame t at row t+2 */
 int ss_debug_buffer(ss_engine* e, const char* name, float** ptr_dev, long* rows, long* cols);

@@ -47,6 +47,7 @@ SYMBOLS = {
     'ss_zero_grads': (_i, [_vp, _vp]),
     'ss_interp_forward': (_i, [_vp, _fp, _ip, _fp, _ip, _i, _i, _i, _fp, _ip, _fp, _ip, _vp]),
     'ss_interp_backward': (_i, [_vp, _fp, _i, _i, _i, _fp, _vp]),
+    'ss_check': (_i, [_vp, _vp]),
     'ss_op_gemm': (_i, [_fp, _l, _fp, _l, _fp, _l, _fp, _i, _i, _i, _i, _i, _vp]),
     'ss_op_lstm_fwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _l, _i, _i, _i, _vp]),
     'ss_op_lstm_bwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _l, _i, _i, _i, _vp]),

@@ -22,6 +22,7 @@ extern int g_lstm_nw, g_lstm_g, g_lstm_mode, g_gemm_bk, g_gemm_want, g_gemm_diag
 int g_overlap = 1;     // 1: weight-gradient GEMMs on the side stream
 int g_side_prio = 0;   // 1: create the side stream with the lowest priority (read at ss_bind).  Measured: 2.3x SLOWER
                        //    (35 ms vs 14.8 ms per step): the low-priority queue starves behind 768 tiny step launches.
+int g_persist = 1;     // 1: decoder recurrences run as ONE persistent launch per layer (lstm_seq.hip) when the batch fits
 int g_split = 0;       // 1: decoder recurrences run as two batch-half chains on two streams (GEMMs of one half fill the
                        //    machine while the other half sits in its latency-bound time loop)
 int g_graph = 0;       // 1: the fused training step is captured into a hipGraph and replayed (measured: no gain while the
@@ -75,6 +76,7 @@ struct LstmBlk {
     float* hf[2] = {nullptr, nullptr};     // per batch-half chain: ping-pong fragment-major h(t),  2 x [2][ceil16(B)][H]
     float* gf[2] = {nullptr, nullptr};     // per chain: ping-pong fragment-major da(t), 2 x [2][ceil16(B)][4H]
     float* dc[2] = {nullptr, nullptr};     // per chain: [2][B][H]
+    unsigned* sync = nullptr;              // persistent kernels: group counters + abort word
     float* dmid[2] = {nullptr, nullptr};   // gradient slabs of inner layer outputs [B,TP,2H]
     bool big() const { return H > 32; }
     int in_of(int l) const { return l == 0 ? In : 2 * H; }
@@ -286,6 +288,7 @@ long ss_engine::carve(int B, int T, bool assign) {
                 lb.gf[c] = (float*)take(2L * 2 * B16 * 4 * lb.H * 4);
                 lb.dc[c] = (float*)take(2L * B * lb.H * 4);
             }
+            lb.sync = (unsigned*)take(128 * 4);
         }
         if (lb.L > 1) {
             lb.dmid[0] = slab((name + ".dmid0").c_str(), 2L * lb.H);
@@ -508,7 +511,9 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
     const int B = e->curB, T = e->curT, H = lb.H;
     const long TP = T + 2 * HALO;
     Chain ch[2];
-    const int nch = make_chains(e, B, s, ch);
+    const bool persist = g_persist && lstm_seq_supported(B, H);
+    const int nch = persist ? 1 : make_chains(e, B, s, ch);
+    if (persist) ch[0] = {0, B, s};
     for (int l = 0; l < lb.L; ++l) {
         for (int dir = 0; dir < 2; ++dir) {
             const LstmDir& pd = lb.pd[l * 2 + dir];
@@ -540,6 +545,10 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
             }
             const long half = 2L * (((ch[c].nb + 15) / 16) * 16) * H;
             HIPCHK(hipMemsetAsync(lb.hf[c], 0, 2 * half * 4, ch[c].st));
+        }
+        if (persist) {
+            HIPCHK(lstm_seq_fwd(lb.gates[l], lb.wfrag[l], lb.hf[0], lb.out[l], lb.csave[l], lb.sync, B, T, H, s));
+            continue;
         }
         for (int st = 0; st < T; ++st)
             for (int c = 0; c < nch; ++c) {
@@ -655,7 +664,8 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
     const float* dcur = d_top;
     Chain ch[2];
     ch[0] = {0, B, s};
-    const int nch = lb.big() ? make_chains(e, B, s, ch) : 1;
+    const bool persist = lb.big() && g_persist && lstm_seq_supported(B, H);
+    const int nch = (lb.big() && !persist) ? make_chains(e, B, s, ch) : 1;
     if (lb.big()) {
         for (int l = 0; l < lb.L; ++l)
             HIPCHK(lstm_pack_w(e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.wfrag[l], H, 1, s));
@@ -671,7 +681,8 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
                 const long half = 2L * (((ch[c].nb + 15) / 16) * 16) * 4 * H;
                 HIPCHK(hipMemsetAsync(lb.gf[c], 0, 2 * half * 4, ch[c].st));
             }
-            for (int st = 0; st < T; ++st)
+            if (persist) HIPCHK(lstm_seq_bwd(dG, lb.wfrag[l], lb.gf[0], dcur, lb.csave[l], lb.sync, B, T, H, s));
+            for (int st = 0; st < T && !persist; ++st)
                 for (int c = 0; c < nch; ++c) {
                     const long r0 = (long)ch[c].b0 * TP;
                     const long half = 2L * (((ch[c].nb + 15) / 16) * 16) * 4 * H;
@@ -1280,6 +1291,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "overlap" && (value == 0 || value == 1)) g_overlap = value;
     else if (k == "graph" && (value == 0 || value == 1)) g_graph = value;
     else if (k == "split" && (value == 0 || value == 1)) g_split = value;
+    else if (k == "persist" && (value == 0 || value == 1)) g_persist = value;
     else if (k == "side_prio" && (value == 0 || value == 1)) g_side_prio = value;
     else if (k == "gemm_bk" && (value == 16 || value == 32)) g_gemm_bk = value;
     else if (k == "gemm_want" && value >= 1) g_gemm_want = value;
@@ -1320,6 +1332,18 @@ int ss_op_lstm_bwd(float* gates, const float* whh_f, const float* whh_b, const f
             HIPCHK(lstm_step_bwd(gates, scratch, gf + (st & 1) * half, gf + ((st & 1) ^ 1) * half, d_out, csave, dc, B, T, H, st, s));
     } else {
         HIPCHK(lstm_small_bwd(gates, whh_f, whh_b, d_out, csave, B, T, H, s));
+    }
+    return 0;
+}
+
+int ss_check(ss_engine* e, void* stream) {
+    HIPCHK(hipStreamSynchronize(S(stream)));
+    HIPCHK(hipGetLastError());
+    for (LstmBlk* lb : {&e->ld, &e->l1, &e->l2, &e->lt}) {
+        if (!lb->sync) continue;
+        unsigned flag = 0;
+        HIPCHK(hipMemcpy(&flag, lb->sync + 64, 4, hipMemcpyDeviceToHost));
+        if (flag) return fail("persistent LSTM kernel gave up waiting for its group (bounded spin expired): results are invalid");
     }
     return 0;
 }

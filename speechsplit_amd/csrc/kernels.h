@@ -98,4 +98,12 @@ hipError_t lstm_step_fwd(float* gates, const float* wfrag, const float* hf_cur, 
 hipError_t lstm_step_bwd(float* gates, const float* wfragT, const float* gf_cur, float* gf_next, const float* d_out,
                          const float* csave, float* dc, int B, int T, int H, int step, hipStream_t s);
 
+// ---------------------------------------------------------------- lstm_seq.hip  (persistent: one launch per layer)
+// Same operands as the step kernels; `sync` = 128 unsigned words (group arrival counters + abort word at [64]).
+bool lstm_seq_supported(int B, int H);
+hipError_t lstm_seq_fwd(float* gates, const float* wfrag, float* hf, float* out, float* csave, unsigned* sync, int B, int T,
+                        int H, hipStream_t s);
+hipError_t lstm_seq_bwd(float* gates, const float* wfragT, float* gf, const float* d_out, const float* csave, unsigned* sync,
+                        int B, int T, int H, hipStream_t s);
+
 }  // namespace ss

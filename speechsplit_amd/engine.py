@@ -187,6 +187,10 @@ class Engine:
     def adam_step(self, grad_scale=1.0):
         _capi.check(self.lib.ss_adam_step(self.h, float(grad_scale), _stream()))
 
+    def check(self):
+        """Synchronise and raise if a kernel reported an asynchronous failure."""
+        _capi.check(self.lib.ss_check(self.h, _stream()))
+
     def zero_grads(self):
         _capi.check(self.lib.ss_zero_grads(self.h, _stream()))
 

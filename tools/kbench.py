@@ -198,17 +198,17 @@ def bench_step():
     mel, f0, emb, lens = [t.cuda() for t in synth_batch(1, B, T, 64)]
     sc, ls = E.draw_interp(B, 4, hp)
     sc, ls = sc.cuda(), ls.cuda()
-    engs = {}
-    for prio in (0, 1):
-        tune('side_prio', prio)
-        engs[prio] = E.Engine('G3', hp, B, T)
-        engs[prio].load_weights(W.make_weights('G3', hp, 0))
-    for rnd in range(3):
-        for prio in (0, 1):
-            eng = engs[prio]
+    eng = E.Engine('G3', hp, B, T)
+    eng.load_weights(W.make_weights('G3', hp, 0))
+    for rnd in range(2):
+        for ps, ov in [(0, 1), (1, 1), (1, 0)]:
+            tune('persist', ps)
+            tune('overlap', ov)
             t, tmin = timeit(lambda: eng.g3_train_step(mel, f0, emb, lens, (sc, ls)), iters=10, warm=3)
-            say(f'train step side_prio{prio}: {t / 1e3:.3f} ms  ({B / t * 1e6:.0f} utt/s) min {tmin / 1e3:.3f}, loss {float(eng.loss):.6f}')
-    tune('side_prio', 1)
+            eng.check()
+            say(f'train step persist{ps} overlap{ov}: {t / 1e3:.3f} ms  ({B / t * 1e6:.0f} utt/s) min {tmin / 1e3:.3f}, loss {float(eng.loss):.6f}')
+    tune('persist', 1)
+    tune('overlap', 1)
 
 
 def bench_lstm_modes(B=64, T=128, H=512):
