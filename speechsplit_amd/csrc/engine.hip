@@ -1310,6 +1310,10 @@ int ss_op_lstm_fwd(float* gates, const float* whh_f, const float* whh_b, float* 
         float* hf = scratch + wn;
         HIPCHK(lstm_pack_w(whh_f, whh_b, scratch, H, 0, s));
         HIPCHK(hipMemsetAsync(hf, 0, 2 * half * 4, s));
+        if (g_persist && lstm_seq_supported(B, H) && scratch_floats >= wn + 2 * half + 128) {
+            HIPCHK(lstm_seq_fwd(gates, scratch, hf, out, csave, (unsigned*)(hf + 2 * half), B, T, H, s));
+            return 0;
+        }
         for (int st = 0; st < T; ++st)
             HIPCHK(lstm_step_fwd(gates, scratch, hf + (st & 1) * half, hf + ((st & 1) ^ 1) * half, out, csave, B, T, H, st, s));
     } else {
@@ -1328,6 +1332,10 @@ int ss_op_lstm_bwd(float* gates, const float* whh_f, const float* whh_b, const f
         float* dc = gf + 2 * half;
         HIPCHK(lstm_pack_w(whh_f, whh_b, scratch, H, 1, s));
         HIPCHK(hipMemsetAsync(gf, 0, 2 * half * 4, s));
+        if (g_persist && lstm_seq_supported(B, H)) {
+            HIPCHK(lstm_seq_bwd(gates, scratch, gf, d_out, csave, (unsigned*)dc, B, T, H, s));
+            return 0;
+        }
         for (int st = 0; st < T; ++st)
             HIPCHK(lstm_step_bwd(gates, scratch, gf + (st & 1) * half, gf + ((st & 1) ^ 1) * half, d_out, csave, dc, B, T, H, st, s));
     } else {

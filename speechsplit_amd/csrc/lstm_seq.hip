@@ -60,6 +60,53 @@ __device__ __forceinline__ void load4x4_sc1(const float* p, f32x4& a0, f32x4& a1
         : "memory");
 }
 
+// eight 16-byte sc1 loads (two bases, 1 KiB apart), one wait
+__device__ __forceinline__ void load8x4_sc1(const float* p, f32x4 (&a)[8]) {
+    const float* p2 = p + 1024;
+    asm volatile(
+        "global_load_dwordx4 %0, %8, off sc1\n\t"
+        "global_load_dwordx4 %1, %8, off offset:1024 sc1\n\t"
+        "global_load_dwordx4 %2, %8, off offset:2048 sc1\n\t"
+        "global_load_dwordx4 %3, %8, off offset:3072 sc1\n\t"
+        "global_load_dwordx4 %4, %9, off sc1\n\t"
+        "global_load_dwordx4 %5, %9, off offset:1024 sc1\n\t"
+        "global_load_dwordx4 %6, %9, off offset:2048 sc1\n\t"
+        "global_load_dwordx4 %7, %9, off offset:3072 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7])
+        : "v"(p), "v"(p2)
+        : "memory");
+}
+
+// sixteen 16-byte sc1 loads (four bases), one wait
+__device__ __forceinline__ void load16x4_sc1(const float* p, f32x4 (&a)[16]) {
+    const float* p1 = p + 1024;
+    const float* p2 = p + 2048;
+    const float* p3 = p + 3072;
+    asm volatile(
+        "global_load_dwordx4 %0, %16, off sc1\n\t"
+        "global_load_dwordx4 %1, %16, off offset:1024 sc1\n\t"
+        "global_load_dwordx4 %2, %16, off offset:2048 sc1\n\t"
+        "global_load_dwordx4 %3, %16, off offset:3072 sc1\n\t"
+        "global_load_dwordx4 %4, %17, off sc1\n\t"
+        "global_load_dwordx4 %5, %17, off offset:1024 sc1\n\t"
+        "global_load_dwordx4 %6, %17, off offset:2048 sc1\n\t"
+        "global_load_dwordx4 %7, %17, off offset:3072 sc1\n\t"
+        "global_load_dwordx4 %8, %18, off sc1\n\t"
+        "global_load_dwordx4 %9, %18, off offset:1024 sc1\n\t"
+        "global_load_dwordx4 %10, %18, off offset:2048 sc1\n\t"
+        "global_load_dwordx4 %11, %18, off offset:3072 sc1\n\t"
+        "global_load_dwordx4 %12, %19, off sc1\n\t"
+        "global_load_dwordx4 %13, %19, off offset:1024 sc1\n\t"
+        "global_load_dwordx4 %14, %19, off offset:2048 sc1\n\t"
+        "global_load_dwordx4 %15, %19, off offset:3072 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7]),
+          "=&v"(a[8]), "=&v"(a[9]), "=&v"(a[10]), "=&v"(a[11]), "=&v"(a[12]), "=&v"(a[13]), "=&v"(a[14]), "=&v"(a[15])
+        : "v"(p), "v"(p1), "v"(p2), "v"(p3)
+        : "memory");
+}
+
 // grid = ngroups * (H/16), block = 64*NW.   sync: [0..ngroups) arrival counters, [64] abort word (all zero on entry)
 template <int H, int NW>
 __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict__ gates, const float* __restrict__ wfrag,
@@ -94,7 +141,8 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
     const int bc = b < B ? b : B - 1;
     float* hwr = hf + (((long)dir * nbt + bt) * NC + jt) * 256 + ((jj >> 2) * 16 + bi) * 4 + (jj & 3);
     const bool cell = tid < 256;
-    float c_state = 0.f;
+    float c_state = 0.f, h_val = 0.f;
+    float sv[4] = {0.f, 0.f, 0.f, 0.f};
     float xg[4] = {0.f, 0.f, 0.f, 0.f}, xn[4] = {0.f, 0.f, 0.f, 0.f};
     auto tau_of = [&](int st) { return HALO + (dir == 0 ? st : T - 1 - st); };
     auto grow_of = [&](int tau) { return gates + ((long)bc * TP + tau) * (8 * H) + dir * 4 * H + j; };
@@ -144,24 +192,27 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
             }
             const float gi = sigmoidf_(pre[0]), gf = sigmoidf_(pre[1]), gg = tanhf(pre[2]), go = sigmoidf_(pre[3]);
             c_state = gf * c_state + gi * gg;
-            const float h = go * tanhf(c_state);
-            if (b < B) {
-                float* gr = grow_of(tau);
-                gr[0] = gi;
-                gr[H] = gf;
-                gr[2 * H] = gg;
-                gr[3 * H] = go;
-                const long o = ((long)b * TP + tau) * (2 * H) + dir * H + j;
-                csave[o] = c_state;
-                out[o] = h;
-                store_sc1(hwr + ((st + 1) & 1) * half, h);          // the hand-off payload: write-through
-            }
+            h_val = go * tanhf(c_state);
+            sv[0] = gi;
+            sv[1] = gf;
+            sv[2] = gg;
+            sv[3] = go;
+            if (b < B) store_sc1(hwr + ((st + 1) & 1) * half, h_val);      // the hand-off payload: write-through, first
 #pragma unroll
             for (int g = 0; g < 4; ++g) xg[g] = xn[g];
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains before the barrier
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // slab copies (consumed only by later kernels) go out after the group has been signalled
+        if (cell && b < B) {
+            float* gr = grow_of(tau);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gr[g * H] = sv[g];
+            const long o = ((long)b * TP + tau) * (2 * H) + dir * H + j;
+            csave[o] = c_state;
+            out[o] = h_val;
+        }
     }
 }
 
@@ -172,7 +223,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
                                                                const float* __restrict__ csave,
                                                                unsigned* __restrict__ sync, int B, int T, int nbt) {
     constexpr int JT = H / 16, NC = 4 * H / 16, kw = 4 * H / NW, nchunk = kw / 16;
-    static_assert(nchunk % 4 == 0, "chunks per wave must be a multiple of 4");
+    static_assert(nchunk == 16 || nchunk == 8, "the persistent backward kernel is written for 8 or 16 chunks per wave");
     __shared__ float red[NW][16][16];
     __shared__ int s_ok;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -196,6 +247,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
     float* gwr = gf + ((long)dir * nbt + bt) * NC * 256 + ((jj >> 2) * 16 + bi) * 4 + (jj & 3);
     const bool cell = tid < 256;
     float dc_rec = 0.f;
+    float da[4] = {0.f, 0.f, 0.f, 0.f};
     auto tau_of = [&](int st) { return HALO + (dir == 0 ? T - 1 - st : st); };
     struct Ops {
         float gi, gf, gg, go, d_o, cc, cp;
@@ -226,21 +278,16 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
             __syncthreads();
             if (!s_ok) return;
             const float* ap = grd + (st & 1) * half;
+            f32x4 a[nchunk];
+            if constexpr (nchunk == 16) load16x4_sc1(ap, a);
+            else load8x4_sc1(ap, a);
 #pragma unroll
-            for (int c4 = 0; c4 < nchunk; c4 += 4) {
-                f32x4 a0, a1, a2, a3;
-                load4x4_sc1(ap + c4 * 256, a0, a1, a2, a3);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q], bw[c4][q], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q], bw[c4 + 1][q], acc1, 0, 0, 0);
-                }
+            for (int c = 0; c < nchunk; c += 2)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[q], bw[c4 + 2][q], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[q], bw[c4 + 3][q], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][q], bw[c][q], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c + 1][q], bw[c + 1][q], acc1, 0, 0, 0);
                 }
-            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[w][(lane >> 4) * 4 + r][li] = acc0[r] + acc1[r];
@@ -254,25 +301,25 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
             const float d_o = dh * tc;
             const float dc = dc_rec + dh * cur.go * (1.0f - tc * tc);
             dc_rec = dc * cur.gf;
-            float da[4];
             da[0] = dc * cur.gg * cur.gi * (1.0f - cur.gi);
             da[1] = dc * cur.cp * cur.gf * (1.0f - cur.gf);
             da[2] = dc * cur.gi * (1.0f - cur.gg * cur.gg);
             da[3] = d_o * cur.go * (1.0f - cur.go);
             if (b < B) {
-                float* gr = gates + ((long)b * TP + tau) * (8 * H) + dir * 4 * H + j;
                 float* gw = gwr + ((st + 1) & 1) * half;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    gr[g * H] = da[g];                                          // slab copy for the weight-gradient GEMMs
-                    store_sc1(gw + (long)(g * JT + jt) * 256, da[g]);           // hand-off payload
-                }
+                for (int g = 0; g < 4; ++g) store_sc1(gw + (long)(g * JT + jt) * 256, da[g]);       // hand-off payload first
             }
             cur = nxt;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cell && b < B) {                                                   // slab copy for the weight-gradient GEMMs
+            float* gr = gates + ((long)b * TP + tau) * (8 * H) + dir * 4 * H + j;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gr[g * H] = da[g];
+        }
     }
 }
 

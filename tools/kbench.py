@@ -233,11 +233,54 @@ def bench_lstm_modes(B=64, T=128, H=512):
     say(f'torch tiny kernel x128: {t / 128:.2f} us each')
 
 
+def bench_seq(B=64, T=128, H=512):
+    dev = 'cuda'
+    g = torch.Generator(device='cpu').manual_seed(0)
+    xproj = (torch.randn(B, T, 2, 4 * H, generator=g) * 0.5).to(dev)
+    whh = (torch.rand(2, 4 * H, H, generator=g) * 2 - 1).to(dev) / H ** 0.5
+    d_out = (torch.randn(B, T, 2 * H, generator=g) * 0.1).to(dev)
+    scratch = torch.zeros(8 * H * H + 16 * B * H + 2 * B * H + 1024, device=dev)
+    gates = torch.zeros(B, T + 4, 8 * H, device=dev)
+    gates[:, 2:2 + T] = xproj.reshape(B, T, 8 * H)
+    xp_keep = gates.clone()
+    out = torch.zeros(B, T + 4, 2 * H, device=dev)
+    cs = torch.zeros(B, T + 4, 2 * H, device=dev)
+    dpad = torch.zeros(B, T + 4, 2 * H, device=dev)
+    dpad[:, 2:2 + T] = d_out
+    res = {}
+    for rnd in range(2):
+        for ps in (0, 1):
+            tune('persist', ps)
+            tune('lstm_nw', 16)
+
+            def fwd():
+                gates.copy_(xp_keep)
+                _capi.check(lib.ss_op_lstm_fwd(P(gates), P(whh[0]), P(whh[1]), P(out), P(cs), P(scratch), scratch.numel(), B, T, H, S()))
+
+            def copy_only():
+                gates.copy_(xp_keep)
+            tf = timeit(fwd)[0] - timeit(copy_only)[0]
+            ga_keep = gates.clone()
+            o_keep = out.clone()
+
+            def bwd():
+                gates.copy_(ga_keep)
+                _capi.check(lib.ss_op_lstm_bwd(P(gates), P(whh[0]), P(whh[1]), P(dpad), P(cs), P(scratch), scratch.numel(), B, T, H, S()))
+            tb = timeit(bwd)[0] - timeit(copy_only)[0]
+            res[ps] = (o_keep, gates.clone())
+            say(f'lstm layer H{H} B{B} T{T} persist{ps}: fwd {tf:.0f} us ({tf / T:.2f}/step)  bwd {tb:.0f} us ({tb / T:.2f}/step)')
+    say(f'   persist vs step kernels: out max diff {float((res[0][0] - res[1][0]).abs().max()):.2e}, '
+        f'dgates max diff {float((res[0][1] - res[1][1]).abs().max()):.2e}')
+    tune('persist', 1)
+
+
 if __name__ == '__main__':
     want = sys.argv[1:] or ['lstm', 'gemm', 'step']
     say('====', ' '.join(want), torch.cuda.get_device_name(0))
     if 'lstm' in want:
         bench_lstm()
+    if 'seq' in want:
+        bench_seq()
     if 'modes' in want:
         bench_lstm_modes()
     if 'gemm' in want:
