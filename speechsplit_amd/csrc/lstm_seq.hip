@@ -23,6 +23,8 @@
 
 namespace ss {
 
+int g_seq_prio = 1;    // 1: persistent recurrence waves run at s_setprio 3
+
 namespace {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -112,11 +114,12 @@ template <int H, int NW>
 __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict__ gates, const float* __restrict__ wfrag,
                                                                float* __restrict__ hf, float* __restrict__ out,
                                                                float* __restrict__ csave, unsigned* __restrict__ sync,
-                                                               int B, int T, int nbt) {
+                                                               int B, int T, int nbt, int prio) {
     constexpr int JT = H / 16, NC = H / 16, kw = H / NW, nchunk = kw / 16;
     static_assert(nchunk == 4, "the persistent forward kernel is written for 4 chunks per wave");
     __shared__ float red[NW][4][16][16];
     __shared__ int s_ok;
+    if (prio) __builtin_amdgcn_s_setprio(3);      // the recurrence is the critical path; co-resident GEMM waves are filler
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ngroups = 2 * nbt;
     const int grp = blockIdx.x % ngroups, jt = blockIdx.x / ngroups;
@@ -221,11 +224,12 @@ template <int H, int NW>
 __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict__ gates, const float* __restrict__ wfragT,
                                                                float* __restrict__ gf, const float* __restrict__ d_out,
                                                                const float* __restrict__ csave,
-                                                               unsigned* __restrict__ sync, int B, int T, int nbt) {
+                                                               unsigned* __restrict__ sync, int B, int T, int nbt, int prio) {
     constexpr int JT = H / 16, NC = 4 * H / 16, kw = 4 * H / NW, nchunk = kw / 16;
     static_assert(nchunk == 16 || nchunk == 8, "the persistent backward kernel is written for 8 or 16 chunks per wave");
     __shared__ float red[NW][16][16];
     __shared__ int s_ok;
+    if (prio) __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ngroups = 2 * nbt;
     const int grp = blockIdx.x % ngroups, jt = blockIdx.x / ngroups;
@@ -336,8 +340,8 @@ hipError_t lstm_seq_fwd(float* gates, const float* wfrag, float* hf, float* out,
     if (!lstm_seq_supported(B, H)) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(sync, 0, 128 * sizeof(unsigned), s);
     if (e != hipSuccess) return e;
-    if (H == 512) hipLaunchKernelGGL((lstm_seq_fwd_kernel<512, 8>), dim3(2 * nbt * 32), dim3(512), 0, s, gates, wfrag, hf, out, csave, sync, B, T, nbt);
-    else          hipLaunchKernelGGL((lstm_seq_fwd_kernel<256, 4>), dim3(2 * nbt * 16), dim3(256), 0, s, gates, wfrag, hf, out, csave, sync, B, T, nbt);
+    if (H == 512) hipLaunchKernelGGL((lstm_seq_fwd_kernel<512, 8>), dim3(2 * nbt * 32), dim3(512), 0, s, gates, wfrag, hf, out, csave, sync, B, T, nbt, g_seq_prio);
+    else          hipLaunchKernelGGL((lstm_seq_fwd_kernel<256, 4>), dim3(2 * nbt * 16), dim3(256), 0, s, gates, wfrag, hf, out, csave, sync, B, T, nbt, g_seq_prio);
     return hipGetLastError();
 }
 
@@ -347,8 +351,8 @@ hipError_t lstm_seq_bwd(float* gates, const float* wfragT, float* gf, const floa
     if (!lstm_seq_supported(B, H)) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(sync, 0, 128 * sizeof(unsigned), s);
     if (e != hipSuccess) return e;
-    if (H == 512) hipLaunchKernelGGL((lstm_seq_bwd_kernel<512, 8>), dim3(2 * nbt * 32), dim3(512), 0, s, gates, wfragT, gf, d_out, csave, sync, B, T, nbt);
-    else          hipLaunchKernelGGL((lstm_seq_bwd_kernel<256, 8>), dim3(2 * nbt * 16), dim3(512), 0, s, gates, wfragT, gf, d_out, csave, sync, B, T, nbt);
+    if (H == 512) hipLaunchKernelGGL((lstm_seq_bwd_kernel<512, 8>), dim3(2 * nbt * 32), dim3(512), 0, s, gates, wfragT, gf, d_out, csave, sync, B, T, nbt, g_seq_prio);
+    else          hipLaunchKernelGGL((lstm_seq_bwd_kernel<256, 8>), dim3(2 * nbt * 16), dim3(512), 0, s, gates, wfragT, gf, d_out, csave, sync, B, T, nbt, g_seq_prio);
     return hipGetLastError();
 }
 

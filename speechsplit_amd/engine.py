@@ -229,6 +229,11 @@ class Engine:
         return flat.view(B, T + 4, cols.value)[:, 2:2 + T].clone()
 
 
+def tune(key, value):
+    """Process-global tuning knob of the HIP library (ss_tune in include/speechsplit_amd.h)."""
+    _capi.check(_capi.lib().ss_tune(key.encode(), int(value)))
+
+
 def gemm(a, b, bias=None, ta=False, tb=False, ksplit=1, out=None):
     """Test hook for the MFMA GEMM: C[M,N] = A(m,k) B(n,k) (+bias).  a: [M,K] or [K,M] if ta; b: [N,K] or [K,N] if tb."""
     lib = _capi.lib()

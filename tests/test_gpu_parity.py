@@ -244,20 +244,33 @@ def test_fused_train_step_against_reference_fixture(E, tag):
                     assert abs(float(flat[p]) - v) <= TOL * s['amax'] + 1e-9, (n, p)
 
 
-@pytest.mark.parametrize('case', [(2, 64, 9, 46, True), (4, 128, 9, 61, False), (5, 192, 4, 70, False)])
+@pytest.mark.parametrize('case', [(2, 64, 9, 46, True, 1), (4, 128, 9, 61, False, 1), (5, 192, 4, 70, False, 1),
+                                  (4, 128, 9, 61, False, 0), (3, 64, 9, 46, False, 2)])
 def test_fused_train_step_full_gradients(E, case):
-    """Every element of all 86 gradients against the oracle's autograd."""
-    B, T, wseed, bseed, want_safe = case
+    """Every element of all 86 gradients against the oracle's autograd.  The last field selects the decoder recurrence
+    schedule: 1 = persistent kernels (default), 0 = one launch per time step, 2 = per-step launches captured in a hipGraph."""
+    B, T, wseed, bseed, want_safe, sched = case
+    E.tune('persist', 1 if sched == 1 else 0)
+    E.tune('graph', 1 if sched == 2 else 0)
+    try:
+        _full_gradients(E, B, T, wseed, bseed, want_safe)
+    finally:
+        E.tune('persist', 1)
+        E.tune('graph', 0)
+
+
+def _full_gradients(E, B, T, wseed, bseed, want_safe):
     hp = W.default_hparams(max_len_pad=T)
     w = W.make_weights('G3', hp, wseed)
     if want_safe:
         mel, f0, emb, lens, draws = kink_safe_case(hp, w, B, T, bseed)
     else:
-        mel, f0, emb, lens = synth_batch(bseed, B, T, 64 if T == 128 else 96)
+        mel, f0, emb, lens = synth_batch(bseed, B, T, 64 if T <= 128 else 96)
         draws = draws_for(bseed + 100, B, 4)
     eng = get_engine(E, 'G3', T, 8)
     eng.load_weights(w)
     loss = eng.g3_train_step(mel, f0, emb, lens, stack_draws(draws), no_adam=True)
+    eng.check()                       # no persistent kernel gave up
     P = ref_model.as_params(w)
     margins = kink_margins(P, hp, mel, f0, emb, lens, draws)
     lo, _ = ref_model.g3_loss(P, hp, mel, f0, emb, lens.numpy(), draws)
