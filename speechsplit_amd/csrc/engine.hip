@@ -18,7 +18,7 @@
 using namespace ss;
 
 namespace ss {
-extern int g_lstm_nw, g_lstm_g, g_lstm_mode, g_gemm_bk, g_gemm_want, g_gemm_diag, g_seq_prio;
+extern int g_lstm_nw, g_lstm_g, g_lstm_mode, g_gemm_bk, g_gemm_want, g_gemm_diag, g_seq_prio, g_gemm_mode;
 int g_overlap = 1;     // 1: weight-gradient GEMMs on the side stream
 int g_side_prio = 0;   // 1: create the side stream with the lowest priority (read at ss_bind).  Measured: 2.3x SLOWER
                        //    (35 ms vs 14.8 ms per step): the low-priority queue starves behind 768 tiny step launches.
@@ -1296,6 +1296,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "side_prio" && (value == 0 || value == 1)) g_side_prio = value;
     else if (k == "gemm_bk" && (value == 16 || value == 32)) g_gemm_bk = value;
     else if (k == "gemm_want" && value >= 1) g_gemm_want = value;
+    else if (k == "gemm_mode" && (value == 0 || value == 1)) g_gemm_mode = value;
     else if (k == "gemm_diag" && value >= 0 && value < 4) g_gemm_diag = value;
     else return fail("ss_tune: unknown key or bad value: " + k);
     ++g_tune_epoch;

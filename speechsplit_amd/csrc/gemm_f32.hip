@@ -318,6 +318,9 @@ hipError_t launch_layout(const GemmDesc& d, bool vec, hipStream_t s) {
 
 }  // namespace
 
+hipError_t launch_gemm_bf16x3(const GemmDesc& d, hipStream_t s);
+extern int g_gemm_mode;
+
 hipError_t launch_gemm(const GemmDesc& din, hipStream_t s) {
     GemmDesc d = din;
     d.diag = g_gemm_diag;
@@ -325,6 +328,7 @@ hipError_t launch_gemm(const GemmDesc& din, hipStream_t s) {
     if (d.ksplit < 1) d.ksplit = 1;
     if (d.ksplit > 1 && !(d.flags & GEMM_ACCUM)) return hipErrorInvalidValue;   // split-K needs a zeroed / live C
     const bool vec = vec_ok(d.A) && vec_ok(d.B);
+    if (vec && g_gemm_mode == 1) return launch_gemm_bf16x3(d, s);
     const bool ta = d.flags & GEMM_TA, tb = d.flags & GEMM_TB;
     if (!ta && !tb) return launch_layout<false, false>(d, vec, s);
     if (!ta && tb) return launch_layout<false, true>(d, vec, s);

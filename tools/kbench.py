@@ -156,17 +156,17 @@ def bench_gemm():
         Bm = torch.randn((K, N) if tb else (N, K), device=dev)
         c = torch.zeros(M, N, device=dev)
         ref = ((A.t() if ta else A).double() @ (Bm if tb else Bm.t()).double())
-        for bk in (16, 32):
+        for mode in (0, 1):
             for want in (256, 1024):
-                tune('gemm_bk', bk)
+                tune('gemm_mode', mode)
                 tune('gemm_want', want)
                 c.zero_()
                 E.gemm(A, Bm, None, ta, tb, ks, out=c)
                 err = float((c.double() - ref).abs().max() / ref.abs().max())
                 t, tmin = timeit(lambda: E.gemm(A, Bm, None, ta, tb, ks, out=c), iters=7)
-                say(f'gemm {name} ks{ks} bk{bk} want{want}: {t:8.1f} us  {2.0 * M * N * K / t / 1e6:6.1f} TF  (min {tmin:.1f} us, err {err:.1e})')
-    tune('gemm_bk', 16)
-    tune('gemm_want', 256)
+                say(f'gemm {name} ks{ks} {"bf16x3" if mode else "fp32  "} want{want}: {t:8.1f} us  {2.0 * M * N * K / t / 1e6:6.1f} TF  (min {tmin:.1f} us, err {err:.1e})')
+    tune('gemm_mode', 1)
+    tune('gemm_want', 1024)
 
 
 def bench_gemm_diag():
@@ -201,13 +201,12 @@ def bench_step():
     eng = E.Engine('G3', hp, B, T)
     eng.load_weights(W.make_weights('G3', hp, 0))
     for rnd in range(2):
-        for ps, ov in [(1, 1), (0, 1), (1, 0)]:
-            tune('persist', 1)
-            tune('seq_prio', ps)
+        for ps, ov in [(0, 1), (1, 1), (1, 0)]:
+            tune('gemm_mode', ps)
             tune('overlap', ov)
             t, tmin = timeit(lambda: eng.g3_train_step(mel, f0, emb, lens, (sc, ls)), iters=10, warm=3)
             eng.check()
-            say(f'train step seq_prio{ps} overlap{ov}: {t / 1e3:.3f} ms  ({B / t * 1e6:.0f} utt/s) min {tmin / 1e3:.3f}, loss {float(eng.loss):.6f}')
+            say(f'train step gemm_mode{ps} overlap{ov}: {t / 1e3:.3f} ms  ({B / t * 1e6:.0f} utt/s) min {tmin / 1e3:.3f}, loss {float(eng.loss):.6f}')
     tune('persist', 1)
     tune('overlap', 1)
 
