@@ -48,10 +48,9 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
     constexpr int PA = BM * 64, PB = BN * 64;                 // bytes per plane
     __shared__ __attribute__((aligned(16))) unsigned char As[3 * PA];
     __shared__ __attribute__((aligned(16))) unsigned char Bs[3 * PB];
-    // slots per thread and tile: K-contiguous operand -> float4 along k (8 per row);
-    // reduction-major operand -> two float4 (rows k, k+1) along 4 consecutive m
-    constexpr int NA = TA ? BM * BK / 8 / 256 : BM * BK / 4 / 256;
-    constexpr int NB = TB ? BN * BK / 8 / 256 : BN * BK / 4 / 256;
+    // a slot = 4 consecutive k of one row of the tile.  K-contiguous operand: one float4 (8 slots per row, lanes along k);
+    // reduction-major operand: four dword loads down the source rows, lanes along the tile rows (coalesced)
+    constexpr int NA = BM * BK / 4 / 256, NB = BN * BK / 4 / 256;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -91,13 +90,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
             const int sg = op.seglen ? c / op.seglen : 0;
             w = op.seglen ? c - sg * op.seglen : c;
             p = base + (long)(ok ? r : 0) * op.ld + (long)sg * op.segstride + w;
-        } else {             // k pair kp = f / (BX/4): source rows k = 2kp, 2kp+1; 4 consecutive columns at (f % (BX/4))*4
-            const int c = x0 + (f % (BX / 4)) * 4;
+        } else {             // tile row (source column) = f % BX, 4 consecutive source rows k = (f / BX) * 4 ...
+            const int c = x0 + f % BX;
             ok = c < X;
             const int cc = ok ? c : 0;
             const int sg = op.seglen ? cc / op.seglen : 0;
-            w = c;
-            p = base + (long)(kbeg + 2 * (f / (BX / 4))) * op.ld + (long)sg * op.segstride + (op.seglen ? cc - sg * op.seglen : cc);
+            w = 0;
+            p = base + (long)(kbeg + 4 * (f / BX)) * op.ld + (long)sg * op.segstride + (op.seglen ? cc - sg * op.seglen : cc);
         }
     };
 #pragma unroll
@@ -105,20 +104,15 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) setup(d.B, Bb, TB, n0, d.N, BN, tid + i * 256, pb[i], wb[i], okb[i]);
 
-    // K-contiguous slot: one float4.  Reduction-major slot: v = row k, v2 = row k+1 (each 4 consecutive columns).
-    struct Slot {
-        f32x4 v, v2;
-    };
-    auto fetch = [&](const Operand& op, bool T, const float*& p, int& w, bool ok, int kpos, int cmax) -> Slot {
-        Slot s;
-        s.v = f32x4{0.f, 0.f, 0.f, 0.f};
-        s.v2 = f32x4{0.f, 0.f, 0.f, 0.f};
+    typedef f32x4 Slot;
+    auto fetch = [&](const Operand& op, bool T, const float*& p, int& w, bool ok, int kpos) -> Slot {
+        Slot s = f32x4{0.f, 0.f, 0.f, 0.f};
         if (!T) {
             if (ok && kpos < kend) {
-                if (kpos + 3 < kend) s.v = *reinterpret_cast<const f32x4*>(p);
+                if (kpos + 3 < kend) s = *reinterpret_cast<const f32x4*>(p);
                 else
                     for (int j = 0; j < 4; ++j)
-                        if (kpos + j < kend) s.v[j] = p[j];
+                        if (kpos + j < kend) s[j] = p[j];
             }
             p += BK;
             if (op.seglen) {
@@ -130,19 +124,9 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
             }
         } else {
             if (ok) {
-                const bool full = w + 3 < cmax;
-                if (kpos < kend) {
-                    if (full) s.v = *reinterpret_cast<const f32x4*>(p);
-                    else
-                        for (int j = 0; j < 4; ++j)
-                            if (w + j < cmax) s.v[j] = p[j];
-                }
-                if (kpos + 1 < kend) {
-                    if (full) s.v2 = *reinterpret_cast<const f32x4*>(p + op.ld);
-                    else
-                        for (int j = 0; j < 4; ++j)
-                            if (w + j < cmax) s.v2[j] = p[op.ld + j];
-                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (kpos + j < kend) s[j] = p[(long)j * op.ld];
             }
             p += (long)BK * op.ld;
         }
@@ -153,37 +137,25 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int f = tid + i * 256;
-            ra[i] = fetch(d.A, TA, pa[i], wa[i], oka[i], TA ? k0 + 2 * (f / (BM / 4)) : k0 + (f % 8) * 4, d.M);
+            ra[i] = fetch(d.A, TA, pa[i], wa[i], oka[i], TA ? k0 + 4 * (f / BM) : k0 + (f % 8) * 4);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int f = tid + i * 256;
-            rb[i] = fetch(d.B, TB, pb[i], wb[i], okb[i], TB ? k0 + 2 * (f / (BN / 4)) : k0 + (f % 8) * 4, d.N);
+            rb[i] = fetch(d.B, TB, pb[i], wb[i], okb[i], TB ? k0 + 4 * (f / BN) : k0 + (f % 8) * 4);
         }
     };
     // split the prefetched fp32 values and write the three bf16 planes
     auto sstore_one = [&](unsigned char* S, int P, bool T, int BX, int f, const Slot& s) {
-        if (!T) {
-            const int row = f / 8, k = (f % 8) * 4;
-            unsigned h0, m0_, l0, h1, m1, l1;
-            split2(s.v[0], s.v[1], h0, m0_, l0);
-            split2(s.v[2], s.v[3], h1, m1, l1);
-            const int o = lds_off(row, k);
-            *reinterpret_cast<u32x2*>(S + o) = u32x2{h0, h1};
-            *reinterpret_cast<u32x2*>(S + P + o) = u32x2{m0_, m1};
-            *reinterpret_cast<u32x2*>(S + 2 * P + o) = u32x2{l0, l1};
-        } else {
-            const int k = 2 * (f / (BX / 4)), row0 = (f % (BX / 4)) * 4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                unsigned h, m, l;
-                split2(s.v[j], s.v2[j], h, m, l);           // (k, k+1) of row row0+j
-                const int o = lds_off(row0 + j, k);
-                *reinterpret_cast<unsigned*>(S + o) = h;
-                *reinterpret_cast<unsigned*>(S + P + o) = m;
-                *reinterpret_cast<unsigned*>(S + 2 * P + o) = l;
-            }
-        }
+        const int row = T ? f % BX : f / 8;
+        const int k = T ? (f / BX) * 4 : (f % 8) * 4;
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split2(s[0], s[1], h0, m0_, l0);
+        split2(s[2], s[3], h1, m1, l1);
+        const int o = lds_off(row, k);
+        *reinterpret_cast<u32x2*>(S + o) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(S + P + o) = u32x2{m0_, m1};
+        *reinterpret_cast<u32x2*>(S + 2 * P + o) = u32x2{l0, l1};
     };
     auto sstore = [&]() {
 #pragma unroll
@@ -273,7 +245,8 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t s) {
 template <bool TA, bool TB>
 hipError_t launch_layout(const GemmDesc& d, hipStream_t s) {
     auto tiles = [&](int bm, int bn) { return (long)cdiv(d.M, bm) * cdiv(d.N, bn) * d.batch * d.ksplit; };
-    const long want = g_gemm_want;
+    // reduction-major operands pay more per staged element, so they prefer the largest tile sooner
+    const long want = (TA && TB && g_gemm_want > 256) ? 256 : g_gemm_want;
     if (d.N > 64 && d.M > 64 && tiles(128, 128) >= want) return launch_cfg<128, 128, TA, TB>(d, s);
     if (d.M > 64 && tiles(128, 64) >= want) return launch_cfg<128, 64, TA, TB>(d, s);
     return launch_cfg<64, 64, TA, TB>(d, s);
