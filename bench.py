@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 # algorithmic work, SURVEY.md section 8(d): 19 405 064 MAC / frame / utterance, fwd+bwd = 3 x 2 x MAC
 MAC_PER_FRAME_G3 = 19405064
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 
 
@@ -127,6 +128,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    eng.profile(True)            # hipEvent pairs around the dominant kernel's launches, on their launch stream (ss_profile)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -143,7 +145,7 @@ def main():
         # roofline of the dominant kernel family: the fp32 MFMA GEMM.  Timed live with HIP events on the launch stream
         # at the shape that carries the most FLOPs in the step (decoder input projection, layer 1/2).
         print(f'[bench] gpu: {ms:.3f} ms/step, {value:.1f} utt/s on {world} GPU(s)', file=sys.stderr, flush=True)
-        roof = gemm_roofline(eng, B, T, dev)
+        roof = gemm_roofline(eng, B, T)
         print(f'[bench] roofline: {roof}', file=sys.stderr, flush=True)
         out = {
             'metric': 'utterances/sec (fwd+bwd, 128-frame 80-mel, batch 64) at 1/2/4/8 MI355X',
@@ -163,38 +165,37 @@ def main():
         dist.destroy_process_group()
 
 
-def gemm_roofline(eng, B, T, dev, iters=20):
-    """Achieved TFLOP/s of gemm_f32_kernel<128,128> on the decoder input-projection shape of this workload
-    (per utterance M=T, N=2048, K=1024, batched over the B utterances): algorithmic FLOPs = 2*B*T*2048*1024 per launch."""
-    from speechsplit_amd import engine as E
-    M, N, K = B * T, 2048, 1024
-    a = torch.randn(M, K, device=dev)
-    b = torch.randn(N, K, device=dev)
-    c = torch.empty(M, N, device=dev)
-    for _ in range(3):
-        E.gemm(a, b, out=c)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        E.gemm(a, b, out=c)
-    e1.record()
-    torch.cuda.synchronize()
-    sec = e0.elapsed_time(e1) / 1e3 / iters
-    flops = 2.0 * M * N * K
+def gemm_roofline(eng, B, T):
+    """Roofline of the dominant kernel, measured INSIDE the timed region: the engine brackets every launch of the decoder
+    input-projection GEMM of layers 1-2 (gemm_bf16x3_kernel<128,128,NT>; per launch M = B*T rows, N = 2048, K = 1024, fp32
+    in / fp32 out / fp32 accumulate) with hipEvents on its launch stream (ss_profile in include/speechsplit_amd.h).
+    achieved = algorithmic FLOPs of one launch (2*M*N*K) / mean launch duration.
+
+    The kernel forms every fp32 product from an exact 3-way bf16 split of both operands: 6 v_mfma_f32_32x32x16_bf16 per
+    fp32 multiply-add (the 3 lowest-order cross terms are dropped, error <= fp32's own rounding).  Its pipe is therefore the
+    dense bf16 MFMA pipe (2.5 PFLOP/s) and its ceiling in algorithmic fp32 FLOP/s is 2500 / 6 = 416.7 TFLOP/s; the fp32 MFMA
+    peak (157.3 TFLOP/s) is reported beside it."""
+    n, us, flops = eng.profile(False)
+    if n == 0:
+        return None
+    sec = us / n / 1e6
     ach = flops / sec / 1e12
-    # HBM bytes per launch of this shape from the PMC passes kept under profiles/ (FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024,
-    # the gfx950 correction of MI355X_MICROARCH.md); they cannot be collected live from inside the benchmark process
+    # HBM bytes per launch of this shape from the PMC passes kept under profiles/ (separate rocprofv3 --pmc runs, gfx950
+    # corrections applied by tools/pmc_summary.py); counters cannot be collected from inside the benchmark process
     traffic = None
     try:
         rec = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'gemm_pmc.json')))[0]
-        if rec['shape'].startswith('proj NT 8192x2048x1024') and B * T == 8192:
+        if rec['shape'].startswith('proj NT 8192x2048x1024') and B * T == 8192 and 'bf16x3' in rec.get('kernel', ''):
             traffic = rec['hbm_read_bytes'] + rec['hbm_write_bytes']
     except Exception:
         pass
-    return {'bound': 'mfma', 'kernel': 'gemm_f32_kernel<128,128,NT> (decoder input projection shape)',
-            'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-            'flops_per_launch': flops, 'us_per_launch': round(sec * 1e6, 2), 'traffic': traffic}
+    peak = PEAK_BF16_MFMA_TFLOPS / 6.0
+    return {'bound': 'mfma', 'kernel': 'gemm_bf16x3_kernel<128,128,NT> (decoder input projection, layers 1-2; fp32 via 6 bf16 MFMAs per product)',
+            'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+            'peak_basis': 'dense bf16 MFMA 2500 TFLOP/s / 6 MFMA products per fp32 multiply-add',
+            'mfma_tflops_executed': round(6 * ach, 1), 'fp32_mfma_peak': PEAK_F32_MFMA_TFLOPS,
+            'vs_fp32_mfma_peak': round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+            'launches_timed': n, 'flops_per_launch': flops, 'us_per_launch': round(sec * 1e6, 2), 'traffic': traffic}
 
 
 if __name__ == '__main__':

@@ -126,6 +126,12 @@ int ss_op_lstm_bwd(float* gates_dev, const float* whh_f_dev, const float* whh_b_
 /* tuning knobs (process-global): "lstm_nw" 4|8|16, "lstm_g" 0..16, "gemm_bk" 16|32, "gemm_want" >= 1,
  * "overlap" 0|1, "graph" 0|1, "persist" 0|1, "split" 0|1; "lstm_mode" / "gemm_diag" are timing experiments that produce wrong results */
 int ss_tune(const char* key, int value);
+/* Live timing of the dominant kernel inside a caller's own timed region: while enabled, the engine brackets every launch
+ * of the decoder input-projection GEMM of layers >= 1 (one launch per direction: M = B*T rows, N = 4H, K = 2H, H = decoder hidden size) with
+ * hipEvents on the stream it is launched on.  A call returns the launches recorded since the previous call, their summed
+ * duration and the algorithmic FLOPs of one launch (2*B*T*4H*2H), resets the record and sets the enable state.
+ * Synchronises on the recorded events.  At most 256 launches are kept between two calls.  Any out pointer may be null. */
+int ss_profile(ss_engine* e, int enable, int* launches, double* total_us, double* flops_per_launch);
 /* named internal slab of the last call ("enc1.xf2", "dec.out2", ...); layout [B, T+4, C], frame t at row t+2 */
 int ss_debug_buffer(ss_engine* e, const char* name, float** ptr_dev, long* rows, long* cols);
 int ss_debug_names(ss_engine* e, char* buf, int cap);

@@ -105,25 +105,30 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
     for (int i = 0; i < NB; ++i) setup(d.B, Bb, TB, n0, d.N, BN, tid + i * 256, pb[i], wb[i], okb[i]);
 
     typedef f32x4 Slot;
-    auto fetch = [&](const Operand& op, bool T, const float*& p, int& w, bool ok, int kpos) -> Slot {
+    // full: the whole k-tile lies inside [kbeg, kend), so the load needs no predicate at all (rows / columns past the
+    // matrix edge read row / column 0: their products land in accumulator entries the epilogue never stores).
+    auto fetch = [&](const Operand& op, bool T, const float*& p, int& w, bool ok, int kpos, bool full) -> Slot {
         Slot s = f32x4{0.f, 0.f, 0.f, 0.f};
         if (!T) {
-            if (ok && kpos < kend) {
+            if (full) s = *reinterpret_cast<const f32x4*>(p);
+            else if (ok && kpos < kend) {
                 if (kpos + 3 < kend) s = *reinterpret_cast<const f32x4*>(p);
                 else
                     for (int j = 0; j < 4; ++j)
                         if (kpos + j < kend) s[j] = p[j];
             }
             p += BK;
-            if (op.seglen) {
+            if (op.seglen) {                          // seglen >= BK (checked by the launcher): at most one wrap per tile
                 w += BK;
-                while (w >= op.seglen) {
-                    w -= op.seglen;
-                    p += op.segstride - op.seglen;
-                }
+                const bool wrap = w >= op.seglen;
+                w -= wrap ? op.seglen : 0;
+                p += wrap ? op.segstride - op.seglen : 0;
             }
         } else {
-            if (ok) {
+            if (full) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[j] = p[(long)j * op.ld];
+            } else if (ok) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (kpos + j < kend) s[j] = p[(long)j * op.ld];
@@ -133,16 +138,16 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
         return s;
     };
     Slot ra[NA], rb[NB];
-    auto gload = [&](int k0) {
+    auto gload = [&](int k0, bool full) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int f = tid + i * 256;
-            ra[i] = fetch(d.A, TA, pa[i], wa[i], oka[i], TA ? k0 + 4 * (f / BM) : k0 + (f % 8) * 4);
+            ra[i] = fetch(d.A, TA, pa[i], wa[i], oka[i], TA ? k0 + 4 * (f / BM) : k0 + (f % 8) * 4, full);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int f = tid + i * 256;
-            rb[i] = fetch(d.B, TB, pb[i], wb[i], okb[i], TB ? k0 + 4 * (f / BN) : k0 + (f % 8) * 4);
+            rb[i] = fetch(d.B, TB, pb[i], wb[i], okb[i], TB ? k0 + 4 * (f / BN) : k0 + (f % 8) * 4, full);
         }
     };
     // split the prefetched fp32 values and write the three bf16 planes
@@ -173,11 +178,14 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     const int l31 = lane & 31, kg = lane >> 5;
-    if (nk > 0) gload(kbeg);
+    const int nfull = (kend - kbeg) / BK;           // k-tiles that need no bounds checks
+    if (nk > 0) gload(kbeg, false);
     for (int kt = 0; kt < nk; ++kt) {
         sstore();                                   // tile kt: registers -> bf16 planes
         __syncthreads();
-        if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);   // tile kt+1 in flight during the MFMAs
+        // tile kt+1 in flight during the MFMAs
+        if (kt + 1 < nfull) gload(kbeg + (kt + 1) * BK, true);
+        else if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK, false);
 #pragma unroll
         for (int ks16 = 0; ks16 < BK / 16; ++ks16) {
             bf16x8 a[3][MI], b[3][NI];

@@ -328,7 +328,8 @@ hipError_t launch_gemm(const GemmDesc& din, hipStream_t s) {
     if (d.ksplit < 1) d.ksplit = 1;
     if (d.ksplit > 1 && !(d.flags & GEMM_ACCUM)) return hipErrorInvalidValue;   // split-K needs a zeroed / live C
     const bool vec = vec_ok(d.A) && vec_ok(d.B);
-    if (vec && g_gemm_mode == 1) return launch_gemm_bf16x3(d, s);
+    const bool seg_ok = (d.A.seglen == 0 || d.A.seglen >= 32) && (d.B.seglen == 0 || d.B.seglen >= 32);   // one wrap per k-tile
+    if (vec && seg_ok && g_gemm_mode == 1) return launch_gemm_bf16x3(d, s);
     const bool ta = d.flags & GEMM_TA, tb = d.flags & GEMM_TB;
     if (!ta && !tb) return launch_layout<false, false>(d, vec, s);
     if (!ta && tb) return launch_layout<false, true>(d, vec, s);

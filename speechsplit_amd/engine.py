@@ -219,6 +219,13 @@ class Engine:
         self.lib.ss_debug_names(self.h, buf, len(buf))
         return [s for s in buf.value.decode().split('\n') if s]
 
+    def profile(self, enable):
+        """ss_profile: (launches, total_us, flops_per_launch) of the decoder input-projection GEMM (layers >= 1) recorded
+        with hipEvents on the launch stream since the previous call; sets the enable state for what follows."""
+        n, us, fl = C.c_int(), C.c_double(), C.c_double()
+        _capi.check(self.lib.ss_profile(self.h, int(bool(enable)), C.byref(n), C.byref(us), C.byref(fl)))
+        return n.value, us.value, fl.value
+
     def debug_buffer(self, name, B, T):
         """Real frames of an internal haloed slab as a [B, T, C] tensor (copy)."""
         p, rows, cols = C.c_void_p(), C.c_long(), C.c_long()
