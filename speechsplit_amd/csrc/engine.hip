@@ -126,7 +126,8 @@ struct ss_engine {
     // weight-gradient GEMMs of a BLSTM layer run on this side stream while the next layer's recurrence (latency-bound,
     // one launch per time step) proceeds on the caller's stream
     hipStream_t side = nullptr;
-    hipStream_t side2 = nullptr;          // second batch-half chain of the decoder recurrences
+    hipStream_t side2 = nullptr;          // independent branches (per-step weight re-layouts, Encoder_t, second encoder BLSTM); second batch-half chain
+    hipStream_t side3 = nullptr;          // third independent branch of the encoder backward (Encoder_t)
     hipStream_t cap = nullptr;            // graphs are captured and replayed here (a legacy default stream cannot capture)
     hipEvent_t ev_io[2] = {};             // caller stream <-> cap ordering
     // captured training steps (hipGraph), keyed by geometry / flags / grad_scale; inputs are staged into engine-owned
@@ -511,6 +512,20 @@ int make_chains(ss_engine* e, int B, hipStream_t s, Chain ch[2]) {
     return 1;
 }
 
+// Per-step re-layouts of one BLSTM block's weights: b_ih + b_hh per (layer, direction) and, for the decoder-size blocks,
+// the fragment-major W_hh of the forward recurrence.  Independent of the activations, so the schedule runs it on a branch.
+int lstm_prep(ss_engine* e, LstmBlk& lb, hipStream_t s) {
+    const int H = lb.H;
+    for (int l = 0; l < lb.L; ++l) {
+        for (int dir = 0; dir < 2; ++dir) {
+            const LstmDir& pd = lb.pd[l * 2 + dir];
+            HIPCHK(add_vec(e->P + pd.bih, e->P + pd.bhh, lb.bsum + ((long)l * 2 + dir) * 4 * H, 4 * H, s));
+        }
+        if (lb.big()) HIPCHK(lstm_pack_w(e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.wfrag[l], H, 0, s));
+    }
+    return 0;
+}
+
 // Decoder-size BLSTM (one launch per time step).  The batch is cut in two halves that run as independent chains on
 // two streams through ALL layers: every operator is per-utterance, so nothing couples them until the head.
 int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
@@ -520,13 +535,6 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
     const bool persist = g_persist && lstm_seq_supported(B, H);
     const int nch = persist ? 1 : make_chains(e, B, s, ch);
     if (persist) ch[0] = {0, B, s};
-    for (int l = 0; l < lb.L; ++l) {
-        for (int dir = 0; dir < 2; ++dir) {
-            const LstmDir& pd = lb.pd[l * 2 + dir];
-            HIPCHK(add_vec(e->P + pd.bih, e->P + pd.bhh, lb.bsum + ((long)l * 2 + dir) * 4 * H, 4 * H, s));
-        }
-        HIPCHK(lstm_pack_w(e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.wfrag[l], H, 0, s));
-    }
     if (nch == 2) CHK(fork_join(e, s, ch[1].st));
     for (int l = 0; l < lb.L; ++l) {
         const int In = lb.in_of(l);
@@ -581,8 +589,7 @@ int lstm_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
         Slab xi = l == 0 ? x : Slab{lb.out[l - 1], 2L * H};
         for (int dir = 0; dir < 2; ++dir) {
             const LstmDir& pd = lb.pd[l * 2 + dir];
-            float* bs = lb.bsum + ((long)l * 2 + dir) * 4 * H;
-            HIPCHK(add_vec(e->P + pd.bih, e->P + pd.bhh, bs, 4 * H, s));
+            float* bs = lb.bsum + ((long)l * 2 + dir) * 4 * H;     // lstm_prep
             GemmDesc d{};
             d.A = {xi.p + HALO * xi.ld, xi.ld, TP * xi.ld, 0, 0};
             d.B = {e->P + pd.wih, In, 0, 0, 0};
@@ -675,11 +682,7 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
     ch[0] = {0, B, s};
     const bool persist = lb.big() && g_persist && lstm_seq_supported(B, H);
     const int nch = (lb.big() && !persist) ? make_chains(e, B, s, ch) : 1;
-    if (lb.big()) {
-        for (int l = 0; l < lb.L; ++l)
-            HIPCHK(lstm_pack_w(e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.wfrag[l], H, 1, s));
-        if (nch == 2) CHK(fork_join(e, s, ch[1].st));
-    }
+    if (lb.big() && nch == 2) CHK(fork_join(e, s, ch[1].st));
     for (int l = lb.L - 1; l >= 0; --l) {
         Slab xi = l == 0 ? x : Slab{lb.out[l - 1], 2L * H};
         Slab dxi = l == 0 ? dx : Slab{lb.dmid[l & 1], 2L * H};
@@ -730,15 +733,6 @@ int join_side(ss_engine* e, hipStream_t s) {
 }
 
 // ---- whole-model schedules ---------------------------------------------------------------------------------
-int pack_weights(ss_engine* e, hipStream_t s) {
-    for (int i = 0; i < 3; ++i) {
-        if (e->c1[i].Co) CHK(conv_pack_all(e, e->c1[i], s));
-        if (e->c2[i].Co) CHK(conv_pack_all(e, e->c2[i], s));
-    }
-    CHK(conv_pack_all(e, e->ct, s));
-    return 0;
-}
-
 // Encoder_7 (G3) / Encoder_6 (G6) trunk + their LSTMs, Encoder_t, decoder, head.  Inputs already in in_mel/in_f0/org/emb.
 int forward_core(ss_engine* e, bool training, const float* scales, const int* len_seg, int draw0, hipStream_t s) {
     const int B = e->curB, T = e->curT;
@@ -746,10 +740,35 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
     const int CE = e->CE;
     const bool g3 = e->kind == SS_GENERATOR_3;
     const int S7 = e->plan[0].S;
-    CHK(pack_weights(e, s));
     const int off2 = g3 ? e->hp.dim_enc : 0;       // first channel of the f0 stream inside the fused slab
+    // Branches.  `s` carries the conv trunk; `b2` the per-step weight re-layouts followed by Encoder_t (depends on x_org
+    // only); after the trunk the two encoder BLSTMs run side by side (`s`, `b1`).  Everything joins at the decoder input.
+    const bool par = e->side && e->side2 && g_overlap;
+    hipStream_t b1 = par ? e->side : s, b2 = par ? e->side2 : s;
+    if (g3) CHK(conv_pack_all(e, e->c1[0], s));
+    CHK(conv_pack_all(e, e->c2[0], s));
+    if (par) CHK(fork_join(e, s, b2));
+    for (int i = 1; i < 3; ++i) {
+        if (g3) CHK(conv_pack_all(e, e->c1[i], b2));
+        CHK(conv_pack_all(e, e->c2[i], b2));
+    }
+    CHK(conv_pack_all(e, e->ct, b2));
+    hipEvent_t packed = nullptr;
+    if (par) {
+        packed = e->ev[e->ev_next];
+        e->ev_next = (e->ev_next + 1) & 15;
+        HIPCHK(hipEventRecord(packed, b2));
+    }
+    if (g3) CHK(lstm_prep(e, e->l1, b2));
+    CHK(lstm_prep(e, e->l2, b2));
+    CHK(lstm_prep(e, e->lt, b2));
+    CHK(lstm_prep(e, e->ld, b2));
+    // Encoder_t (model.py:74-89)
+    CHK(conv_block_fwd(e, e->ct, Slab{e->org, e->hp.dim_freq}, Slab{e->act_t, e->hp.dim_enc_2}, b2));
+    CHK(lstm_fwd(e, e->lt, Slab{e->act_t, e->hp.dim_enc_2}, b2));
     for (int i = 0; i < 3; ++i) {
         float* y = training ? e->act : e->xf[i];
+        if (i == 1 && packed) HIPCHK(hipStreamWaitEvent(s, packed, 0));
         if (g3) {
             Slab x1 = i == 0 ? Slab{e->in_mel, e->hp.dim_freq} : Slab{e->xf[i - 1], CE};
             CHK(conv_block_fwd(e, e->c1[i], x1, Slab{y, CE}, s));
@@ -764,11 +783,13 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
             HIPCHK(interp_gather(pl, e->act + HALO * CE, CE, TP * CE, e->xf[i] + HALO * CE, CE, TP * CE, CE, B, s));
         }
     }
+    if (par) {
+        CHK(fork_join(e, b2, s));                  // bias sums of every block are ready (and Encoder_t is done)
+        CHK(fork_join(e, s, b1));
+    }
+    CHK(lstm_fwd(e, e->l2, Slab{e->xf[2] + off2, CE}, b1));
     if (g3) CHK(lstm_fwd(e, e->l1, Slab{e->xf[2], CE}, s));
-    CHK(lstm_fwd(e, e->l2, Slab{e->xf[2] + off2, CE}, s));
-    // Encoder_t (model.py:74-89)
-    CHK(conv_block_fwd(e, e->ct, Slab{e->org, e->hp.dim_freq}, Slab{e->act_t, e->hp.dim_enc_2}, s));
-    CHK(lstm_fwd(e, e->lt, Slab{e->act_t, e->hp.dim_enc_2}, s));
+    if (par) CHK(fork_join(e, b1, s));
     // decoder input (model.py:301-309 / 341-347)
     CodeSrc src[3];
     int n = 0;
@@ -812,6 +833,13 @@ int backward_decoder(ss_engine* e, hipStream_t s) {
     const int B = e->curB, T = e->curT;
     const long TP = T + 2 * HALO, R = (long)B * TP;
     HIPCHK(hipMemsetAsync(e->G, 0, e->arena * 4, s));
+    // fragment-major W_hh^T of the decoder recurrences (overwrites the forward layout, no longer needed), beside the head
+    const bool par = e->side2 && g_overlap;
+    hipStream_t b2 = par ? e->side2 : s;
+    if (par) CHK(fork_join(e, s, b2));
+    if (e->ld.big())
+        for (int l = 0; l < e->ld.L; ++l)
+            HIPCHK(lstm_pack_w(e->P + e->ld.pd[l * 2].whh, e->P + e->ld.pd[l * 2 + 1].whh, e->ld.wfrag[l], e->ld.H, 1, b2));
     // head
     const long HD = 2L * e->ld.H;
     const float* h3 = e->ld.out[e->ld.L - 1];
@@ -842,6 +870,7 @@ int backward_decoder(ss_engine* e, hipStream_t s) {
         g.ksplit = 1;
         GEMM(g);
     }
+    if (par) CHK(fork_join(e, b2, s));
     CHK(lstm_bwd(e, e->ld, e->d_top, Slab{e->dec_in, e->dec_in_dim}, Slab{e->d_dec_in, e->dec_in_dim}, s));
     return 0;
 }
@@ -867,12 +896,21 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
     }
     HIPCHK(dec_in_grad(src, n, e->d_dec_in, e->dec_in_dim, B, T, s));
     const int off2 = g3 ? h.dim_enc : 0;
+    // Three independent branches below the decoder input: lstm_1 (on `s`), lstm_2 (`b2`; writes the other columns of d_xf)
+    // and Encoder_t (`b3`; joins at the end).  Their weight-gradient GEMMs share the side stream.
+    const bool par = e->side2 && e->side3 && g_overlap;
+    hipStream_t b2 = par ? e->side2 : s, b3 = par ? e->side3 : s;
+    if (par) {
+        CHK(fork_join(e, s, b2));
+        CHK(fork_join(e, s, b3));
+    }
     // encoder BLSTMs -> gradient of the last fused slab
+    CHK(lstm_bwd(e, e->l2, e->d_o2, Slab{e->xf[2] + off2, CE}, Slab{e->d_xf + off2, CE}, b2));
     if (g3) CHK(lstm_bwd(e, e->l1, e->d_o1, Slab{e->xf[2], CE}, Slab{e->d_xf, CE}, s));
-    CHK(lstm_bwd(e, e->l2, e->d_o2, Slab{e->xf[2] + off2, CE}, Slab{e->d_xf + off2, CE}, s));
     // Encoder_t
-    CHK(lstm_bwd(e, e->lt, e->d_ot, Slab{e->act_t, h.dim_enc_2}, Slab{e->d_act_t, h.dim_enc_2}, s));
-    CHK(conv_block_bwd(e, e->ct, Slab{e->d_act_t, h.dim_enc_2}, Slab{e->org, h.dim_freq}, Slab{nullptr, 0}, s));
+    CHK(lstm_bwd(e, e->lt, e->d_ot, Slab{e->act_t, h.dim_enc_2}, Slab{e->d_act_t, h.dim_enc_2}, b3));
+    CHK(conv_block_bwd(e, e->ct, Slab{e->d_act_t, h.dim_enc_2}, Slab{e->org, h.dim_freq}, Slab{nullptr, 0}, b3));
+    if (par) CHK(fork_join(e, b2, s));
     // conv trunk, last layer first
     for (int i = 2; i >= 0; --i) {
         float* dy = e->d_xf;
@@ -894,6 +932,7 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
             HIPCHK(hipMemcpyAsync(e->d_xf, e->d_act, R * CE * 4, hipMemcpyDeviceToDevice, s));
         }
     }
+    if (par) CHK(fork_join(e, b3, s));
     CHK(join_side(e, s));
     return 0;
 }
@@ -980,10 +1019,11 @@ void ss_destroy(ss_engine* e) {
         for (auto& ev : e->ev)
             if (ev) (void)hipEventDestroy(ev);
         (void)hipStreamDestroy(e->side);
-        if (e->side2) {
-            (void)hipStreamSynchronize(e->side2);
-            (void)hipStreamDestroy(e->side2);
-        }
+        for (hipStream_t st : {e->side2, e->side3})
+            if (st) {
+                (void)hipStreamSynchronize(st);
+                (void)hipStreamDestroy(st);
+            }
         if (e->cap) {
             (void)hipStreamSynchronize(e->cap);
             for (auto& ev : e->ev_io)
@@ -1041,6 +1081,7 @@ int ss_bind(ss_engine* e, float* params, float* grads, float* m, float* v, void*
         }
         for (auto& ev : e->ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         HIPCHK(hipStreamCreateWithFlags(&e->side2, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&e->side3, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&e->cap, hipStreamNonBlocking));
         for (auto& ev : e->ev_io) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
@@ -1111,6 +1152,7 @@ int ss_g3_rhythm(ss_engine* e, const float* x_org, int B, int T, float* codes, v
     HIPCHK(copy_rows(x_org, h.dim_freq, (long)T * h.dim_freq, e->org + HALO * h.dim_freq, h.dim_freq, TP * h.dim_freq, B, T,
                      h.dim_freq, s));
     CHK(conv_pack_all(e, e->ct, s));
+    CHK(lstm_prep(e, e->lt, s));
     CHK(conv_block_fwd(e, e->ct, Slab{e->org, h.dim_freq}, Slab{e->act_t, h.dim_enc_2}, s));
     CHK(lstm_fwd(e, e->lt, Slab{e->act_t, h.dim_enc_2}, s));
     // codes = cat(fwd[:, 7::8], bwd[:, ::8]) (model.py:84-87): reuse the decoder-input assembler on a 2H-wide row and pick t % freq == 0
