@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restrict__ x, long x_ld, long x_bs,
                                                           float* __restrict__ dy, long dy_ld, long dy_bs,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          const float* __restrict__ stats, float* __restrict__ part,
+                                                          const float* __restrict__ stats, float* __restrict__ g_gamma,
+                                                          float* __restrict__ g_beta, float* __restrict__ g_bias,
                                                           int B, int T, int C) {
     __shared__ float red[256];
     __shared__ float g4[4];
@@ -163,7 +164,8 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
         const int which = tid >> 6, cc = tid & 63;
         float s = 0.f;
         for (int r = 0; r < 16; ++r) s += colred[which][r][cc];
-        part[((long)which * B + b) * C + blockIdx.x * 64 + cc] = s;
+        float* dst = which == 0 ? g_gamma : which == 1 ? g_beta : g_bias;     // sums over the utterances meet in the arena
+        atomicAdd(dst + blockIdx.x * 64 + cc, s);
     }
 }
 
@@ -405,10 +407,11 @@ hipError_t gn_relu_fwd(const float* x, long x_ld, long x_bs, float* y, long y_ld
 }
 
 hipError_t gn_relu_bwd(const float* x, long x_ld, long x_bs, float* dy, long dy_ld, long dy_bs, const float* gamma,
-                       const float* beta, const float* stats, float* part, int B, int T, int C, hipStream_t s) {
+                       const float* beta, const float* stats, float* g_gamma, float* g_beta, float* g_bias, int B, int T, int C,
+                       hipStream_t s) {
     if (C % 64 != 0 || T > 16 * GN_MAXIT) return hipErrorInvalidValue;
     hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(C / 64, B), dim3(256), 0, s, x, x_ld, x_bs, dy, dy_ld, dy_bs, gamma, beta,
-                       stats, part, B, T, C);
+                       stats, g_gamma, g_beta, g_bias, B, T, C);
     return hipGetLastError();
 }
 

@@ -59,7 +59,7 @@ struct ParamInfo {
 struct ConvBlk {
     int Ci = 0, Co = 0, Cp = 0;
     long w = 0, b = 0, ga = 0, be = 0;     // arena offsets
-    float *wf = nullptr, *wb = nullptr, *gp = nullptr, *cout = nullptr, *stats = nullptr, *part = nullptr;
+    float *wf = nullptr, *wb = nullptr, *gp = nullptr, *cout = nullptr, *stats = nullptr;
     bool need_dx = false;
 };
 
@@ -76,7 +76,15 @@ struct LstmBlk {
     float* hf[2] = {nullptr, nullptr};     // per batch-half chain: ping-pong fragment-major h(t),  2 x [2][ceil16(B)][H]
     float* gf[2] = {nullptr, nullptr};     // per chain: ping-pong fragment-major da(t), 2 x [2][ceil16(B)][4H]
     float* dc[2] = {nullptr, nullptr};     // per chain: [2][B][H]
-    unsigned* sync = nullptr;              // persistent kernels: group counters + abort word
+    unsigned* sync = nullptr;              // persistent kernels: group counters + abort word (one-off ops path)
+    // persistent schedule: per-layer start state, contiguous so ONE memset per pass readies every layer's launch.
+    //   zf = [L][128 sync words] ++ [L][hf]      (forward)        zb = [L][128 sync words] ++ [L][gf]   (backward)
+    char *zf = nullptr, *zb = nullptr;
+    long zf_bytes = 0, zb_bytes = 0, hf_bytes = 0, gf_bytes = 0;
+    unsigned* sync_f(int l) const { return (unsigned*)zf + 128 * l; }
+    unsigned* sync_b(int l) const { return (unsigned*)zb + 128 * l; }
+    float* hf_l(int l) const { return (float*)(zf + 512L * L + hf_bytes * l); }
+    float* gf_l(int l) const { return (float*)(zb + 512L * L + gf_bytes * l); }
     float* dmid[2] = {nullptr, nullptr};   // gradient slabs of inner layer outputs [B,TP,2H]
     bool big() const { return H > 32; }
     int in_of(int l) const { return l == 0 ? In : 2 * H; }
@@ -118,6 +126,8 @@ struct ss_engine {
     float *dec_in = nullptr, *d_dec_in = nullptr, *d_top = nullptr;
     float *d_o1 = nullptr, *d_o2 = nullptr, *d_ot = nullptr;
     float *out_slab = nullptr, *d_out_slab = nullptr;
+    float* gp_all = nullptr;               // packed conv weight-gradient images (all blocks)
+    long gp_bytes = 0;
     float *loss_part = nullptr;
     int* qidx = nullptr;
     InterpPlan plan[4];
@@ -270,10 +280,8 @@ long ss_engine::carve(int B, int T, bool assign) {
         if (cb.Co == 0) return;
         cb.wf = (float*)take((long)cb.Co * 5 * cb.Cp * 4);
         cb.wb = cb.need_dx ? (float*)take((long)cb.Ci * 5 * cb.Co * 4) : nullptr;
-        cb.gp = (float*)take((long)cb.Co * 5 * cb.Cp * 4);
         cb.cout = slab((name + ".conv").c_str(), cb.Co);
         cb.stats = (float*)take((long)B * (cb.Co / 16) * 2 * 4);
-        cb.part = (float*)take(3L * B * cb.Co * 4);
     };
     auto lstm_ws = [&](LstmBlk& lb, const std::string& name) {
         if (lb.L == 0) return;
@@ -296,6 +304,12 @@ long ss_engine::carve(int B, int T, bool assign) {
                 lb.dc[c] = (float*)take(2L * B * lb.H * 4);
             }
             lb.sync = (unsigned*)take(128 * 4);
+            lb.hf_bytes = 2L * 2 * B16 * lb.H * 4;
+            lb.gf_bytes = 2L * 2 * B16 * 4 * lb.H * 4;
+            lb.zf_bytes = lb.L * (512L + lb.hf_bytes);
+            lb.zb_bytes = lb.L * (512L + lb.gf_bytes);
+            lb.zf = (char*)take(lb.zf_bytes);
+            lb.zb = (char*)take(lb.zb_bytes);
         }
         if (lb.L > 1) {
             lb.dmid[0] = slab((name + ".dmid0").c_str(), 2L * lb.H);
@@ -330,6 +344,18 @@ long ss_engine::carve(int B, int T, bool assign) {
     d_act = slab("enc.d_act", CE);
     d_xf = slab("enc.d_xf", CE);
     conv_ws(ct, "enc2.c");
+    {   // packed weight-gradient images of every conv, contiguous so one memset per backward zeroes them all
+        long tot = 0;
+        ConvBlk* all[7] = {&c1[0], &c1[1], &c1[2], &c2[0], &c2[1], &c2[2], &ct};
+        for (ConvBlk* cb : all) tot += align4((long)cb->Co * 5 * cb->Cp);
+        float* p = (float*)take(tot * 4);
+        gp_all = p;
+        gp_bytes = tot * 4;
+        for (ConvBlk* cb : all) {
+            cb->gp = cb->Co ? p : nullptr;
+            p += align4((long)cb->Co * 5 * cb->Cp);
+        }
+    }
     act_t = slab("enc2.act", hp.dim_enc_2);
     d_act_t = slab("enc2.d_act", hp.dim_enc_2);
     lstm_ws(l1, "enc1.lstm1");
@@ -432,6 +458,11 @@ int conv_pack_all(ss_engine* e, ConvBlk& cb, hipStream_t s) {
     return 0;
 }
 
+int zero_conv_grads(ss_engine* e, hipStream_t s) {
+    HIPCHK(hipMemsetAsync(e->gp_all, 0, e->gp_bytes, s));
+    return 0;
+}
+
 // y = relu(GN(conv5(x)))   x: slab view (ld), y: slab view
 int conv_block_fwd(ss_engine* e, ConvBlk& cb, Slab x, Slab y, hipStream_t s) {
     const int B = e->curB, T = e->curT;
@@ -458,13 +489,9 @@ int conv_block_fwd(ss_engine* e, ConvBlk& cb, Slab x, Slab y, hipStream_t s) {
 int conv_block_bwd(ss_engine* e, ConvBlk& cb, Slab dy, Slab x, Slab dx, hipStream_t s) {
     const int B = e->curB, T = e->curT;
     const long TP = T + 2 * HALO, R = (long)B * TP;
-    HIPCHK(gn_relu_bwd(cb.cout, cb.Co, TP * cb.Co, dy.p, dy.ld, TP * dy.ld, e->P + cb.ga, e->P + cb.be, cb.stats, cb.part,
-                       B, T, cb.Co, s));
-    HIPCHK(colsum_acc(cb.part, cb.Co, B, cb.Co, e->G + cb.ga, s));
-    HIPCHK(colsum_acc(cb.part + (long)B * cb.Co, cb.Co, B, cb.Co, e->G + cb.be, s));
-    HIPCHK(colsum_acc(cb.part + 2L * B * cb.Co, cb.Co, B, cb.Co, e->G + cb.b, s));
-    // weight gradient: one reduction over every slab row (halo rows of dy are zero)
-    HIPCHK(hipMemsetAsync(cb.gp, 0, (long)cb.Co * 5 * cb.Cp * 4, s));
+    HIPCHK(gn_relu_bwd(cb.cout, cb.Co, TP * cb.Co, dy.p, dy.ld, TP * dy.ld, e->P + cb.ga, e->P + cb.be, cb.stats,
+                       e->G + cb.ga, e->G + cb.be, e->G + cb.b, B, T, cb.Co, s));
+    // weight gradient: one reduction over every slab row (halo rows of dy are zero); cb.gp was zeroed by zero_conv_grads
     GemmDesc d{};
     d.A = {dy.p + 2 * dy.ld, dy.ld, 0, 0, 0};
     d.B = {x.p, x.ld, 0, cb.Cp, x.ld};
@@ -523,6 +550,7 @@ int lstm_prep(ss_engine* e, LstmBlk& lb, hipStream_t s) {
         }
         if (lb.big()) HIPCHK(lstm_pack_w(e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.wfrag[l], H, 0, s));
     }
+    if (lb.big()) HIPCHK(hipMemsetAsync(lb.zf, 0, lb.zf_bytes, s));     // h(-1) = 0 and the group counters of every layer
     return 0;
 }
 
@@ -560,11 +588,13 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
                 GEMM_ON(d, ch[c].st);
                 if (timed) HIPCHK(hipEventRecord(e->prof_ev[2 * e->prof_n++ + 1], ch[c].st));
             }
-            const long half = 2L * (((ch[c].nb + 15) / 16) * 16) * H;
-            HIPCHK(hipMemsetAsync(lb.hf[c], 0, 2 * half * 4, ch[c].st));
+            if (!persist) {
+                const long half = 2L * (((ch[c].nb + 15) / 16) * 16) * H;
+                HIPCHK(hipMemsetAsync(lb.hf[c], 0, 2 * half * 4, ch[c].st));
+            }
         }
-        if (persist) {
-            HIPCHK(lstm_seq_fwd(lb.gates[l], lb.wfrag[l], lb.hf[0], lb.out[l], lb.csave[l], lb.sync, B, T, H, s));
+        if (persist) {   // start state zeroed by lstm_prep
+            HIPCHK(lstm_seq_fwd(lb.gates[l], lb.wfrag[l], lb.hf_l(l), lb.out[l], lb.csave[l], lb.sync_f(l), B, T, H, false, s));
             continue;
         }
         for (int st = 0; st < T; ++st)
@@ -689,11 +719,12 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
         float* dG = lb.gates[l];
         hipStream_t ws = s;
         if (lb.big()) {
-            for (int c = 0; c < nch; ++c) {
+            for (int c = 0; c < nch && !persist; ++c) {
                 const long half = 2L * (((ch[c].nb + 15) / 16) * 16) * 4 * H;
                 HIPCHK(hipMemsetAsync(lb.gf[c], 0, 2 * half * 4, ch[c].st));
             }
-            if (persist) HIPCHK(lstm_seq_bwd(dG, lb.wfrag[l], lb.gf[0], dcur, lb.csave[l], lb.sync, B, T, H, s));
+            // persistent: start state zeroed by backward_decoder
+            if (persist) HIPCHK(lstm_seq_bwd(dG, lb.wfrag[l], lb.gf_l(l), dcur, lb.csave[l], lb.sync_b(l), B, T, H, false, s));
             for (int st = 0; st < T && !persist; ++st)
                 for (int c = 0; c < nch; ++c) {
                     const long r0 = (long)ch[c].b0 * TP;
@@ -840,6 +871,7 @@ int backward_decoder(ss_engine* e, hipStream_t s) {
     if (e->ld.big())
         for (int l = 0; l < e->ld.L; ++l)
             HIPCHK(lstm_pack_w(e->P + e->ld.pd[l * 2].whh, e->P + e->ld.pd[l * 2 + 1].whh, e->ld.wfrag[l], e->ld.H, 1, b2));
+    if (e->ld.big()) HIPCHK(hipMemsetAsync(e->ld.zb, 0, e->ld.zb_bytes, b2));   // da(T) = 0 and the group counters of every layer
     // head
     const long HD = 2L * e->ld.H;
     const float* h3 = e->ld.out[e->ld.L - 1];
@@ -904,6 +936,8 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
         CHK(fork_join(e, s, b2));
         CHK(fork_join(e, s, b3));
     }
+    CHK(zero_conv_grads(e, b2));                   // long done when the first conv weight gradient starts (b2 joins s, b3 forks after)
+    if (par) CHK(fork_join(e, b2, b3));
     // encoder BLSTMs -> gradient of the last fused slab
     CHK(lstm_bwd(e, e->l2, e->d_o2, Slab{e->xf[2] + off2, CE}, Slab{e->d_xf + off2, CE}, b2));
     if (g3) CHK(lstm_bwd(e, e->l1, e->d_o1, Slab{e->xf[2], CE}, Slab{e->d_xf, CE}, s));
@@ -1391,7 +1425,7 @@ int ss_op_lstm_fwd(float* gates, const float* whh_f, const float* whh_b, float* 
         HIPCHK(lstm_pack_w(whh_f, whh_b, scratch, H, 0, s));
         HIPCHK(hipMemsetAsync(hf, 0, 2 * half * 4, s));
         if (g_persist && lstm_seq_supported(B, H) && scratch_floats >= wn + 2 * half + 128) {
-            HIPCHK(lstm_seq_fwd(gates, scratch, hf, out, csave, (unsigned*)(hf + 2 * half), B, T, H, s));
+            HIPCHK(lstm_seq_fwd(gates, scratch, hf, out, csave, (unsigned*)(hf + 2 * half), B, T, H, true, s));
             return 0;
         }
         for (int st = 0; st < T; ++st)
@@ -1413,7 +1447,7 @@ int ss_op_lstm_bwd(float* gates, const float* whh_f, const float* whh_b, const f
         HIPCHK(lstm_pack_w(whh_f, whh_b, scratch, H, 1, s));
         HIPCHK(hipMemsetAsync(gf, 0, 2 * half * 4, s));
         if (g_persist && lstm_seq_supported(B, H)) {
-            HIPCHK(lstm_seq_bwd(gates, scratch, gf, d_out, csave, (unsigned*)dc, B, T, H, s));
+            HIPCHK(lstm_seq_bwd(gates, scratch, gf, d_out, csave, (unsigned*)dc, B, T, H, true, s));
             return 0;
         }
         for (int st = 0; st < T; ++st)
@@ -1428,10 +1462,12 @@ int ss_check(ss_engine* e, void* stream) {
     HIPCHK(hipStreamSynchronize(S(stream)));
     HIPCHK(hipGetLastError());
     for (LstmBlk* lb : {&e->ld, &e->l1, &e->l2, &e->lt}) {
-        if (!lb->sync) continue;
-        unsigned flag = 0;
-        HIPCHK(hipMemcpy(&flag, lb->sync + 64, 4, hipMemcpyDeviceToHost));
-        if (flag) return fail("persistent LSTM kernel gave up waiting for its group (bounded spin expired): results are invalid");
+        if (!lb->zf) continue;
+        for (int l = 0; l < 2 * lb->L; ++l) {
+            unsigned flag = 0;
+            HIPCHK(hipMemcpy(&flag, (l < lb->L ? lb->sync_f(l) : lb->sync_b(l - lb->L)) + 64, 4, hipMemcpyDeviceToHost));
+            if (flag) return fail("persistent LSTM kernel gave up waiting for its group (bounded spin expired): results are invalid");
+        }
     }
     return 0;
 }

@@ -37,9 +37,10 @@ hipError_t interp_scatter(const InterpPlan& p, const float* dy, long dy_ld, long
 hipError_t gn_relu_fwd(const float* x, long x_ld, long x_bs, float* y, long y_ld, long y_bs, const float* gamma,
                        const float* beta, float* stats /*[B, C/16, 2] mean, rstd*/, int B, int T, int C, hipStream_t s);
 // dy (grad of the ReLU output) is replaced in place by the grad of the GroupNorm input (= conv output).
-// part: [3][B][C] per-utterance partial sums of d_gamma, d_beta, d_convbias.
+// g_gamma / g_beta / g_bias [C]: every utterance's d_gamma, d_beta, d_convbias are ACCUMULATED here (f32 atomics).
 hipError_t gn_relu_bwd(const float* x, long x_ld, long x_bs, float* dy, long dy_ld, long dy_bs, const float* gamma,
-                       const float* beta, const float* stats, float* part, int B, int T, int C, hipStream_t s);
+                       const float* beta, const float* stats, float* g_gamma, float* g_beta, float* g_bias, int B, int T, int C,
+                       hipStream_t s);
 // out[c] += sum_r in[r*ld + c]   (atomic accumulate)
 hipError_t colsum_acc(const float* in, long ld, int R, int C, float* out, hipStream_t s);
 hipError_t copy_rows(const float* src, long s_ld, long s_bs, float* dst, long d_ld, long d_bs, int B, int T, int C,
@@ -99,11 +100,12 @@ hipError_t lstm_step_bwd(float* gates, const float* wfragT, const float* gf_cur,
                          const float* csave, float* dc, int B, int T, int H, int step, hipStream_t s);
 
 // ---------------------------------------------------------------- lstm_seq.hip  (persistent: one launch per layer)
-// Same operands as the step kernels; `sync` = 128 unsigned words (group arrival counters + abort word at [64]).
+// Same operands as the step kernels; `sync` = 128 unsigned words (group arrival counters + abort word at [64]).  hf / gf
+// and sync must be zero at launch: zero_sync = false means the caller has already zeroed `sync` (and hf / gf) itself.
 bool lstm_seq_supported(int B, int H);
 hipError_t lstm_seq_fwd(float* gates, const float* wfrag, float* hf, float* out, float* csave, unsigned* sync, int B, int T,
-                        int H, hipStream_t s);
+                        int H, bool zero_sync, hipStream_t s);
 hipError_t lstm_seq_bwd(float* gates, const float* wfragT, float* gf, const float* d_out, const float* csave, unsigned* sync,
-                        int B, int T, int H, hipStream_t s);
+                        int B, int T, int H, bool zero_sync, hipStream_t s);
 
 }  // namespace ss

@@ -335,10 +335,10 @@ bool lstm_seq_supported(int B, int H) {
 }
 
 hipError_t lstm_seq_fwd(float* gates, const float* wfrag, float* hf, float* out, float* csave, unsigned* sync, int B, int T,
-                        int H, hipStream_t s) {
+                        int H, bool zero_sync, hipStream_t s) {
     const int nbt = (B + 15) / 16;
     if (!lstm_seq_supported(B, H)) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(sync, 0, 128 * sizeof(unsigned), s);
+    hipError_t e = zero_sync ? hipMemsetAsync(sync, 0, 128 * sizeof(unsigned), s) : hipSuccess;
     if (e != hipSuccess) return e;
     if (H == 512) hipLaunchKernelGGL((lstm_seq_fwd_kernel<512, 8>), dim3(2 * nbt * 32), dim3(512), 0, s, gates, wfrag, hf, out, csave, sync, B, T, nbt, g_seq_prio);
     else          hipLaunchKernelGGL((lstm_seq_fwd_kernel<256, 4>), dim3(2 * nbt * 16), dim3(256), 0, s, gates, wfrag, hf, out, csave, sync, B, T, nbt, g_seq_prio);
@@ -346,10 +346,10 @@ hipError_t lstm_seq_fwd(float* gates, const float* wfrag, float* hf, float* out,
 }
 
 hipError_t lstm_seq_bwd(float* gates, const float* wfragT, float* gf, const float* d_out, const float* csave, unsigned* sync,
-                        int B, int T, int H, hipStream_t s) {
+                        int B, int T, int H, bool zero_sync, hipStream_t s) {
     const int nbt = (B + 15) / 16;
     if (!lstm_seq_supported(B, H)) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(sync, 0, 128 * sizeof(unsigned), s);
+    hipError_t e = zero_sync ? hipMemsetAsync(sync, 0, 128 * sizeof(unsigned), s) : hipSuccess;
     if (e != hipSuccess) return e;
     if (H == 512) hipLaunchKernelGGL((lstm_seq_bwd_kernel<512, 8>), dim3(2 * nbt * 32), dim3(512), 0, s, gates, wfragT, gf, d_out, csave, sync, B, T, nbt, g_seq_prio);
     else          hipLaunchKernelGGL((lstm_seq_bwd_kernel<256, 8>), dim3(2 * nbt * 16), dim3(512), 0, s, gates, wfragT, gf, d_out, csave, sync, B, T, nbt, g_seq_prio);
