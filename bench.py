@@ -81,6 +81,8 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='utterances per GPU')
     ap.add_argument('--frames', type=int, default=128)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', choices=['f32', 'bf16'], default='f32',
+                    help="f32 (default): the 1e-4 parity mode the headline is quoted on; bf16: BASELINE configs 2-4's arithmetic")
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -104,6 +106,7 @@ def main():
     eng = Engine('G3', hp, B, T, device=dev)
     eng.load_weights(W.make_weights('G3', hp, 0))
     eng.set_adam(1e-4, 0.9, 0.999, 1e-8, 0)
+    eng.set_precision(args.precision)
     mel, f0, emb, lens = synth(B, T, 1000 + rank, dev)
     torch.manual_seed(1234)
     sc_all, ls_all = draw_interp(B * world, 4, hp)          # one global draw stream, each rank takes its utterances' slice
@@ -145,13 +148,13 @@ def main():
         # roofline of the dominant kernel family: the fp32 MFMA GEMM.  Timed live with HIP events on the launch stream
         # at the shape that carries the most FLOPs in the step (decoder input projection, layer 1/2).
         print(f'[bench] gpu: {ms:.3f} ms/step, {value:.1f} utt/s on {world} GPU(s)', file=sys.stderr, flush=True)
-        roof = gemm_roofline(eng, B, T)
+        roof = gemm_roofline(eng, B, T, args.precision)
         print(f'[bench] roofline: {roof}', file=sys.stderr, flush=True)
         out = {
             'metric': 'utterances/sec (fwd+bwd, 128-frame 80-mel, batch 64) at 1/2/4/8 MI355X',
             'value': round(value, 1), 'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': args.precision, 'data': 'synthetic',
             'config': {'workload': f'Generator_3 full training step (resample+quantise+fwd+MSE+bwd+Adam), '
                                    f'{B} utterances/GPU x {T} frames x 80 mel + F0, max_len_pad={T}',
                        'global_batch': B * world, 'seq_len': T, 'parallelism': f'dp{world}'},
@@ -165,7 +168,7 @@ def main():
         dist.destroy_process_group()
 
 
-def gemm_roofline(eng, B, T):
+def gemm_roofline(eng, B, T, precision='f32'):
     """Roofline of the dominant kernel, measured INSIDE the timed region: the engine brackets every launch of the decoder
     input-projection GEMM of layers 1-2 (gemm_bf16x3_kernel<128,128,NT>; per launch M = B*T rows, N = 2048, K = 1024, fp32
     in / fp32 out / fp32 accumulate) with hipEvents on its launch stream (ss_profile in include/speechsplit_amd.h).
@@ -189,6 +192,10 @@ def gemm_roofline(eng, B, T):
             traffic = rec['hbm_read_bytes'] + rec['hbm_write_bytes']
     except Exception:
         pass
+    if precision == 'bf16':      # one bf16 MFMA per product: the pipe's own peak
+        return {'bound': 'mfma', 'kernel': 'gemm_bf16x3_kernel<128,128,NT,1 plane> (decoder input projection, layers 1-2; bf16 operands, fp32 accumulate)',
+                'achieved': round(ach, 2), 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
+                'launches_timed': n, 'flops_per_launch': flops, 'us_per_launch': round(sec * 1e6, 2), 'traffic': None}
     peak = PEAK_BF16_MFMA_TFLOPS / 6.0
     return {'bound': 'mfma', 'kernel': 'gemm_bf16x3_kernel<128,128,NT> (decoder input projection, layers 1-2; fp32 via 6 bf16 MFMAs per product)',
             'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),

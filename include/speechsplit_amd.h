@@ -111,7 +111,7 @@ int ss_interp_backward(ss_engine* e, const float* dy_dev, int B, int T, int C, f
 int ss_check(ss_engine* e, void* stream);
 
 /* ---- test / profiling hooks ---- */
-/* C[M,N] = A . B^T style fp32 MFMA GEMM used by every contraction on the path (flags: 1 = A stored [K,M], 2 = B stored [K,N]) */
+/* C[M,N] = A . B^T style fp32 MFMA GEMM used by every contraction on the path (flags: 1 = A stored [K,M], 2 = B stored [K,N], 8 = bf16-rounded operands) */
 int ss_op_gemm(const float* a_dev, long lda, const float* b_dev, long ldb, float* c_dev, long ldc, const float* bias_dev,
                int M, int N, int K, int flags, int ksplit, void* stream);
 /* One bidirectional LSTM recurrence on haloed slabs (speechsplit_amd/csrc/kernels.h): gates [B,T+4,8H] holds
@@ -126,6 +126,13 @@ int ss_op_lstm_bwd(float* gates_dev, const float* whh_f_dev, const float* whh_b_
 /* tuning knobs (process-global): "lstm_nw" 4|8|16, "lstm_g" 0..16, "gemm_bk" 16|32, "gemm_want" >= 1,
  * "overlap" 0|1, "graph" 0|1, "persist" 0|1, "split" 0|1; "lstm_mode" / "gemm_diag" are timing experiments that produce wrong results */
 int ss_tune(const char* key, int value);
+/* Arithmetic of the contractions (convolutions, LSTM input projections, all weight / input gradients, head).
+ * SS_PRECISION_F32 (default): fp32-grade products (exact 3-way bf16 split, 6 MFMAs) -- the 1e-4 parity mode.
+ * SS_PRECISION_BF16: operands rounded to bf16 (nearest-even) inside the GEMM, one MFMA, fp32 accumulation; storage, the
+ * recurrences (W_hh.h, cell state), GroupNorm, losses, resampling indices and Adam stay fp32 (BASELINE configs 2-4). */
+#define SS_PRECISION_F32 0
+#define SS_PRECISION_BF16 1
+int ss_set_precision(ss_engine* e, int precision);
 /* Live timing of the dominant kernel inside a caller's own timed region: while enabled, the engine brackets every launch
  * of the decoder input-projection GEMM of layers >= 1 (one launch per direction: M = B*T rows, N = 4H, K = 2H, H = decoder hidden size) with
  * hipEvents on the stream it is launched on.  A call returns the launches recorded since the previous call, their summed

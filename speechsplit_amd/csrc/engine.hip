@@ -101,6 +101,7 @@ struct ss_engine {
     int kind;
     ss_hparams hp;
     int maxB, maxT;
+    int precision = SS_PRECISION_F32;
     std::vector<ParamInfo> params;
     long arena = 0;
 
@@ -440,8 +441,13 @@ int pick_ksplit(int M, int N, long K) {
     return (int)ks;
 }
 
-#define GEMM(d) HIPCHK(launch_gemm(d, s))
-#define GEMM_ON(d, st) HIPCHK(launch_gemm(d, st))
+// every contraction of the engine honours its precision mode (ss_set_precision)
+#define GEMM(d) GEMM_ON(d, s)
+#define GEMM_ON(d, st)                                  \
+    do {                                                \
+        if (e->precision == SS_PRECISION_BF16) (d).flags |= GEMM_BF16; \
+        HIPCHK(launch_gemm(d, st));                     \
+    } while (0)
 
 // make `to` wait for everything enqueued on `from` so far
 int fork_join(ss_engine* e, hipStream_t from, hipStream_t to) {
@@ -1365,8 +1371,16 @@ int ss_op_gemm(const float* a, long lda, const float* b, long ldb, float* c, lon
     d.K = K;
     d.batch = 1;
     d.ksplit = ksplit < 1 ? 1 : ksplit;
-    d.flags = (flags & 1 ? GEMM_TA : 0) | (flags & 2 ? GEMM_TB : 0) | (d.ksplit > 1 ? GEMM_ACCUM : 0);
+    d.flags = (flags & 1 ? GEMM_TA : 0) | (flags & 2 ? GEMM_TB : 0) | (flags & 8 ? GEMM_BF16 : 0) | (d.ksplit > 1 ? GEMM_ACCUM : 0);
     HIPCHK(launch_gemm(d, S(stream)));
+    return 0;
+}
+
+int ss_set_precision(ss_engine* e, int precision) {
+    if (!e) return fail("ss_set_precision: null engine");
+    if (precision != SS_PRECISION_F32 && precision != SS_PRECISION_BF16) return fail("ss_set_precision: unknown precision");
+    if (e->precision != precision) drop_graphs(e);      // captured steps bake the kernel choice in
+    e->precision = precision;
     return 0;
 }
 

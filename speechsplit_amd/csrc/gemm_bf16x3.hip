@@ -39,15 +39,23 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned
     l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
 }
 
+// two fp32 values -> packed bf16 pair, round to nearest even (element 0 in the low half)
+__device__ __forceinline__ unsigned round2(float x0, float x1) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(x0), "v"(x1));
+    return r;
+}
+
 // byte offset of bf16 element (row, k) inside one plane: rows of 32 bf16 (64 B), 16-B chunks XOR-swizzled
 __device__ __forceinline__ int lds_off(int row, int k) { return row * 64 + (((k >> 3) ^ ((row >> 2) & 3)) << 4) + ((k & 7) << 1); }
 
-template <int BM, int BN, bool TA, bool TB>
+// NPL = 3: the exact split above (fp32-grade result).  NPL = 1 (GEMM_BF16): operands rounded once to bf16, one MFMA.
+template <int BM, int BN, bool TA, bool TB, int NPL>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
     constexpr int MI = BM / 64, NI = BN / 64;
     constexpr int PA = BM * 64, PB = BN * 64;                 // bytes per plane
-    __shared__ __attribute__((aligned(16))) unsigned char As[3 * PA];
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[3 * PB];
+    __shared__ __attribute__((aligned(16))) unsigned char As[NPL * PA];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[NPL * PB];
     // a slot = 4 consecutive k of one row of the tile.  K-contiguous operand: one float4 (8 slots per row, lanes along k);
     // reduction-major operand: four dword loads down the source rows, lanes along the tile rows (coalesced)
     constexpr int NA = BM * BK / 4 / 256, NB = BN * BK / 4 / 256;
@@ -154,10 +162,14 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
     auto sstore_one = [&](unsigned char* S, int P, bool T, int BX, int f, const Slot& s) {
         const int row = T ? f % BX : f / 8;
         const int k = T ? (f / BX) * 4 : (f % 8) * 4;
+        const int o = lds_off(row, k);
+        if (NPL == 1) {
+            *reinterpret_cast<u32x2*>(S + o) = u32x2{round2(s[0], s[1]), round2(s[2], s[3])};
+            return;
+        }
         unsigned h0, m0_, l0, h1, m1, l1;
         split2(s[0], s[1], h0, m0_, l0);
         split2(s[2], s[3], h1, m1, l1);
-        const int o = lds_off(row, k);
         *reinterpret_cast<u32x2*>(S + o) = u32x2{h0, h1};
         *reinterpret_cast<u32x2*>(S + P + o) = u32x2{m0_, m1};
         *reinterpret_cast<u32x2*>(S + 2 * P + o) = u32x2{l0, l1};
@@ -188,33 +200,34 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
         else if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK, false);
 #pragma unroll
         for (int ks16 = 0; ks16 < BK / 16; ++ks16) {
-            bf16x8 a[3][MI], b[3][NI];
+            bf16x8 a[NPL][MI], b[NPL][NI];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 const int row = wm * (BM / 2) + mi * 32 + l31;
                 const int o = lds_off(row, ks16 * 16 + kg * 8);
 #pragma unroll
-                for (int p = 0; p < 3; ++p) a[p][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + p * PA + o));
+                for (int p = 0; p < NPL; ++p) a[p][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + p * PA + o));
             }
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 const int row = wn * (BN / 2) + ni * 32 + l31;
                 const int o = lds_off(row, ks16 * 16 + kg * 8);
 #pragma unroll
-                for (int p = 0; p < 3; ++p) b[p][ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bs + p * PB + o));
+                for (int p = 0; p < NPL; ++p) b[p][ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bs + p * PB + o));
             }
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     f32x16 c = acc[mi][ni];
-                    // smallest terms first
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][mi], b[1][ni], c, 0, 0, 0);   // m.m
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], b[2][ni], c, 0, 0, 0);   // h.l
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][mi], b[0][ni], c, 0, 0, 0);   // l.h
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], b[1][ni], c, 0, 0, 0);   // h.m
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][mi], b[0][ni], c, 0, 0, 0);   // m.h
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], b[0][ni], c, 0, 0, 0);   // h.h
+                    if (NPL == 3) {   // smallest terms first
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NPL - 2][mi], b[NPL - 2][ni], c, 0, 0, 0);   // m.m
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], b[NPL - 1][ni], c, 0, 0, 0);         // h.l
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NPL - 1][mi], b[0][ni], c, 0, 0, 0);         // l.h
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], b[NPL - 2][ni], c, 0, 0, 0);         // h.m
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NPL - 2][mi], b[0][ni], c, 0, 0, 0);         // m.h
+                    }
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], b[0][ni], c, 0, 0, 0);                   // h.h
                     acc[mi][ni] = c;
                 }
         }
@@ -246,7 +259,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
 template <int BM, int BN, bool TA, bool TB>
 hipError_t launch_cfg(const GemmDesc& d, hipStream_t s) {
     dim3 grid(cdiv(d.N, BN), cdiv(d.M, BM), d.batch * d.ksplit);
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB>), grid, dim3(256), 0, s, d);
+    if (d.flags & GEMM_BF16) hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB, 1>), grid, dim3(256), 0, s, d);
+    else hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB, 3>), grid, dim3(256), 0, s, d);
     return hipGetLastError();
 }
 

@@ -219,6 +219,12 @@ class Engine:
         self.lib.ss_debug_names(self.h, buf, len(buf))
         return [s for s in buf.value.decode().split('\n') if s]
 
+    def set_precision(self, precision):
+        """'f32' (default, the 1e-4 parity mode) or 'bf16' (bf16-rounded GEMM operands, fp32 accumulate / state)."""
+        code = {'f32': 0, 'fp32': 0, 'bf16': 1}[precision]
+        _capi.check(self.lib.ss_set_precision(self.h, code))
+        self.precision = 'bf16' if code else 'f32'
+
     def profile(self, enable):
         """ss_profile: (launches, total_us, flops_per_launch) of the decoder input-projection GEMM (layers >= 1) recorded
         with hipEvents on the launch stream since the previous call; sets the enable state for what follows."""
@@ -241,7 +247,7 @@ def tune(key, value):
     _capi.check(_capi.lib().ss_tune(key.encode(), int(value)))
 
 
-def gemm(a, b, bias=None, ta=False, tb=False, ksplit=1, out=None):
+def gemm(a, b, bias=None, ta=False, tb=False, ksplit=1, out=None, bf16=False):
     """Test hook for the MFMA GEMM: C[M,N] = A(m,k) B(n,k) (+bias).  a: [M,K] or [K,M] if ta; b: [N,K] or [K,N] if tb."""
     lib = _capi.lib()
     M = a.shape[1] if ta else a.shape[0]
@@ -250,5 +256,5 @@ def gemm(a, b, bias=None, ta=False, tb=False, ksplit=1, out=None):
     assert (b.shape[0] if tb else b.shape[1]) == K
     c = torch.zeros(M, N, device=a.device) if out is None else out
     _capi.check(lib.ss_op_gemm(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(c), N, _ptr(bias), M, N, K,
-                               (1 if ta else 0) | (2 if tb else 0), ksplit, _stream()))
+                               (1 if ta else 0) | (2 if tb else 0) | (8 if bf16 else 0), ksplit, _stream()))
     return c

@@ -214,6 +214,59 @@ def test_module_train_step_with_torch_adam(E):
 
 
 # --------------------------------------------------------------------------------------------- fused training step (B2)
+def test_gemm_bf16_mode(E):
+    """GEMM_BF16: operands rounded to bf16 (nearest-even) inside the kernel, fp32 accumulation.  Against an fp64 product of
+    the bf16-rounded operands the result is fp32-accurate; against the fp32 product it shows bf16's ~2e-3."""
+    g = torch.Generator().manual_seed(5)
+    for M, N, K, ta, tb in [(256, 512, 400, False, False), (384, 256, 1024, False, True), (1024, 512, 2560, True, True)]:
+        A = torch.randn((K, M) if ta else (M, K), generator=g)
+        Bm = torch.randn((K, N) if tb else (N, K), generator=g)
+        Ab, Bb = A.bfloat16().double(), Bm.bfloat16().double()
+        ref = (Ab.t() if ta else Ab) @ (Bb if tb else Bb.t())
+        ref32 = (A.t() if ta else A).double() @ (Bm if tb else Bm.t()).double()
+        for ks in (1, 4):
+            c = E.gemm(A.cuda(), Bm.cuda(), None, ta, tb, ks, bf16=True)
+            assert rel(c, ref) < 5e-6, (M, N, K, ta, tb, ks)
+            assert 1e-4 < rel(c, ref32) < 1e-2
+
+
+def test_bf16_precision_train_step(E):
+    """BASELINE configs 2-4 name bf16.  ss_set_precision(BF16) rounds the operands of every contraction to bf16 (fp32
+    accumulate, fp32 storage / recurrent state / GroupNorm / Adam).  Stated bounds against the fp32 reference fixture and
+    the fp32 engine: loss 1e-3, mel reconstruction 1e-2, every gradient tensor 1e-1 (max-norm relative); the resampling
+    index path stays bit-exact because it never touches the GEMMs."""
+    tag = 'b8_t128'
+    rec = json.load(open(os.path.join(GOLD, 'train_steps.json')))[tag]
+    B, T = rec['B'], rec['T']
+    hp = W.default_hparams(max_len_pad=T)
+    mel, f0, emb, lens = synth_batch(rec['bseed'], B, T, 64)
+    nsteps = len(rec['losses'])
+    draws = draws_for(rec['dseed'], B, 4 * nsteps)
+    got = {}
+    for prec in ('f32', 'bf16'):
+        eng = E.Engine('G3', hp, B, T)
+        eng.set_precision(prec)
+        eng.load_weights(W.make_weights('G3', hp, rec['wseed']))
+        eng.set_adam(1e-4, 0.9, 0.999, 1e-8, 0)
+        loss = eng.g3_train_step(mel, f0, emb, lens, stack_draws(draws[:4]), no_adam=True)
+        got[prec] = dict(loss=float(loss), out=eng.debug_buffer('out', B, T).cpu(), mel=eng.debug_buffer('in.mel', B, T).cpu(),
+                         f0=eng.debug_buffer('in.f0', B, T).cpu(), grads={n: v.clone().cpu() for n, v in eng.grad_views().items()})
+        eng.adam_step()
+        losses = [float(loss)]
+        for it in range(1, nsteps):
+            losses.append(float(eng.g3_train_step(mel, f0, emb, lens, stack_draws(draws[4 * it:4 * it + 4]))))
+        got[prec]['losses'] = losses
+        eng.check()
+    b = got['bf16']
+    for it in range(nsteps):
+        assert abs(b['losses'][it] - rec['losses'][it]) <= 1e-3 * rec['losses'][it], (it, b['losses'])
+    assert rel(b['out'], np.load(os.path.join(GOLD, f'train_{tag}_out.npy'))) < 1e-2
+    assert np.array_equal(b['mel'].numpy(), np.load(os.path.join(GOLD, f'train_{tag}_xin_mel.npy')))        # bit-exact
+    assert torch.equal(b['f0'], got['f32']['f0'])
+    worst = max(rel(b['grads'][n], got['f32']['grads'][n]) for n in b['grads'])
+    assert 1e-4 < worst < 1e-1, worst        # really a different arithmetic, and within the stated bound
+
+
 @pytest.mark.parametrize('tag', ['b2_t128', 'b2_t192', 'b8_t128'])
 def test_fused_train_step_against_reference_fixture(E, tag):
     rec = json.load(open(os.path.join(GOLD, 'train_steps.json')))[tag]
