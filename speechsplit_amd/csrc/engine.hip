@@ -78,13 +78,13 @@ struct LstmBlk {
     float* dc[2] = {nullptr, nullptr};     // per chain: [2][B][H]
     unsigned* sync = nullptr;              // persistent kernels: group counters + abort word (one-off ops path)
     // persistent schedule: per-layer start state, contiguous so ONE memset per pass readies every layer's launch.
-    //   zf = [L][128 sync words] ++ [L][hf]      (forward)        zb = [L][128 sync words] ++ [L][gf]   (backward)
+    //   zf = [L][128 sync words] ++ [L][hf]      (forward)        zb = [L][128 sync words]   (backward)
     char *zf = nullptr, *zb = nullptr;
     long zf_bytes = 0, zb_bytes = 0, hf_bytes = 0, gf_bytes = 0;
     unsigned* sync_f(int l) const { return (unsigned*)zf + 128 * l; }
     unsigned* sync_b(int l) const { return (unsigned*)zb + 128 * l; }
-    float* hf_l(int l) const { return (float*)(zf + 512L * L + hf_bytes * l); }
-    float* gf_l(int l) const { return (float*)(zb + 512L * L + gf_bytes * l); }
+    void* hf_l(int l) const { return zf + 512L * L + hf_bytes * l; }
+    void* px = nullptr;                    // backward exchange tiles (shared by the layers, needs no initial state)
     float* dmid[2] = {nullptr, nullptr};   // gradient slabs of inner layer outputs [B,TP,2H]
     bool big() const { return H > 32; }
     int in_of(int l) const { return l == 0 ? In : 2 * H; }
@@ -305,12 +305,13 @@ long ss_engine::carve(int B, int T, bool assign) {
                 lb.dc[c] = (float*)take(2L * B * lb.H * 4);
             }
             lb.sync = (unsigned*)take(128 * 4);
-            lb.hf_bytes = 2L * 2 * B16 * lb.H * 4;
-            lb.gf_bytes = 2L * 2 * B16 * 4 * lb.H * 4;
+            lb.hf_bytes = lstm_seq_xbytes(B, lb.H, false);       // exchange buffers of the persistent kernels
+            lb.gf_bytes = lstm_seq_xbytes(B, lb.H, true);
             lb.zf_bytes = lb.L * (512L + lb.hf_bytes);
-            lb.zb_bytes = lb.L * (512L + lb.gf_bytes);
+            lb.zb_bytes = lb.L * 512L;
             lb.zf = (char*)take(lb.zf_bytes);
             lb.zb = (char*)take(lb.zb_bytes);
+            lb.px = take(lb.gf_bytes);
         }
         if (lb.L > 1) {
             lb.dmid[0] = slab((name + ".dmid0").c_str(), 2L * lb.H);
@@ -549,14 +550,16 @@ int make_chains(ss_engine* e, int B, hipStream_t s, Chain ch[2]) {
 // the fragment-major W_hh of the forward recurrence.  Independent of the activations, so the schedule runs it on a branch.
 int lstm_prep(ss_engine* e, LstmBlk& lb, hipStream_t s) {
     const int H = lb.H;
+    const bool persist = lb.big() && g_persist && lstm_seq_supported(e->curB, H);
     for (int l = 0; l < lb.L; ++l) {
         for (int dir = 0; dir < 2; ++dir) {
             const LstmDir& pd = lb.pd[l * 2 + dir];
             HIPCHK(add_vec(e->P + pd.bih, e->P + pd.bhh, lb.bsum + ((long)l * 2 + dir) * 4 * H, 4 * H, s));
         }
-        if (lb.big()) HIPCHK(lstm_pack_w(e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.wfrag[l], H, 0, s));
+        // fragment-major W_hh for the one-launch-per-step schedule (the persistent kernels read the parameters directly)
+        if (lb.big() && !persist) HIPCHK(lstm_pack_w(e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.wfrag[l], H, 0, s));
     }
-    if (lb.big()) HIPCHK(hipMemsetAsync(lb.zf, 0, lb.zf_bytes, s));     // h(-1) = 0 and the group counters of every layer
+    if (lb.big() && persist) HIPCHK(hipMemsetAsync(lb.zf, 0, lb.zf_bytes, s));     // h(-1) = 0 and the group counters of every layer
     return 0;
 }
 
@@ -600,7 +603,8 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
             }
         }
         if (persist) {   // start state zeroed by lstm_prep
-            HIPCHK(lstm_seq_fwd(lb.gates[l], lb.wfrag[l], lb.hf_l(l), lb.out[l], lb.csave[l], lb.sync_f(l), B, T, H, false, s));
+            HIPCHK(lstm_seq_fwd(lb.gates[l], e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.hf_l(l), lb.out[l], lb.csave[l],
+                                lb.sync_f(l), B, T, H, false, s));
             continue;
         }
         for (int st = 0; st < T; ++st)
@@ -730,7 +734,9 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
                 HIPCHK(hipMemsetAsync(lb.gf[c], 0, 2 * half * 4, ch[c].st));
             }
             // persistent: start state zeroed by backward_decoder
-            if (persist) HIPCHK(lstm_seq_bwd(dG, lb.wfrag[l], lb.gf_l(l), dcur, lb.csave[l], lb.sync_b(l), B, T, H, false, s));
+            if (persist)
+                HIPCHK(lstm_seq_bwd(dG, e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.px, dcur, lb.csave[l], lb.sync_b(l),
+                                    B, T, H, false, s));
             for (int st = 0; st < T && !persist; ++st)
                 for (int c = 0; c < nch; ++c) {
                     const long r0 = (long)ch[c].b0 * TP;
@@ -874,10 +880,14 @@ int backward_decoder(ss_engine* e, hipStream_t s) {
     const bool par = e->side2 && g_overlap;
     hipStream_t b2 = par ? e->side2 : s;
     if (par) CHK(fork_join(e, s, b2));
-    if (e->ld.big())
-        for (int l = 0; l < e->ld.L; ++l)
-            HIPCHK(lstm_pack_w(e->P + e->ld.pd[l * 2].whh, e->P + e->ld.pd[l * 2 + 1].whh, e->ld.wfrag[l], e->ld.H, 1, b2));
-    if (e->ld.big()) HIPCHK(hipMemsetAsync(e->ld.zb, 0, e->ld.zb_bytes, b2));   // da(T) = 0 and the group counters of every layer
+    if (e->ld.big()) {
+        if (g_persist && lstm_seq_supported(e->curB, e->ld.H)) {
+            HIPCHK(hipMemsetAsync(e->ld.zb, 0, e->ld.zb_bytes, b2));   // the group counters of every layer
+        } else {
+            for (int l = 0; l < e->ld.L; ++l)
+                HIPCHK(lstm_pack_w(e->P + e->ld.pd[l * 2].whh, e->P + e->ld.pd[l * 2 + 1].whh, e->ld.wfrag[l], e->ld.H, 1, b2));
+        }
+    }
     // head
     const long HD = 2L * e->ld.H;
     const float* h3 = e->ld.out[e->ld.L - 1];
@@ -1418,7 +1428,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "graph" && (value == 0 || value == 1)) g_graph = value;
     else if (k == "split" && (value == 0 || value == 1)) g_split = value;
     else if (k == "persist" && (value == 0 || value == 1)) g_persist = value;
-    else if (k == "seq_prio" && (value == 0 || value == 1)) g_seq_prio = value;
+    else if (k == "seq_prio" && value >= 0 && value < 256) g_seq_prio = value;
     else if (k == "side_prio" && (value == 0 || value == 1)) g_side_prio = value;
     else if (k == "gemm_bk" && (value == 16 || value == 32)) g_gemm_bk = value;
     else if (k == "gemm_want" && value >= 1) g_gemm_want = value;
@@ -1436,12 +1446,13 @@ int ss_op_lstm_fwd(float* gates, const float* whh_f, const float* whh_b, float* 
         const long half = 2L * (((B + 15) / 16) * 16) * H, wn = 2L * 4 * H * H;
         if (!scratch || scratch_floats < wn + 2 * half) return fail("ss_op_lstm_fwd: scratch too small");
         float* hf = scratch + wn;
-        HIPCHK(lstm_pack_w(whh_f, whh_b, scratch, H, 0, s));
-        HIPCHK(hipMemsetAsync(hf, 0, 2 * half * 4, s));
-        if (g_persist && lstm_seq_supported(B, H) && scratch_floats >= wn + 2 * half + 128) {
-            HIPCHK(lstm_seq_fwd(gates, scratch, hf, out, csave, (unsigned*)(hf + 2 * half), B, T, H, true, s));
+        if (g_persist && lstm_seq_supported(B, H) && wn * 4 >= lstm_seq_xbytes(B, H, false)) {
+            // exchange buffer in the (unused) packed-weight area, counters behind it
+            HIPCHK(lstm_seq_fwd(gates, whh_f, whh_b, scratch, out, csave, (unsigned*)hf, B, T, H, true, s));
             return 0;
         }
+        HIPCHK(lstm_pack_w(whh_f, whh_b, scratch, H, 0, s));
+        HIPCHK(hipMemsetAsync(hf, 0, 2 * half * 4, s));
         for (int st = 0; st < T; ++st)
             HIPCHK(lstm_step_fwd(gates, scratch, hf + (st & 1) * half, hf + ((st & 1) ^ 1) * half, out, csave, B, T, H, st, s));
     } else {
@@ -1458,12 +1469,13 @@ int ss_op_lstm_bwd(float* gates, const float* whh_f, const float* whh_b, const f
         if (!scratch || scratch_floats < wn + 2 * half + 2L * B * H) return fail("ss_op_lstm_bwd: scratch too small");
         float* gf = scratch + wn;
         float* dc = gf + 2 * half;
-        HIPCHK(lstm_pack_w(whh_f, whh_b, scratch, H, 1, s));
-        HIPCHK(hipMemsetAsync(gf, 0, 2 * half * 4, s));
-        if (g_persist && lstm_seq_supported(B, H)) {
-            HIPCHK(lstm_seq_bwd(gates, scratch, gf, d_out, csave, (unsigned*)dc, B, T, H, true, s));
+        const long xbytes = lstm_seq_xbytes(B, H, true);
+        if (g_persist && lstm_seq_supported(B, H) && scratch_floats * 4 >= xbytes + 512) {     // [exchange tiles][counters]
+            HIPCHK(lstm_seq_bwd(gates, whh_f, whh_b, scratch, d_out, csave, (unsigned*)((char*)scratch + xbytes), B, T, H, true, s));
             return 0;
         }
+        HIPCHK(lstm_pack_w(whh_f, whh_b, scratch, H, 1, s));
+        HIPCHK(hipMemsetAsync(gf, 0, 2 * half * 4, s));
         for (int st = 0; st < T; ++st)
             HIPCHK(lstm_step_bwd(gates, scratch, gf + (st & 1) * half, gf + ((st & 1) ^ 1) * half, d_out, csave, dc, B, T, H, st, s));
     } else {

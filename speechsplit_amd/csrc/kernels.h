@@ -100,12 +100,15 @@ hipError_t lstm_step_bwd(float* gates, const float* wfragT, const float* gf_cur,
                          const float* csave, float* dc, int B, int T, int H, int step, hipStream_t s);
 
 // ---------------------------------------------------------------- lstm_seq.hip  (persistent: one launch per layer)
-// Same operands as the step kernels; `sync` = 128 unsigned words (group arrival counters + abort word at [64]).  hf / gf
-// and sync must be zero at launch: zero_sync = false means the caller has already zeroed `sync` (and hf / gf) itself.
+// gates / out / csave / d_out as above; whh_* are the parameter tensors themselves ([4H][H] row-major): each workgroup
+// splits its slice into bf16 pieces once and keeps it in registers.  xbuf = lstm_seq_xbytes() bytes of exchange buffer
+// (h(t) or da(t) as bf16 pieces in MFMA fragment order), sync = 128 unsigned words (group arrival counters + abort word at
+// [64]); both must be all zero at launch: zero_state = false means the caller has zeroed them itself.
 bool lstm_seq_supported(int B, int H);
-hipError_t lstm_seq_fwd(float* gates, const float* wfrag, float* hf, float* out, float* csave, unsigned* sync, int B, int T,
-                        int H, bool zero_sync, hipStream_t s);
-hipError_t lstm_seq_bwd(float* gates, const float* wfragT, float* gf, const float* d_out, const float* csave, unsigned* sync,
-                        int B, int T, int H, bool zero_sync, hipStream_t s);
+long lstm_seq_xbytes(int B, int H, bool backward);
+hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, float* out, float* csave,
+                        unsigned* sync, int B, int T, int H, bool zero_state, hipStream_t s);
+hipError_t lstm_seq_bwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, const float* d_out,
+                        const float* csave, unsigned* sync, int B, int T, int H, bool zero_state, hipStream_t s);
 
 }  // namespace ss

@@ -49,100 +49,177 @@ __device__ __forceinline__ void store_sc1(float* p, float v) {
     __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// four 16-byte sc1 loads 1 KiB apart, waited for inside the statement (hipcc does not track asm loads)
-__device__ __forceinline__ void load4x4_sc1(const float* p, f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3) {
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// exact 3-way truncation split of fp32 into bf16 pieces x = h + m + l (see gemm_bf16x3.hip); returns the three 16-bit patterns
+__device__ __forceinline__ void split1(float x, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned b = __float_as_uint(x);
+    const float r = x - __uint_as_float(b & 0xFFFF0000u);
+    const unsigned c = __float_as_uint(r);
+    const float q = r - __uint_as_float(c & 0xFFFF0000u);
+    h = b >> 16;
+    m = c >> 16;
+    l = __float_as_uint(q) >> 16;
+}
+
+// eight fp32 values -> three bf16x8 MFMA fragments
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& fh, bf16x8& fm, bf16x8& fl) {
+    u32x4 H4, M4, L4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        split1(x[2 * i], h0, m0, l0);
+        split1(x[2 * i + 1], h1, m1, l1);
+        H4[i] = h0 | (h1 << 16);
+        M4[i] = m0 | (m1 << 16);
+        L4[i] = l0 | (l1 << 16);
+    }
+    fh = __builtin_bit_cast(bf16x8, H4);
+    fm = __builtin_bit_cast(bf16x8, M4);
+    fl = __builtin_bit_cast(bf16x8, L4);
+}
+
+// N 16-byte write-through-coherent loads 1 KiB apart from each base, issued and waited for inside ONE asm statement:
+// hipcc does not track asm loads, so the destination registers must not be visible to it before the data has landed.
+__device__ __forceinline__ void load2x3_sc1(const unsigned char* p0, const unsigned char* p1, const unsigned char* p2, u32x4 (&r)[2][3]) {
+    asm volatile(
+        "global_load_dwordx4 %0, %6, off sc1\n\t"
+        "global_load_dwordx4 %1, %7, off sc1\n\t"
+        "global_load_dwordx4 %2, %8, off sc1\n\t"
+        "global_load_dwordx4 %3, %6, off offset:1024 sc1\n\t"
+        "global_load_dwordx4 %4, %7, off offset:1024 sc1\n\t"
+        "global_load_dwordx4 %5, %8, off offset:1024 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[0][2]), "=&v"(r[1][0]), "=&v"(r[1][1]), "=&v"(r[1][2])
+        : "v"(p0), "v"(p1), "v"(p2)
+        : "memory");
+}
+__device__ __forceinline__ void load4_sc1(const unsigned char* p, u32x4 (&r)[4]) {
     asm volatile(
         "global_load_dwordx4 %0, %4, off sc1\n\t"
         "global_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
         "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\t"
         "global_load_dwordx4 %3, %4, off offset:3072 sc1\n\t"
         "s_waitcnt vmcnt(0)"
-        : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3)
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+        : "v"(p)
+        : "memory");
+}
+__device__ __forceinline__ void load2_sc1(const unsigned char* p, u32x4 (&r)[2]) {
+    asm volatile(
+        "global_load_dwordx4 %0, %2, off sc1\n\t"
+        "global_load_dwordx4 %1, %2, off offset:1024 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(r[0]), "=&v"(r[1])
         : "v"(p)
         : "memory");
 }
 
-// eight 16-byte sc1 loads (two bases, 1 KiB apart), one wait
-__device__ __forceinline__ void load8x4_sc1(const float* p, f32x4 (&a)[8]) {
-    const float* p2 = p + 1024;
-    asm volatile(
-        "global_load_dwordx4 %0, %8, off sc1\n\t"
-        "global_load_dwordx4 %1, %8, off offset:1024 sc1\n\t"
-        "global_load_dwordx4 %2, %8, off offset:2048 sc1\n\t"
-        "global_load_dwordx4 %3, %8, off offset:3072 sc1\n\t"
-        "global_load_dwordx4 %4, %9, off sc1\n\t"
-        "global_load_dwordx4 %5, %9, off offset:1024 sc1\n\t"
-        "global_load_dwordx4 %6, %9, off offset:2048 sc1\n\t"
-        "global_load_dwordx4 %7, %9, off offset:3072 sc1\n\t"
-        "s_waitcnt vmcnt(0)"
-        : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7])
-        : "v"(p), "v"(p2)
-        : "memory");
+// fp32-grade product on the bf16 pipe: acc += a . b with a = (ah, am, al), b = (bh, bm, bl); smallest terms first
+__device__ __forceinline__ f32x4 mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+    return acc;
 }
 
-// sixteen 16-byte sc1 loads (four bases), one wait
-__device__ __forceinline__ void load16x4_sc1(const float* p, f32x4 (&a)[16]) {
-    const float* p1 = p + 1024;
-    const float* p2 = p + 2048;
-    const float* p3 = p + 3072;
-    asm volatile(
-        "global_load_dwordx4 %0, %16, off sc1\n\t"
-        "global_load_dwordx4 %1, %16, off offset:1024 sc1\n\t"
-        "global_load_dwordx4 %2, %16, off offset:2048 sc1\n\t"
-        "global_load_dwordx4 %3, %16, off offset:3072 sc1\n\t"
-        "global_load_dwordx4 %4, %17, off sc1\n\t"
-        "global_load_dwordx4 %5, %17, off offset:1024 sc1\n\t"
-        "global_load_dwordx4 %6, %17, off offset:2048 sc1\n\t"
-        "global_load_dwordx4 %7, %17, off offset:3072 sc1\n\t"
-        "global_load_dwordx4 %8, %18, off sc1\n\t"
-        "global_load_dwordx4 %9, %18, off offset:1024 sc1\n\t"
-        "global_load_dwordx4 %10, %18, off offset:2048 sc1\n\t"
-        "global_load_dwordx4 %11, %18, off offset:3072 sc1\n\t"
-        "global_load_dwordx4 %12, %19, off sc1\n\t"
-        "global_load_dwordx4 %13, %19, off offset:1024 sc1\n\t"
-        "global_load_dwordx4 %14, %19, off offset:2048 sc1\n\t"
-        "global_load_dwordx4 %15, %19, off offset:3072 sc1\n\t"
-        "s_waitcnt vmcnt(0)"
-        : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7]),
-          "=&v"(a[8]), "=&v"(a[9]), "=&v"(a[10]), "=&v"(a[11]), "=&v"(a[12]), "=&v"(a[13]), "=&v"(a[14]), "=&v"(a[15])
-        : "v"(p), "v"(p1), "v"(p2), "v"(p3)
-        : "memory");
+// XCD the workgroup runs on.  The L2 is shared (and coherent) inside one XCD only: a group whose members all sit on the
+// same XCD can hand its payload over with ordinary stores (they reach the L2 through the write-through L1) instead of
+// pushing every tile through to memory with sc1.  Which case holds is DETECTED at run time, never assumed.
+__device__ __forceinline__ unsigned xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 15u;
 }
 
-// grid = ngroups * (H/16), block = 64*NW.   sync: [0..ngroups) arrival counters, [64] abort word (all zero on entry)
+// Round 0 of the group protocol (one lane): publish my XCD in the group's mask word, arrive, wait for the JT members,
+// read the mask back.  Returns 1 if the group is XCD-local, 0 if it spans XCDs, -1 on abort.  After this round the arrival
+// counter stands at JT, so step st waits for JT * (st + 1).
+__device__ __forceinline__ int group_locality(unsigned* cnt, unsigned* mask, unsigned* abortp, unsigned JT) {
+    const unsigned old = __hip_atomic_fetch_or(mask, 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(old) : "memory");          // the returned value forces the OR to have been performed before the arrival
+    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!wait_count(cnt, JT, abortp)) return -1;
+    const unsigned m = __hip_atomic_load(mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (m & (m - 1)) == 0 ? 1 : 0;
+}
+
+// A load whose only purpose is to bring the line (and its translation) close.  It is not waited for here, so `sink` must
+// stay live (untouched by the compiler) until the wave has passed an s_waitcnt vmcnt(0): see keep_live().
+__device__ __forceinline__ void touch(const float* p, unsigned& sink) {
+    asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void keep_live(unsigned (&w)[7]) {
+    asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]));
+}
+
+// Exchange buffer ("xbuf"): what one group hands from step to step, stored as the three bf16 pieces of every value in the
+// A-fragment order of v_mfma_f32_16x16x32_bf16, so a consumer wave's loads are whole 1 KiB fragments and nobody re-splits:
+//     [2 ping-pong][2 dir][nbt][3 pieces][KC k-chunks of 32][64 lanes][8 bf16]        lane = 16 * (k % 32 / 8) + (b % 16)
+// KC = H/32 for h(t) (forward), 4H/32 for da(t) (backward).  Byte offset helpers:
+__device__ __forceinline__ long xb_half(int nbt, int KC) { return 2L * nbt * 3 * KC * 1024; }
+__device__ __forceinline__ long xb_group(int dir, int nbt, int bt, int KC) { return ((long)dir * nbt + bt) * 3 * KC * 1024; }
+
+// one lane's bf16 pieces of value (b % 16 = bi, k) go to chunk k/32, lane 16*(k%32/8)+bi, element k%8.  Two lanes with
+// adjacent k (even, odd) combine their 16-bit pieces so that the even one stores whole dwords (write-through).
+__device__ __forceinline__ void xb_store(unsigned char* xb_plane0, long plane_stride, int k, int bi, float v) {
+    unsigned h, m, l;
+    split1(v, h, m, l);
+    const unsigned ph = __shfl_xor((int)h, 1), pm = __shfl_xor((int)m, 1), pl = __shfl_xor((int)l, 1);
+    if ((k & 1) == 0) {
+        unsigned char* q = xb_plane0 + (long)(k >> 5) * 1024 + ((((k & 31) >> 3) * 16 + bi) << 4) + ((k & 7) << 1);
+        __hip_atomic_store(reinterpret_cast<unsigned*>(q), h | (ph << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<unsigned*>(q + plane_stride), m | (pm << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<unsigned*>(q + 2 * plane_stride), l | (pl << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// grid = ngroups * (H/16), block = 64*NW.   sync: [0..ngroups) arrival counters, [64] abort word; xb and sync all zero on entry
 template <int H, int NW>
-__global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict__ gates, const float* __restrict__ wfrag,
-                                                               float* __restrict__ hf, float* __restrict__ out,
-                                                               float* __restrict__ csave, unsigned* __restrict__ sync,
-                                                               int B, int T, int nbt, int prio) {
-    constexpr int JT = H / 16, NC = H / 16, kw = H / NW, nchunk = kw / 16;
-    static_assert(nchunk == 4, "the persistent forward kernel is written for 4 chunks per wave");
+__global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict__ gates, const float* __restrict__ whh_f,
+                                                               const float* __restrict__ whh_b, unsigned char* __restrict__ xb,
+                                                               float* __restrict__ out, float* __restrict__ csave,
+                                                               unsigned* __restrict__ sync, int B, int T, int nbt, int prio) {
+    constexpr int JT = H / 16, KC = H / 32, KS = H / NW / 32;       // KS k-steps of 32 per wave
+    static_assert(KS == 2, "the persistent forward kernel is written for 64 reduction elements per wave");
     __shared__ float red[NW][4][16][16];
     __shared__ int s_ok;
-    if (prio) __builtin_amdgcn_s_setprio(3);      // the recurrence is the critical path; co-resident GEMM waves are filler
+    if (prio & 1) __builtin_amdgcn_s_setprio(3);  // the recurrence is the critical path; co-resident GEMM waves are filler
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ngroups = 2 * nbt;
     const int grp = blockIdx.x % ngroups, jt = blockIdx.x / ngroups;
     const int dir = grp / nbt, bt = grp % nbt;
     const int TP = T + 2 * HALO;
-    const int li = lane & 15;
+    const int li = lane & 15, lq = lane >> 4;
     unsigned* cnt = sync + grp;
     unsigned* abortp = sync + 64;
 
-    // this wave's slice of W_hh, resident in registers for the whole sequence
-    f32x4 bw[4][nchunk];
+    // this wave's slice of W_hh as bf16 pieces, resident in registers for the whole sequence:
+    // B fragment of gate g, k-step ks: lane holds W_hh[g*H + jt*16 + li][(w*KS + ks)*32 + 8*lq .. +7]
+    bf16x8 bw[4][KS][3];
+    {
+        const float* W = dir == 0 ? whh_f : whh_b;
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int c = 0; c < nchunk; ++c)
-            bw[g][c] = ld4(wfrag + ((((long)dir * JT + jt) * 4 + g) * NC + w * nchunk + c) * 256 + lane * 4);
+            for (int ks = 0; ks < KS; ++ks) {
+                const float* src = W + (long)(g * H + jt * 16 + li) * H + (w * KS + ks) * 32 + 8 * lq;
+                const f32x4 v0 = ld4(src), v1 = ld4(src + 4);
+                const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                split8(x, bw[g][ks][0], bw[g][ks][1], bw[g][ks][2]);
+            }
+    }
 
-    const long half = 2L * nbt * 16 * H;                                   // floats per ping-pong half
-    const float* hrd = hf + (((long)dir * nbt + bt) * NC + w * nchunk) * 256 + lane * 4;
+    const long half = xb_half(nbt, KC), plane = (long)KC * 1024;
+    const unsigned char* xrd = xb + xb_group(dir, nbt, bt, KC) + (long)(w * KS) * 1024 + lane * 16;
+    unsigned char* xwr = xb + xb_group(dir, nbt, bt, KC);
     const int bi = (tid >> 4) & 15, jj = tid & 15;
     const int b = bt * 16 + bi, j = jt * 16 + jj;
     const int bc = b < B ? b : B - 1;
-    float* hwr = hf + (((long)dir * nbt + bt) * NC + jt) * 256 + ((jj >> 2) * 16 + bi) * 4 + (jj & 3);
     const bool cell = tid < 256;
     float c_state = 0.f, h_val = 0.f;
     float sv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -169,20 +246,26 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
             if (tid == 0) s_ok = wait_count(cnt, (unsigned)(JT * st), abortp) ? 1 : 0;
             __syncthreads();
             if (!s_ok) return;                          // uniform: every thread reads the same LDS word
-            f32x4 a[nchunk];
-            load4x4_sc1(hrd + (st & 1) * half, a[0], a[1], a[2], a[3]);
+            const unsigned char* p0 = xrd + (st & 1) * half;
+            const unsigned char* p1 = p0 + plane;
+            const unsigned char* p2 = p1 + plane;
+            u32x4 r[KS][3];
+            load2x3_sc1(p0, p1, p2, r);
+            {
+                const bf16x8 a[3] = {__builtin_bit_cast(bf16x8, r[0][0]), __builtin_bit_cast(bf16x8, r[0][1]), __builtin_bit_cast(bf16x8, r[0][2])};
 #pragma unroll
-            for (int c = 0; c < nchunk; ++c)
+                for (int g = 0; g < 4; ++g) acc[g] = mfma6(a, bw[g][0], acc[g]);
+            }
+            {
+                const bf16x8 a[3] = {__builtin_bit_cast(bf16x8, r[1][0]), __builtin_bit_cast(bf16x8, r[1][1]), __builtin_bit_cast(bf16x8, r[1][2])};
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][q], bw[g][c][q], acc[g], 0, 0, 0);
+                for (int g = 0; g < 4; ++g) acc[g] = mfma6(a, bw[g][1], acc[g]);
+            }
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[w][g][(lane >> 4) * 4 + r][li] = acc[g][r];
+            for (int r = 0; r < 4; ++r) red[w][g][lq * 4 + r][li] = acc[g][r];
         __syncthreads();
         if (cell) {
             float pre[4];
@@ -200,7 +283,8 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
             sv[1] = gf;
             sv[2] = gg;
             sv[3] = go;
-            if (b < B) store_sc1(hwr + ((st + 1) & 1) * half, h_val);      // the hand-off payload: write-through, first
+            // the hand-off payload: write-through, first (rows past B carry garbage nobody stores downstream)
+            xb_store(xwr + ((st + 1) & 1) * half, plane, j, bi, h_val);
 #pragma unroll
             for (int g = 0; g < 4; ++g) xg[g] = xn[g];
         }
@@ -219,36 +303,78 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
     }
 }
 
-// Backward: dh(t) = d_out(t) + da(t+1) . W_hh ; da(t) handed to the group in fragment-major form.
+// One 16-byte write-through store per lane (whole 1 KiB tiles per wave: no partial sectors).  The value comes straight
+// out of an MFMA and hipcc inserts the MFMA -> VMEM-read wait states only for consumers it can see, so the asm carries
+// its own: 2 x s_nop 15 = 32 wait states, above the 18 the longest MFMA needs.
+__device__ __forceinline__ void store16_sc1(unsigned char* p, f32x4 v) {
+    asm volatile("s_nop 15\n\ts_nop 15\n\tglobal_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store16_plain(unsigned char* p, f32x4 v) {      // XCD-local groups only
+    asm volatile("s_nop 15\n\ts_nop 15\n\tglobal_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+
+// Backward: dh(t) = d_out(t) + da(t+1) . W_hh.  The reduction runs over all 4H gate units, which live 64 per workgroup,
+// so instead of every workgroup fetching all of da(t+1) (128 KB) each one multiplies ITS OWN 64 gate units -- straight
+// from LDS, as bf16 pieces -- into a partial dh for all H hidden units and hands 16x16 fp32 tiles to their owners:
+//     producer jt:  P_jt[b, :] = da(t+1)[b, units of jt] . W_hh[units of jt, :]        [16 x 64] . [64 x H]
+//     consumer jt': dh(t)[b, j in jt'] = d_out + sum over the JT producers of P_jt[b, j]
+// Exchange buffer: [2 ping-pong][2 dir][nbt][JT consumers][JT producers][64 lanes][4 f32] (a tile in MFMA accumulator order);
+// a workgroup writes H/16 KB and reads H/16 KB per step.  Every tile read was written one step earlier: no zeroing needed.
+// Tiles are stored write-through (sc1) unless round 0 found the whole group on one XCD (group_locality): then ordinary
+// stores are used, which is what makes this formulation pay (8 MB of sc1 traffic per step costs ~1.8 us of every step).
+// sync: [0..ngroups) arrival counters, [64] abort word, [65..65+ngroups) XCD masks.
 template <int H, int NW>
-__global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict__ gates, const float* __restrict__ wfragT,
-                                                               float* __restrict__ gf, const float* __restrict__ d_out,
-                                                               const float* __restrict__ csave,
+__global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict__ gates, const float* __restrict__ whh_f,
+                                                               const float* __restrict__ whh_b, unsigned char* __restrict__ xb,
+                                                               const float* __restrict__ d_out, const float* __restrict__ csave,
                                                                unsigned* __restrict__ sync, int B, int T, int nbt, int prio) {
-    constexpr int JT = H / 16, NC = 4 * H / 16, kw = 4 * H / NW, nchunk = kw / 16;
-    static_assert(nchunk == 16 || nchunk == 8, "the persistent backward kernel is written for 8 or 16 chunks per wave");
+    constexpr int JT = H / 16, CT = JT / NW, PW = JT / NW;      // column tiles (= consumers) / producers handled per wave
+    static_assert(CT == 4 || CT == 2, "the persistent backward kernel is written for 2 or 4 column tiles per wave");
     __shared__ float red[NW][16][16];
+    __shared__ __attribute__((aligned(16))) unsigned short a_lds[2][3][64][8];      // own da(t) as A fragments: [k-step][piece]
     __shared__ int s_ok;
-    if (prio) __builtin_amdgcn_s_setprio(3);
+    if (prio & 1) __builtin_amdgcn_s_setprio(3);
+    // timing experiments (wrong results unless noted): 1 no exchange loads, 2 no products, 4 no operand fetch, 8 no slab stores,
+    // 16 no waits, 32 ordinary tile stores even if the group spans XCDs, 64 operands from two hot rows, 128 no warm-up touches (correct)
+    const int diag = prio >> 1;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ngroups = 2 * nbt;
     const int grp = blockIdx.x % ngroups, jt = blockIdx.x / ngroups;
     const int dir = grp / nbt, bt = grp % nbt;
     const int TP = T + 2 * HALO;
-    const int li = lane & 15;
+    const int li = lane & 15, lq = lane >> 4;
     unsigned* cnt = sync + grp;
     unsigned* abortp = sync + 64;
+    if (tid == 0) s_ok = (diag & 16) ? 1 : group_locality(cnt, sync + 65 + grp, abortp, JT);
+    __syncthreads();
+    if (s_ok < 0) return;
+    const bool local = s_ok == 1 || (diag & 32);
+    __syncthreads();                                   // s_ok is reused by the step loop
 
-    f32x4 bw[nchunk];                                                   // W_hh^T slice of this wave
+    // B fragments, resident for the whole sequence.  Local reduction index k = gate*16 + unit (64 per workgroup): k-step ks,
+    // lane (li = column, lq) holds k = 32*ks + 8*lq + e  ->  W_hh[(2*ks + lq/2)*H + jt*16 + 8*(lq%2) + e][(w*CT + ct)*16 + li]
+    bf16x8 bw[2][CT][3];
+    {
+        const float* W = dir == 0 ? whh_f : whh_b;
 #pragma unroll
-    for (int c = 0; c < nchunk; ++c) bw[c] = ld4(wfragT + (((long)dir * JT + jt) * NC + w * nchunk + c) * 256 + lane * 4);
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const float* src = W + (long)((2 * ks + (lq >> 1)) * H + jt * 16 + 8 * (lq & 1)) * H + (w * CT + ct) * 16 + li;
+                float x[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = src[(long)i * H];
+                split8(x, bw[ks][ct][0], bw[ks][ct][1], bw[ks][ct][2]);
+            }
+    }
 
-    const long half = 2L * nbt * 16 * 4 * H;
-    const float* grd = gf + (((long)dir * nbt + bt) * NC + w * nchunk) * 256 + lane * 4;
+    const long half = 2L * nbt * JT * JT * 1024;
+    unsigned char* gb = xb + ((long)dir * nbt + bt) * JT * JT * 1024;
+    const unsigned char* xrd = gb + ((long)jt * JT + w * PW) * 1024 + lane * 16;        // tiles for me, from producers w*PW ..
+    unsigned char* xwr = gb + ((long)(w * CT) * JT + jt) * 1024 + lane * 16;            // my tiles for consumers w*CT ..
     const int bi = (tid >> 4) & 15, jj = tid & 15;
     const int b = bt * 16 + bi, j = jt * 16 + jj;
     const int bc = b < B ? b : B - 1;
-    float* gwr = gf + ((long)dir * nbt + bt) * NC * 256 + ((jj >> 2) * 16 + bi) * 4 + (jj & 3);
     const bool cell = tid < 256;
     float dc_rec = 0.f;
     float da[4] = {0.f, 0.f, 0.f, 0.f};
@@ -272,29 +398,31 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
     };
     Ops cur{}, nxt{};
     if (cell) cur = fetch(0);
+    unsigned warm[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};        // destinations of the warm-up loads in flight
 
     for (int st = 0; st < T; ++st) {
         const int tau = tau_of(st);
-        if (cell && st + 1 < T) nxt = fetch(st + 1);
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if (cell && st + 1 < T && !(diag & 4)) nxt = fetch((diag & 64) ? (st & 1) : st + 1);     // 64: always the same two rows (cache-hot)
+        f32x4 part = {0.f, 0.f, 0.f, 0.f};
         if (st > 0) {
-            if (tid == 0) s_ok = wait_count(cnt, (unsigned)(JT * st), abortp) ? 1 : 0;
+            if (tid == 0) s_ok = (diag & 16) ? 1 : (wait_count(cnt, (unsigned)(JT * (st + 1)), abortp) ? 1 : 0);
             __syncthreads();
             if (!s_ok) return;
-            const float* ap = grd + (st & 1) * half;
-            f32x4 a[nchunk];
-            if constexpr (nchunk == 16) load16x4_sc1(ap, a);
-            else load8x4_sc1(ap, a);
+            const unsigned char* p = xrd + (st & 1) * half;
+            u32x4 r[PW];
+            if (diag & 1) {
 #pragma unroll
-            for (int c = 0; c < nchunk; c += 2)
+                for (int i = 0; i < PW; ++i) r[i] = u32x4{0u, 0u, 0u, 0u};
+            } else if constexpr (PW == 4) load4_sc1(p, r);
+            else load2_sc1(p, r);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][q], bw[c][q], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c + 1][q], bw[c + 1][q], acc1, 0, 0, 0);
-                }
+            for (int i = 0; i < PW; ++i) {
+                const f32x4 v = __builtin_bit_cast(f32x4, r[i]);
+                part += v;
+            }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[w][(lane >> 4) * 4 + r][li] = acc0[r] + acc1[r];
+        for (int r = 0; r < 4; ++r) red[w][lq * 4 + r][li] = part[r];
         __syncthreads();
         if (cell) {
             float s = 0.f;
@@ -309,20 +437,57 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
             da[1] = dc * cur.cp * cur.gf * (1.0f - cur.gf);
             da[2] = dc * cur.gi * (1.0f - cur.gg * cur.gg);
             da[3] = d_o * cur.go * (1.0f - cur.go);
-            if (b < B) {
-                float* gw = gwr + ((st + 1) & 1) * half;
+            // own gate units as A fragments in LDS: k = g*16 + jj  ->  k-step g/2, lane 16*((g%2)*2 + jj/8) + bi, element jj%8
 #pragma unroll
-                for (int g = 0; g < 4; ++g) store_sc1(gw + (long)(g * JT + jt) * 256, da[g]);       // hand-off payload first
+            for (int g = 0; g < 4; ++g) {
+                unsigned h, m, l;
+                split1(da[g], h, m, l);
+                const int la = ((g & 1) * 2 + (jj >> 3)) * 16 + bi;
+                a_lds[g >> 1][0][la][jj & 7] = (unsigned short)h;
+                a_lds[g >> 1][1][la][jj & 7] = (unsigned short)m;
+                a_lds[g >> 1][2][la][jj & 7] = (unsigned short)l;
             }
             cur = nxt;
         }
+        __syncthreads();
+        if (st + 1 < T && !(diag & 2)) {                  // partial dh(t-1) of my gate units for every hidden unit
+            bf16x8 a[2][3];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) a[ks][pc] = *reinterpret_cast<const bf16x8*>(&a_lds[ks][pc][lane][0]);
+            unsigned char* q = xwr + ((st + 1) & 1) * half;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = mfma6(a[0], bw[0][ct], acc);
+                acc = mfma6(a[1], bw[1][ct], acc);
+                if (local) store16_plain(q + (long)ct * JT * 1024, acc);     // hand-off payload, group on one XCD: the shared L2 has it
+                else store16_sc1(q + (long)ct * JT * 1024, acc);              // group spans XCDs: write-through
+            }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        keep_live(warm);                                  // last step's warm-up loads have landed: their registers may go
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cell && b < B) {                                                   // slab copy for the weight-gradient GEMMs
+        if (cell && b < B && !(diag & 8)) {                                    // slab copy for the weight-gradient GEMMs
             float* gr = gates + ((long)b * TP + tau) * (8 * H) + dir * 4 * H + j;
 #pragma unroll
             for (int g = 0; g < 4; ++g) gr[g * H] = da[g];
+        }
+        if (NW == 8 && !cell && st + 2 < T && !(diag & 128)) {
+            // the idle half of the workgroup pulls the operands of step st+2 towards the L2 (they were written a whole
+            // forward pass ago): the cell threads' own fetch one step later then hits, instead of holding up vmcnt(0)
+            const int t2 = tau_of(st + 2), tp2 = dir == 0 ? t2 - 1 : t2 + 1;
+            const float* gr = gates + ((long)bc * TP + t2) * (8 * H) + dir * 4 * H + j;
+            const long oo = ((long)bc * TP + t2) * (2 * H) + dir * H + j;
+            touch(gr, warm[0]);
+            touch(gr + H, warm[1]);
+            touch(gr + 2 * H, warm[2]);
+            touch(gr + 3 * H, warm[3]);
+            touch(d_out + oo, warm[4]);
+            touch(csave + oo, warm[5]);
+            touch(csave + ((long)bc * TP + tp2) * (2 * H) + dir * H + j, warm[6]);
         }
     }
 }
@@ -331,28 +496,40 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
 
 bool lstm_seq_supported(int B, int H) {
     const int nbt = (B + 15) / 16;
-    return (H == 512 || H == 256) && 2 * nbt * (H / 16) <= 256 && 2 * nbt <= 64;
+    return (H == 512 || H == 256) && 2 * nbt * (H / 16) <= 256 && 2 * nbt <= 60;     // counters, abort word and masks share 128 words
 }
 
-hipError_t lstm_seq_fwd(float* gates, const float* wfrag, float* hf, float* out, float* csave, unsigned* sync, int B, int T,
-                        int H, bool zero_sync, hipStream_t s) {
+long lstm_seq_xbytes(int B, int H, bool backward) {
+    const long nbt = (B + 15) / 16, JT = H / 16;
+    return backward ? 2 * (2 * nbt * JT * JT * 1024) : 2 * (2 * nbt * 3 * (H / 32) * 1024);
+}
+
+hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, float* out, float* csave,
+                        unsigned* sync, int B, int T, int H, bool zero_state, hipStream_t s) {
     const int nbt = (B + 15) / 16;
     if (!lstm_seq_supported(B, H)) return hipErrorInvalidValue;
-    hipError_t e = zero_sync ? hipMemsetAsync(sync, 0, 128 * sizeof(unsigned), s) : hipSuccess;
-    if (e != hipSuccess) return e;
-    if (H == 512) hipLaunchKernelGGL((lstm_seq_fwd_kernel<512, 8>), dim3(2 * nbt * 32), dim3(512), 0, s, gates, wfrag, hf, out, csave, sync, B, T, nbt, g_seq_prio);
-    else          hipLaunchKernelGGL((lstm_seq_fwd_kernel<256, 4>), dim3(2 * nbt * 16), dim3(256), 0, s, gates, wfrag, hf, out, csave, sync, B, T, nbt, g_seq_prio);
+    if (zero_state) {
+        hipError_t e = hipMemsetAsync(sync, 0, 128 * sizeof(unsigned), s);
+        if (e == hipSuccess) e = hipMemsetAsync(xbuf, 0, lstm_seq_xbytes(B, H, false), s);
+        if (e != hipSuccess) return e;
+    }
+    unsigned char* xb = static_cast<unsigned char*>(xbuf);
+    if (H == 512) hipLaunchKernelGGL((lstm_seq_fwd_kernel<512, 8>), dim3(2 * nbt * 32), dim3(512), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, B, T, nbt, g_seq_prio);
+    else          hipLaunchKernelGGL((lstm_seq_fwd_kernel<256, 4>), dim3(2 * nbt * 16), dim3(256), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, B, T, nbt, g_seq_prio);
     return hipGetLastError();
 }
 
-hipError_t lstm_seq_bwd(float* gates, const float* wfragT, float* gf, const float* d_out, const float* csave, unsigned* sync,
-                        int B, int T, int H, bool zero_sync, hipStream_t s) {
+hipError_t lstm_seq_bwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, const float* d_out,
+                        const float* csave, unsigned* sync, int B, int T, int H, bool zero_state, hipStream_t s) {
     const int nbt = (B + 15) / 16;
     if (!lstm_seq_supported(B, H)) return hipErrorInvalidValue;
-    hipError_t e = zero_sync ? hipMemsetAsync(sync, 0, 128 * sizeof(unsigned), s) : hipSuccess;
-    if (e != hipSuccess) return e;
-    if (H == 512) hipLaunchKernelGGL((lstm_seq_bwd_kernel<512, 8>), dim3(2 * nbt * 32), dim3(512), 0, s, gates, wfragT, gf, d_out, csave, sync, B, T, nbt, g_seq_prio);
-    else          hipLaunchKernelGGL((lstm_seq_bwd_kernel<256, 8>), dim3(2 * nbt * 16), dim3(512), 0, s, gates, wfragT, gf, d_out, csave, sync, B, T, nbt, g_seq_prio);
+    if (zero_state) {
+        hipError_t e = hipMemsetAsync(sync, 0, 128 * sizeof(unsigned), s);      // the exchange tiles need no initial state
+        if (e != hipSuccess) return e;
+    }
+    unsigned char* xb = static_cast<unsigned char*>(xbuf);
+    if (H == 512) hipLaunchKernelGGL((lstm_seq_bwd_kernel<512, 8>), dim3(2 * nbt * 32), dim3(512), 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, B, T, nbt, g_seq_prio);
+    else          hipLaunchKernelGGL((lstm_seq_bwd_kernel<256, 8>), dim3(2 * nbt * 16), dim3(512), 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, B, T, nbt, g_seq_prio);
     return hipGetLastError();
 }
 

@@ -166,7 +166,11 @@ class _EngineModule(nn.Module):
         old = {n: p.data.detach().clone() for n, p in zip(self._names, self._plist)}
         eng = _engine.Engine(self.KIND, self.hparams_, max(need, self._max_batch or 0),
                              max(self.hparams_.max_len_pad, 192), device=dev)
-        eng.set_precision(getattr(self.hparams_, 'precision', 'f32'))   # optional extra hparam: 'f32' (reference arithmetic) | 'bf16'
+        try:                                           # optional extra hparam: 'f32' (reference arithmetic) | 'bf16'
+            precision = self.hparams_.precision
+        except (AttributeError, KeyError):
+            precision = 'f32'
+        eng.set_precision(precision)
         eng.load_weights(old)
         pv = eng.param_views()
         for n, p in zip(self._names, self._plist):

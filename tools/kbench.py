@@ -239,7 +239,7 @@ def bench_seq(B=64, T=128, H=512):
     xproj = (torch.randn(B, T, 2, 4 * H, generator=g) * 0.5).to(dev)
     whh = (torch.rand(2, 4 * H, H, generator=g) * 2 - 1).to(dev) / H ** 0.5
     d_out = (torch.randn(B, T, 2 * H, generator=g) * 0.1).to(dev)
-    scratch = torch.zeros(8 * H * H + 16 * B * H + 2 * B * H + 1024, device=dev)
+    scratch = torch.zeros(max(8 * H * H + 16 * B * H + 2 * B * H + 1024, ((B + 15) // 16) * (H // 16) ** 2 * 1024 + 256), device=dev)
     gates = torch.zeros(B, T + 4, 8 * H, device=dev)
     gates[:, 2:2 + T] = xproj.reshape(B, T, 8 * H)
     xp_keep = gates.clone()
@@ -267,11 +267,20 @@ def bench_seq(B=64, T=128, H=512):
                 gates.copy_(ga_keep)
                 _capi.check(lib.ss_op_lstm_bwd(P(gates), P(whh[0]), P(whh[1]), P(dpad), P(cs), P(scratch), scratch.numel(), B, T, H, S()))
             tb = timeit(bwd)[0] - timeit(copy_only)[0]
+            bwd()
             res[ps] = (o_keep, gates.clone())
             say(f'lstm layer H{H} B{B} T{T} persist{ps}: fwd {tf:.0f} us ({tf / T:.2f}/step)  bwd {tb:.0f} us ({tb / T:.2f}/step)')
     say(f'   persist vs step kernels: out max diff {float((res[0][0] - res[1][0]).abs().max()):.2e}, '
         f'dgates max diff {float((res[0][1] - res[1][1]).abs().max()):.2e}')
     tune('persist', 1)
+    # where a backward step's time goes: seq_prio bit 0 = s_setprio, bits 1.. = ablations (wrong results)
+    for dg, what in [(0, 'full'), (1, 'no exchange loads'), (2, 'no products / tile stores'), (4, 'no operand fetch'), (8, 'no slab stores'),
+                     (16, 'no wait'), (31, 'nothing but the barriers + cell math'), (32, 'tile stores without sc1'), (64, 'operand fetch from two hot rows'), (128, 'no warm-up touches (correct results)'), (96, 'plain tile stores + hot operand rows'), (36, 'plain tile stores + no operand fetch'),
+                     (44, 'plain tile stores, no fetch, no slab stores')]:
+        tune('seq_prio', 1 | (dg << 1))
+        tb = timeit(bwd)[0] - timeit(copy_only)[0]
+        say(f'   bwd ablation [{what:40s}]: {tb / T:.2f} us/step')
+    tune('seq_prio', 1)
 
 
 if __name__ == '__main__':
