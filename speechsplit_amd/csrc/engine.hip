@@ -1428,7 +1428,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "graph" && (value == 0 || value == 1)) g_graph = value;
     else if (k == "split" && (value == 0 || value == 1)) g_split = value;
     else if (k == "persist" && (value == 0 || value == 1)) g_persist = value;
-    else if (k == "seq_prio" && value >= 0 && value < 256) g_seq_prio = value;
+    else if (k == "seq_prio" && value >= 0 && value < 1024) g_seq_prio = value;
     else if (k == "side_prio" && (value == 0 || value == 1)) g_side_prio = value;
     else if (k == "gemm_bk" && (value == 16 || value == 32)) g_gemm_bk = value;
     else if (k == "gemm_want" && value >= 1) g_gemm_want = value;

@@ -166,19 +166,26 @@ __device__ __forceinline__ long xb_group(int dir, int nbt, int bt, int KC) { ret
 
 // one lane's bf16 pieces of value (b % 16 = bi, k) go to chunk k/32, lane 16*(k%32/8)+bi, element k%8.  Two lanes with
 // adjacent k (even, odd) combine their 16-bit pieces so that the even one stores whole dwords (write-through).
-__device__ __forceinline__ void xb_store(unsigned char* xb_plane0, long plane_stride, int k, int bi, float v) {
+__device__ __forceinline__ void xb_store(unsigned char* xb_plane0, long plane_stride, int k, int bi, float v, bool local) {
     unsigned h, m, l;
     split1(v, h, m, l);
     const unsigned ph = __shfl_xor((int)h, 1), pm = __shfl_xor((int)m, 1), pl = __shfl_xor((int)l, 1);
     if ((k & 1) == 0) {
         unsigned char* q = xb_plane0 + (long)(k >> 5) * 1024 + ((((k & 31) >> 3) * 16 + bi) << 4) + ((k & 7) << 1);
+        if (local) {                                   // group on one XCD: ordinary stores reach the shared L2
+            *reinterpret_cast<unsigned*>(q) = h | (ph << 16);
+            *reinterpret_cast<unsigned*>(q + plane_stride) = m | (pm << 16);
+            *reinterpret_cast<unsigned*>(q + 2 * plane_stride) = l | (pl << 16);
+            return;
+        }
         __hip_atomic_store(reinterpret_cast<unsigned*>(q), h | (ph << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(reinterpret_cast<unsigned*>(q + plane_stride), m | (pm << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(reinterpret_cast<unsigned*>(q + 2 * plane_stride), l | (pl << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-// grid = ngroups * (H/16), block = 64*NW.   sync: [0..ngroups) arrival counters, [64] abort word; xb and sync all zero on entry
+// grid = ngroups * (H/16), block = 64*NW.   sync: [0..ngroups) arrival counters, [64] abort word,
+// [65..65+ngroups) XCD masks; xb and sync all zero on entry
 template <int H, int NW>
 __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict__ gates, const float* __restrict__ whh_f,
                                                                const float* __restrict__ whh_b, unsigned char* __restrict__ xb,
@@ -197,6 +204,12 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
     const int li = lane & 15, lq = lane >> 4;
     unsigned* cnt = sync + grp;
     unsigned* abortp = sync + 64;
+    const int diag = prio >> 1;                            // 32: ordinary stores regardless (timing), 128: no warm-up touches
+    if (tid == 0) s_ok = group_locality(cnt, sync + 65 + grp, abortp, JT);
+    __syncthreads();
+    if (s_ok < 0) return;
+    const bool local = s_ok == 1 || (diag & 32);
+    __syncthreads();                                       // s_ok is reused by the step loop
 
     // this wave's slice of W_hh as bf16 pieces, resident in registers for the whole sequence:
     // B fragment of gate g, k-step ks: lane holds W_hh[g*H + jt*16 + li][(w*KS + ks)*32 + 8*lq .. +7]
@@ -232,6 +245,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
         for (int g = 0; g < 4; ++g) xg[g] = g0[g * H];
     }
 
+    unsigned warm[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};        // destinations of the warm-up loads in flight
     for (int st = 0; st < T; ++st) {
         const int tau = tau_of(st);
         if (cell && st + 1 < T) {                       // next step's input projection, requested before the wait
@@ -243,7 +257,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (st > 0) {                                   // h(-1) = 0: nothing to multiply at the first step
-            if (tid == 0) s_ok = wait_count(cnt, (unsigned)(JT * st), abortp) ? 1 : 0;
+            if (tid == 0) s_ok = wait_count(cnt, (unsigned)(JT * (st + 1)), abortp) ? 1 : 0;
             __syncthreads();
             if (!s_ok) return;                          // uniform: every thread reads the same LDS word
             const unsigned char* p0 = xrd + (st & 1) * half;
@@ -284,11 +298,12 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
             sv[2] = gg;
             sv[3] = go;
             // the hand-off payload: write-through, first (rows past B carry garbage nobody stores downstream)
-            xb_store(xwr + ((st + 1) & 1) * half, plane, j, bi, h_val);
+            xb_store(xwr + ((st + 1) & 1) * half, plane, j, bi, h_val, local);
 #pragma unroll
             for (int g = 0; g < 4; ++g) xg[g] = xn[g];
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains before the barrier
+        keep_live(warm);
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // slab copies (consumed only by later kernels) go out after the group has been signalled
@@ -299,6 +314,13 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
             const long o = ((long)b * TP + tau) * (2 * H) + dir * H + j;
             csave[o] = c_state;
             out[o] = h_val;
+        }
+        if (NW == 8 && !cell && st + 2 < T && !(diag & 128)) {     // the idle half pulls step st+2's input projection towards the L2
+            const float* gn = grow_of(tau_of(st + 2));
+            touch(gn, warm[0]);
+            touch(gn + H, warm[1]);
+            touch(gn + 2 * H, warm[2]);
+            touch(gn + 3 * H, warm[3]);
         }
     }
 }
