@@ -1,23 +1,36 @@
 // Persistent form of the decoder BLSTM recurrence: ONE launch walks all T time steps of a layer (both directions).
 //
-// Why: with one launch per step (lstm_step.hip) a step costs ~7-8 us of which only ~1.7 us is MFMA work; the rest is
+// Why: with one launch per step (lstm_step.hip) a step costs ~7-8 us of which ~1.7 us is fp32 MFMA work; the rest is
 // the launch/drain floor (~3.5 us) and re-streaming the workgroup's 128 KB slice of W_hh from L2 every step.  Here
-// each workgroup keeps its W_hh slice in REGISTERS for the whole sequence (64 VGPRs per lane at 8 waves) and only
-// h(t-1) / da(t+1) of its 16 utterances crosses workgroups per step.
+// each workgroup keeps its W_hh slice in REGISTERS for the whole sequence -- as the three bf16 pieces of the exact split
+// x = h + m + l (gemm_bf16x3.hip), 96 VGPRs per lane -- and multiplies on the bf16 pipe with six
+// v_mfma_f32_16x16x32_bf16 per product (fp32-grade result, 0.75 us instead of 1.9 us of matrix-pipe time per step).
 //
-// Dependency structure: the workgroup (dir, btile, jtile) needs, at step t, the h(t-1) tiles of the JT workgroups
-// with the same (dir, btile) -- nothing else.  So there is no grid-wide barrier, only 2*ceil(B/16) independent
-// groups of JT = H/16 workgroups, each with one monotonic arrival counter.  The 1-D block id is laid out so that a
-// group is blockIdx % ngroups: with B = 64 that is 8 groups = the 8 XCDs under the observed round-robin placement,
-// so a group's traffic stays inside one XCD's L2.  That placement is a speed assumption only: the hand-off follows
-// the placement-independent protocol of the CDNA guide (Guideline 16 / MI355X_MICROARCH "Valid forms", counter row):
-//   producer: payload stored write-through (sc1) -> every storing wave s_waitcnt vmcnt(0) -> workgroup barrier ->
-//             one lane adds 1 to the group counter (relaxed, agent scope)
-//   consumer: one lane polls the counter with sc1 loads -> workgroup barrier -> every payload load is an sc1 load
+// Forward: the workgroup (dir, btile, jtile) needs, at step t, h(t-1) of its 16 utterances from the JT workgroups with
+// the same (dir, btile) -- nothing else.  Producers store h as bf16 pieces in A-fragment order, so consumers load whole
+// fragments and nobody re-splits.  Backward: every workgroup multiplies its OWN 64 gate units of da(t+1) (straight from
+// LDS) into a partial dh for all H hidden units and hands 16x16 fp32 tiles to their owners, who add up JT tiles
+// (see lstm_seq_bwd_kernel).  Either way there is no grid-wide barrier, only 2*ceil(B/16) independent groups of
+// JT = H/16 workgroups, each with one monotonic arrival counter.  The 1-D block id is laid out so that a group is
+// blockIdx % ngroups: with B = 64 that is 8 groups = the 8 XCDs under the observed round-robin placement.
+//
+// Hand-off protocol (CDNA guide Guideline 16 / MI355X_MICROARCH "Valid forms", counter row), placement-independent:
+//   producer: payload stores -> every storing wave s_waitcnt vmcnt(0) -> workgroup barrier -> one lane adds 1 to the
+//             group counter (relaxed, agent scope)
+//   consumer: one lane polls the counter -> workgroup barrier -> every payload load is an sc1 load
+// Payload stores are write-through (sc1) in general.  Round 0 of every launch has each member publish the XCD it runs on
+// (s_getreg XCC_ID) in a group mask: if the whole group shares one XCD -- hence one L2 -- ordinary stores suffice, and
+// that is worth 1.8 us per backward step (8 MB of sc1 traffic per step otherwise).  Measured, never assumed: a group that
+// spans XCDs (B = 16, 48, ...) takes the sc1 path and stays correct (tools/seq_debug.py).
 //
 // Residency: the grid (ngroups * JT <= 256 workgroups of 512 threads) fits the 256 CUs at one workgroup per CU; other
 // kernels sharing the chip can only delay it (they never wait on it).  Every spin is bounded: on expiry the
 // workgroup raises a global abort word that all pollers watch, and the kernel drains (ss_check() reports it).
+//
+// Inline-asm rules learnt the hard way (both were silent corruptions): (1) a register written by an asm load that is not
+// waited for inside the same statement must be kept live until after an s_waitcnt (keep_live), or hipcc re-uses it while
+// the load is in flight; (2) an asm instruction that reads an MFMA result needs its own wait states (store16_*), hipcc
+// inserts them only for consumers it can see.
 #include "common.h"
 #include "kernels.h"
 

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Locate where the persistent backward recurrence differs from the per-step kernels (small case)."""
+"""Persistent recurrence kernels vs. the per-step kernels on one layer: seq_debug.py <B> [ablation bits].
+B = 64 gives XCD-local groups (ordinary payload stores), B = 16 / 48 groups that span XCDs (sc1 path)."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
