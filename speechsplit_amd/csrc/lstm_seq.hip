@@ -27,10 +27,11 @@
 // kernels sharing the chip can only delay it (they never wait on it).  Every spin is bounded: on expiry the
 // workgroup raises a global abort word that all pollers watch, and the kernel drains (ss_check() reports it).
 //
-// Inline-asm rules learnt the hard way (both were silent corruptions): (1) a register written by an asm load that is not
-// waited for inside the same statement must be kept live until after an s_waitcnt (keep_live), or hipcc re-uses it while
-// the load is in flight; (2) an asm instruction that reads an MFMA result needs its own wait states (store16_*), hipcc
-// inserts them only for consumers it can see.
+// Inline-asm rules learnt the hard way (both were silent corruptions): (1) an asm load must be waited for inside the same
+// statement, or hipcc re-uses / copies its destination register while the load is in flight; (2) an asm instruction that
+// reads an MFMA result needs its own wait states (store16_*), hipcc inserts them only for consumers it can see.
+// Measured and dropped: "warm-up" loads of the next steps' operands by the idle waves (-0.4 us/step on one layer in
+// isolation with hot operands, +0.1 ms on the whole training step).
 #include "common.h"
 #include "kernels.h"
 
@@ -161,15 +162,6 @@ __device__ __forceinline__ int group_locality(unsigned* cnt, unsigned* mask, uns
     return (m & (m - 1)) == 0 ? 1 : 0;
 }
 
-// A load whose only purpose is to bring the line (and its translation) close.  It is not waited for here, so `sink` must
-// stay live (untouched by the compiler) until the wave has passed an s_waitcnt vmcnt(0): see keep_live().
-__device__ __forceinline__ void touch(const float* p, unsigned& sink) {
-    asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(p) : "memory");
-}
-__device__ __forceinline__ void keep_live(unsigned (&w)[7]) {
-    asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]));
-}
-
 // Exchange buffer ("xbuf"): what one group hands from step to step, stored as the three bf16 pieces of every value in the
 // A-fragment order of v_mfma_f32_16x16x32_bf16, so a consumer wave's loads are whole 1 KiB fragments and nobody re-splits:
 //     [2 ping-pong][2 dir][nbt][3 pieces][KC k-chunks of 32][64 lanes][8 bf16]        lane = 16 * (k % 32 / 8) + (b % 16)
@@ -217,7 +209,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
     const int li = lane & 15, lq = lane >> 4;
     unsigned* cnt = sync + grp;
     unsigned* abortp = sync + 64;
-    const int diag = prio >> 1;                            // 32: ordinary stores regardless (timing), 128: no warm-up touches
+    const int diag = prio >> 1;                            // 32: ordinary stores regardless (timing experiment)
     if (tid == 0) s_ok = group_locality(cnt, sync + 65 + grp, abortp, JT);
     __syncthreads();
     if (s_ok < 0) return;
@@ -258,7 +250,6 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
         for (int g = 0; g < 4; ++g) xg[g] = g0[g * H];
     }
 
-    unsigned warm[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};        // destinations of the warm-up loads in flight
     for (int st = 0; st < T; ++st) {
         const int tau = tau_of(st);
         if (cell && st + 1 < T) {                       // next step's input projection, requested before the wait
@@ -316,7 +307,6 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
             for (int g = 0; g < 4; ++g) xg[g] = xn[g];
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains before the barrier
-        keep_live(warm);
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // slab copies (consumed only by later kernels) go out after the group has been signalled
@@ -327,13 +317,6 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
             const long o = ((long)b * TP + tau) * (2 * H) + dir * H + j;
             csave[o] = c_state;
             out[o] = h_val;
-        }
-        if (NW == 8 && !cell && st + 2 < T && !(diag & 128)) {     // the idle half pulls step st+2's input projection towards the L2
-            const float* gn = grow_of(tau_of(st + 2));
-            touch(gn, warm[0]);
-            touch(gn + H, warm[1]);
-            touch(gn + 2 * H, warm[2]);
-            touch(gn + 3 * H, warm[3]);
         }
     }
 }
@@ -370,7 +353,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
     __shared__ int s_ok;
     if (prio & 1) __builtin_amdgcn_s_setprio(3);
     // timing experiments (wrong results unless noted): 1 no exchange loads, 2 no products, 4 no operand fetch, 8 no slab stores,
-    // 16 no waits, 32 ordinary tile stores even if the group spans XCDs, 64 operands from two hot rows, 128 no warm-up touches (correct)
+    // 16 no waits, 32 ordinary tile stores even if the group spans XCDs, 64 operands from two hot rows
     const int diag = prio >> 1;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ngroups = 2 * nbt;
@@ -433,7 +416,6 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
     };
     Ops cur{}, nxt{};
     if (cell) cur = fetch(0);
-    unsigned warm[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};        // destinations of the warm-up loads in flight
 
     for (int st = 0; st < T; ++st) {
         const int tau = tau_of(st);
@@ -502,27 +484,12 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        keep_live(warm);                                  // last step's warm-up loads have landed: their registers may go
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cell && b < B && !(diag & 8)) {                                    // slab copy for the weight-gradient GEMMs
             float* gr = gates + ((long)b * TP + tau) * (8 * H) + dir * 4 * H + j;
 #pragma unroll
             for (int g = 0; g < 4; ++g) gr[g * H] = da[g];
-        }
-        if (NW == 8 && !cell && st + 2 < T && !(diag & 128)) {
-            // the idle half of the workgroup pulls the operands of step st+2 towards the L2 (they were written a whole
-            // forward pass ago): the cell threads' own fetch one step later then hits, instead of holding up vmcnt(0)
-            const int t2 = tau_of(st + 2), tp2 = dir == 0 ? t2 - 1 : t2 + 1;
-            const float* gr = gates + ((long)bc * TP + t2) * (8 * H) + dir * 4 * H + j;
-            const long oo = ((long)bc * TP + t2) * (2 * H) + dir * H + j;
-            touch(gr, warm[0]);
-            touch(gr + H, warm[1]);
-            touch(gr + 2 * H, warm[2]);
-            touch(gr + 3 * H, warm[3]);
-            touch(d_out + oo, warm[4]);
-            touch(csave + oo, warm[5]);
-            touch(csave + ((long)bc * TP + tp2) * (2 * H) + dir * H + j, warm[6]);
         }
     }
 }
