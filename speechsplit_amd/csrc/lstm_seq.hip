@@ -249,6 +249,19 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
 #pragma unroll
         for (int g = 0; g < 4; ++g) xg[g] = g0[g * H];
     }
+    float sv_p[4] = {0.f, 0.f, 0.f, 0.f}, c_p = 0.f, h_p = 0.f;
+    int tau_p = -1;
+    auto flush_slabs = [&]() {
+        if (cell && b < B && tau_p >= 0) {
+            float* gr = grow_of(tau_p);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gr[g * H] = sv_p[g];
+            const long o = ((long)b * TP + tau_p) * (2 * H) + dir * H + j;
+            csave[o] = c_p;
+            out[o] = h_p;
+        }
+        tau_p = -1;
+    };
 
     for (int st = 0; st < T; ++st) {
         const int tau = tau_of(st);
@@ -269,6 +282,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
             const unsigned char* p2 = p1 + plane;
             u32x4 r[KS][3];
             load2x3_sc1(p0, p1, p2, r);
+            flush_slabs();                              // last step's slab copies: their acks hide behind the products below
             {
                 const bf16x8 a[3] = {__builtin_bit_cast(bf16x8, r[0][0]), __builtin_bit_cast(bf16x8, r[0][1]), __builtin_bit_cast(bf16x8, r[0][2])};
 #pragma unroll
@@ -309,16 +323,15 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains before the barrier
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // slab copies (consumed only by later kernels) go out after the group has been signalled
-        if (cell && b < B) {
-            float* gr = grow_of(tau);
+        // slab copies (consumed only by later kernels) are held back until the next step's fragments have arrived: issued
+        // right here, their acknowledgements would sit in front of those loads' s_waitcnt vmcnt(0)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) gr[g * H] = sv[g];
-            const long o = ((long)b * TP + tau) * (2 * H) + dir * H + j;
-            csave[o] = c_state;
-            out[o] = h_val;
-        }
+        for (int g = 0; g < 4; ++g) sv_p[g] = sv[g];
+        c_p = c_state;
+        h_p = h_val;
+        tau_p = tau;
     }
+    flush_slabs();
 }
 
 // One 16-byte write-through store per lane (whole 1 KiB tiles per wave: no partial sectors).  The value comes straight
@@ -416,6 +429,16 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
     };
     Ops cur{}, nxt{};
     if (cell) cur = fetch(0);
+    float da_p[4] = {0.f, 0.f, 0.f, 0.f};
+    int tau_p = -1;
+    auto flush_slab = [&]() {
+        if (cell && b < B && tau_p >= 0 && !(diag & 8)) {
+            float* gr = gates + ((long)b * TP + tau_p) * (8 * H) + dir * 4 * H + j;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gr[g * H] = da_p[g];
+        }
+        tau_p = -1;
+    };
 
     for (int st = 0; st < T; ++st) {
         const int tau = tau_of(st);
@@ -432,6 +455,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
                 for (int i = 0; i < PW; ++i) r[i] = u32x4{0u, 0u, 0u, 0u};
             } else if constexpr (PW == 4) load4_sc1(p, r);
             else load2_sc1(p, r);
+            flush_slab();                               // last step's slab copy: its acks hide behind the cell math and products
 #pragma unroll
             for (int i = 0; i < PW; ++i) {
                 const f32x4 v = __builtin_bit_cast(f32x4, r[i]);
@@ -486,12 +510,12 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cell && b < B && !(diag & 8)) {                                    // slab copy for the weight-gradient GEMMs
-            float* gr = gates + ((long)b * TP + tau) * (8 * H) + dir * 4 * H + j;
+        // the slab copy for the weight-gradient GEMMs is held back until the next step's tiles have arrived (see forward)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) gr[g * H] = da[g];
-        }
+        for (int g = 0; g < 4; ++g) da_p[g] = da[g];
+        tau_p = tau;
     }
+    flush_slab();
 }
 
 }  // namespace
