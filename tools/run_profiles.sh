@@ -19,4 +19,5 @@ timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv 
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 tools/gemm_pmc.py 1024 > $O/pmc_w.log 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_sq -- python3 tools/gemm_pmc.py 1024 > $O/pmc_s.log 2>&1
 python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/gemm_pmc
+timeout -k 10 120 python3 tools/kbench.py seq 2>&1 | grep -v amdgpu.ids > $O/kbench_seq_ablation.txt
 rm -rf $O/prof/*/*.db
