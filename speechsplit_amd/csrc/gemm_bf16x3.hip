@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
                     for (int j = 0; j < 4; ++j)
                         if (kpos + j < kend) s[j] = p[j];
             }
-            p += BK;
+            if (!(d.diag & 4)) p += BK;             // diag 4 (timing only): every k-tile re-reads tile 0 -> no memory latency
             if (op.seglen) {                          // seglen >= BK (checked by the launcher): at most one wrap per tile
                 w += BK;
                 const bool wrap = w >= op.seglen;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
                 for (int j = 0; j < 4; ++j)
                     if (kpos + j < kend) s[j] = p[(long)j * op.ld];
             }
-            p += (long)BK * op.ld;
+            if (!(d.diag & 4)) p += (long)BK * op.ld;
         }
         return s;
     };
