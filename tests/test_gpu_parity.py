@@ -395,6 +395,68 @@ def test_full_size_data_parallel_linearity_and_descent(E):
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
 
 
+def _shard_linearity(E, kind, B, T, len_lo, parts, wseed=0, bseed=11, descent=True):
+    """Gradient of a B-utterance batch == mean of the gradients of its `parts` equal shards given the matching draw slices,
+    and a few Adam steps on the fixed batch reduce the loss.  The shards may run a different recurrence schedule than the
+    whole batch (persistent kernels, XCD-local or not, or one launch per time step), which this cross-checks at full size."""
+    from speechsplit_amd import dist as D
+    hp = W.default_hparams(max_len_pad=T)
+    eng = E.Engine(kind, hp, B, T)
+    eng.load_weights(W.make_weights(kind, hp, wseed))
+    mel, f0, emb, lens = synth_batch(bseed, B, T, len_lo)
+    ncalls = 4 if kind == 'G3' else 3
+    sc, ls = stack_draws(draws_for(bseed + 1, B, ncalls))
+    sc, ls = torch.from_numpy(sc), torch.from_numpy(ls)
+    if kind == 'G6':
+        qidx = torch.from_numpy(interp_np.quantize_f0(f0[:, :, 0].numpy()))
+        onehot = torch.nn.functional.one_hot(qidx, 257).float()
+
+    def step(lo, hi, draws, **kw):
+        if kind == 'G3':
+            return eng.g3_train_step(mel[lo:hi], f0[lo:hi], emb[lo:hi], lens[lo:hi], draws, **kw)
+        return eng.g6_train_step(mel[lo:hi], onehot[lo:hi], qidx[lo:hi], draws, **kw)
+
+    l_full = float(step(0, B, (sc, ls), no_adam=True))
+    g_full = eng.grads.clone()
+    eng.check()
+    acc = torch.zeros_like(g_full)
+    l_sh = 0.0
+    for r in range(parts):
+        lo, hi = D.shard_range(B, r, parts)
+        l_sh += float(step(lo, hi, D.shard_draws(sc, ls, B, r, parts), no_adam=True)) / parts
+        acc += eng.grads / parts
+    eng.check()
+    assert abs(l_sh - l_full) <= 1e-5 * abs(l_full), (l_sh, l_full)
+    gv_f, gv_s = eng.views(g_full), eng.views(acc)
+    for n in gv_f:
+        assert rel(gv_s[n], gv_f[n]) < TOL, n
+    if descent:
+        eng.adam_m.zero_()
+        eng.adam_v.zero_()
+        eng.set_adam(1e-3, 0.9, 0.999, 1e-8, 0)
+        losses = [float(step(0, B, (sc, ls))) for _ in range(5)]
+        assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_full_size_generator6_config(E):
+    """BASELINE config 3's per-GPU shape: Generator_6 (Encoder_6 pitch path, CE loss), 32 utterances x 192 frames.
+    The whole batch runs the H=256 persistent recurrences with 4 groups (spanning XCDs: write-through hand-off), the two
+    16-utterance shards with 2 groups."""
+    _shard_linearity(E, 'G6', 32, 192, 96, 2)
+
+
+def test_full_size_192_frames(E):
+    """BASELINE config 4's frame count: Generator_3, 64 utterances x 192 frames, lengths 96..192 (padded, as the
+    reference does); shards of 32 run the persistent recurrences with groups that span XCDs."""
+    _shard_linearity(E, 'G3', 64, 192, 96, 2)
+
+
+def test_batch_beyond_one_workgroup_per_cu(E):
+    """128 utterances per GPU do not fit the persistent recurrence (one workgroup per CU): the decoder falls back to one
+    launch per time step.  Its gradients must equal the mean over two 64-utterance shards, which run the persistent kernels."""
+    _shard_linearity(E, 'G3', 128, 128, 64, 2, descent=False)
+
+
 def test_solver_trains_and_checkpoints(E, tmp_path):
     from types import SimpleNamespace
     from speechsplit_amd import data_loader, hparams as HP, solver
