@@ -80,6 +80,48 @@ def synth_batch(seed, B, T, len_lo=64):
     return mel, f0, emb, lens
 
 
+CONDITIONS = ['R', 'F', 'U', 'RF', 'RU', 'FU', 'RFU']
+
+
+def demo_conversion(ref_model, ref_utils):
+    """F1b: the seven conversion conditions of demo.ipynb cell 0 on demo.pkl entries 0 -> 1, reference Generator_3 (weights
+    seed 3) and Generator_6 (seed 4), eval mode.  Inputs are the padded tensors already kept in demo_config1.npz."""
+    hp = W.default_hparams()
+    demo = pickle.load(open(os.path.join(REF, 'assets', 'demo.pkl'), 'rb'))
+    G = ref_model.Generator_3(hp)
+    G.load_state_dict({**{k: torch.from_numpy(v) for k, v in W.make_weights('G3', hp, seed=3).items()},
+                       'encoder_1.len_org': torch.tensor(hp.max_len_pad)})
+    P = ref_model.Generator_6(hp)
+    P.load_state_dict({**{k: torch.from_numpy(v) for k, v in W.make_weights('G6', hp, seed=4).items()},
+                       'encoder_3.len_org': torch.tensor(hp.max_len_pad)})
+    G.eval()
+    P.eval()
+
+    def prep(ent):
+        mel, f0, L = ent[2][0], ent[2][1], ent[2][2]
+        pad, _ = ref_utils.pad_seq_to_2(mel[np.newaxis, :, :], 192)
+        f0p = np.pad(f0, (0, 192 - L), 'constant', constant_values=(0, 0))
+        onehot = ref_utils.quantize_f0_numpy(f0p)[0][np.newaxis]
+        return torch.from_numpy(pad), torch.from_numpy(onehot), torch.from_numpy(ent[1]), L
+
+    x_org, oh_org, emb_org, len_org = prep(demo[0])
+    x_trg, oh_trg, emb_trg, len_trg = prep(demo[1])
+    d = {}
+    with torch.no_grad():
+        f0_pred = P(x_org, oh_trg)[0]
+        q = f0_pred.argmax(dim=-1).squeeze(0)
+        oh_con = torch.zeros((1, 192, 257))
+        oh_con[0, torch.arange(192), q] = 1
+        xf_org, xf_trg = torch.cat((x_org, oh_org), -1), torch.cat((x_org, oh_con), -1)
+        for c in CONDITIONS:
+            y = G(xf_trg if 'F' in c else xf_org, x_trg if 'R' in c else x_org, emb_trg if 'U' in c else emb_org)
+            d[f'out_{c}'] = y[0, :(len_trg if 'R' in c else len_org), :].numpy()
+    d['f0_logits'] = f0_pred.numpy().astype(np.float32)
+    d['f0_pred_idx'] = q.numpy().astype(np.int16)
+    np.savez_compressed(os.path.join(GOLD, 'demo_conversion.npz'), **d)
+    print('demo_conversion.npz written:', {k: v.shape for k, v in d.items()})
+
+
 def main():
     mods = import_reference()
     if mods is None:
@@ -88,6 +130,9 @@ def main():
     ref_model, ref_utils = mods
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == 'demo_conversion':      # only this fixture
+        demo_conversion(ref_model, ref_utils)
+        return 0
 
     # ---------------------------------------------------------------- F0: state_dict keys
     for kind, cls in (('G3', ref_model.Generator_3), ('G6', ref_model.Generator_6)):
@@ -194,6 +239,7 @@ def main():
     d['seed_g3'] = np.int64(3)
     d['seed_g6'] = np.int64(4)
     np.savez_compressed(os.path.join(GOLD, 'demo_config1.npz'), **d)
+    demo_conversion(ref_model, ref_utils)
 
     # ---------------------------------------------------------------- F4/F5: full train steps (stats + output)
     steps = {}

@@ -21,6 +21,14 @@ import torch.nn as nn
 from . import engine as _engine
 
 
+def _hp_get(hp, name, default):
+    """Optional hyper-parameter: attribute bags differ in what a missing name raises."""
+    try:
+        return getattr(hp, name)
+    except (AttributeError, KeyError):
+        return default
+
+
 class _Node(nn.Module):
     """Anonymous container used to reproduce the reference's dotted parameter names."""
 
@@ -160,17 +168,13 @@ class _EngineModule(nn.Module):
         return self
 
     def _ensure_engine(self, dev, batch=None):
-        need = batch or self._max_batch or getattr(self.hparams_, 'batch_size', 16)
+        need = batch or self._max_batch or _hp_get(self.hparams_, 'batch_size', 16)
         if self._eng is not None and self._eng.device == dev and self._eng.max_batch >= need:
             return
         old = {n: p.data.detach().clone() for n, p in zip(self._names, self._plist)}
         eng = _engine.Engine(self.KIND, self.hparams_, max(need, self._max_batch or 0),
                              max(self.hparams_.max_len_pad, 192), device=dev)
-        try:                                           # optional extra hparam: 'f32' (reference arithmetic) | 'bf16'
-            precision = self.hparams_.precision
-        except (AttributeError, KeyError):
-            precision = 'f32'
-        eng.set_precision(precision)
+        eng.set_precision(_hp_get(self.hparams_, 'precision', 'f32'))   # optional extra hparam: 'f32' (reference arithmetic) | 'bf16'
         eng.load_weights(old)
         pv = eng.param_views()
         for n, p in zip(self._names, self._plist):

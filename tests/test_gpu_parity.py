@@ -152,6 +152,31 @@ def test_config1_demo_eval_forward(E):
         assert rel(e6.g6_forward(mel, onehot), z[f'u{n}_out6']) < TOL
 
 
+def test_demo_conversion_seven_conditions(E):
+    """demo.ipynb cell 0 through the drop-in modules: Generator_6 F0 conversion (argmax classes identical to the reference's)
+    and the seven conversion conditions as one batch-7 forward, against the reference's seven batch-1 outputs."""
+    from speechsplit_amd import convert, model
+    z, c = np.load(os.path.join(GOLD, 'demo_config1.npz')), np.load(os.path.join(GOLD, 'demo_conversion.npz'))
+    hp = W.default_hparams()
+    G, P = model.Generator_3(hp).eval(), model.Generator_6(hp).eval()
+    G.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_weights('G3', hp, int(z['seed_g3'])).items()}, strict=False)
+    P.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_weights('G6', hp, int(z['seed_g6'])).items()}, strict=False)
+    G, P = G.to('cuda:0'), P.to('cuda:0')
+    ent = []
+    for n in range(2):
+        L = int(z[f'u{n}_len'])
+        ent.append([f'p{n}', z[f'u{n}_emb'], (z[f'u{n}_mel_pad'][0, :L], z[f'u{n}_f0_pad'][:L], L, f'utt{n}')])
+    x_org = torch.from_numpy(z['u0_mel_pad']).cuda()
+    oh_trg = torch.from_numpy(interp_np.onehot(z['u1_qidx'].astype(np.int64)))[None].cuda()
+    _, idx = convert.convert_f0(P, x_org, oh_trg)
+    assert np.array_equal(idx.cpu().numpy(), c['f0_pred_idx'].astype(np.int64))
+    res = convert.demo_conversion(G, P, ent[0], ent[1])
+    assert [r[0] for r in res] == [f'p0_p1_utt0_{cond}' for cond in convert.CONDITIONS]
+    for (name, mel), cond in zip(res, convert.CONDITIONS):
+        assert mel.shape == c[f'out_{cond}'].shape
+        assert rel(mel, c[f'out_{cond}']) < TOL, cond
+
+
 def test_eval_forward_ragged_batch(E):
     """B not a multiple of the 16-utterance LSTM tile, T below max_len_pad (eval works at any T % 8 == 0)."""
     hp = W.default_hparams()

@@ -136,6 +136,29 @@ def test_demo_config1(gold_dir):
         assert _rel(out6.numpy(), z[f'u{n}_out6']) < 1e-6
 
 
+def test_demo_conversion_conditions(gold_dir):
+    """demo.ipynb cell 0: F0 conversion through Generator_6 and the seven conversion conditions, oracle vs reference."""
+    z, c = np.load(os.path.join(gold_dir, 'demo_config1.npz')), np.load(os.path.join(gold_dir, 'demo_conversion.npz'))
+    hp = W.default_hparams()
+    P3 = ref_model.as_params(W.make_weights('G3', hp, int(z['seed_g3'])), False)
+    P6 = ref_model.as_params(W.make_weights('G6', hp, int(z['seed_g6'])), False)
+    mel = [torch.from_numpy(z[f'u{n}_mel_pad']) for n in range(2)]
+    oh = [torch.from_numpy(interp_np.onehot(z[f'u{n}_qidx'].astype(np.int64)))[None] for n in range(2)]
+    emb = [torch.from_numpy(z[f'u{n}_emb']) for n in range(2)]
+    lens = [int(z[f'u{n}_len']) for n in range(2)]
+    with torch.no_grad():
+        logits = ref_model.generator_6(P6, hp, mel[0], oh[1])[0]
+        assert _rel(logits.numpy(), c['f0_logits']) < 1e-6
+        q = logits.argmax(-1)
+        assert np.array_equal(q.numpy(), c['f0_pred_idx'].astype(np.int64))
+        oh_con = torch.nn.functional.one_hot(q, 257).float()[None]
+        for cond in ['R', 'F', 'U', 'RF', 'RU', 'FU', 'RFU']:
+            y = ref_model.generator_3(P3, hp, torch.cat((mel[0], oh_con if 'F' in cond else oh[0]), -1),
+                                      mel[1] if 'R' in cond else mel[0], emb[1] if 'U' in cond else emb[0])
+            keep = lens[1] if 'R' in cond else lens[0]
+            assert _rel(y[0, :keep].numpy(), c[f'out_{cond}']) < 1e-6, cond
+
+
 def _synth(seed, B, T, lo):
     from oracle.gen_fixtures import synth_batch
     return synth_batch(seed, B, T, lo)
