@@ -107,6 +107,15 @@ int ss_interp_forward(ss_engine* e, const float* x_dev, const int* len_seq_dev, 
 /* adjoint of the last ss_interp_forward: dy [B,P,C] -> dx [B,T,C] */
 int ss_interp_backward(ss_engine* e, const float* dy_dev, int B, int T, int C, float* dx_dev, void* stream);
 
+/* Batch producer on the GPU side (replaces the host loop of MyCollator.__call__, reference data_loader.py:101-128, for a
+ * corpus kept resident in HBM): utterance b of the batch is rows [row0[b], row0[b] + len[b]) of the concatenated corpus
+ * mel_cat [rows, n_mel] / f0_cat [rows]; the host only draws the crops (same generator calls, same order as the reference).
+ * mel [B,T,n_mel] = clip(crop, 0, 1) zero-padded, f0 [B,T] = crop padded with -1e10, emb [B,emb_dim] = emb_tab[item[b]].
+ * All pointers are device pointers; row0 is int64, len / item int32.  No engine needed. */
+int ss_collate(const float* mel_cat_dev, const float* f0_cat_dev, const float* emb_tab_dev, const long* row0_dev,
+               const int* len_dev, const int* item_dev, int B, int T, int n_mel, int emb_dim, float* mel_dev, float* f0_dev,
+               float* emb_dev, void* stream);
+
 /* Synchronise `stream` and report asynchronous failures (a persistent recurrence kernel whose bounded wait expired). */
 int ss_check(ss_engine* e, void* stream);
 

@@ -197,6 +197,31 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict_
     }
 }
 
+// Batch assembly from an HBM-resident corpus (reference data_loader.py:101-128): utterance b is rows [row0[b], row0[b] + len[b])
+// of the concatenated corpus; mel is clipped to [0,1] and zero-padded to T rows, F0 is padded with -1e10, the speaker row is copied.
+__global__ __launch_bounds__(256) void collate_kernel(const float* __restrict__ mel_cat, const float* __restrict__ f0_cat,
+                                                      const float* __restrict__ emb_tab, const long* __restrict__ row0,
+                                                      const int* __restrict__ len, const int* __restrict__ item, int T, int C,
+                                                      int E, float* __restrict__ mel, float* __restrict__ f0,
+                                                      float* __restrict__ emb) {
+    const int b = blockIdx.y;
+    const long r0 = row0[b];
+    const int n = len[b];
+    const long tot = (long)T * C;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
+        const int t = (int)(i / C);
+        float v = 0.f;
+        if (t < n) {
+            v = mel_cat[r0 * C + i];
+            v = fminf(fmaxf(v, 0.f), 1.f);
+        }
+        mel[(long)b * tot + i] = v;
+    }
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < T; t += gridDim.x * 256) f0[(long)b * T + t] = t < n ? f0_cat[r0 + t] : -1e10f;
+    if (blockIdx.x == 0)
+        for (int k = threadIdx.x; k < E; k += 256) emb[(long)b * E + k] = emb_tab[(long)item[b] * E + k];
+}
+
 __global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict__ w, int Co, int Ci, int Cp,
                                                         float* __restrict__ wf, float* __restrict__ wb) {
     // wf[co][k][cp] ; wb[ci][k][co] = w[co][ci][4-k]
@@ -430,6 +455,14 @@ hipError_t copy_rows(const float* src, long s_ld, long s_bs, float* dst, long d_
     int gx = cdiv((long)T * C, 256);
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(copy_rows_kernel, dim3(gx, B), dim3(256), 0, s, src, s_ld, s_bs, dst, d_ld, d_bs, T, C);
+    return hipGetLastError();
+}
+
+hipError_t collate(const float* mel_cat, const float* f0_cat, const float* emb_tab, const long* row0, const int* len,
+                   const int* item, int B, int T, int C, int E, float* mel, float* f0, float* emb, hipStream_t s) {
+    int gx = cdiv((long)T * C, 256 * 4);
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(collate_kernel, dim3(gx, B), dim3(256), 0, s, mel_cat, f0_cat, emb_tab, row0, len, item, T, C, E, mel, f0, emb);
     return hipGetLastError();
 }
 

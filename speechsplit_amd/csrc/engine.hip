@@ -1340,6 +1340,14 @@ int ss_g6_train_step(ss_engine* e, const float* mel, const float* f0_onehot, con
     return 0;
 }
 
+int ss_collate(const float* mel_cat, const float* f0_cat, const float* emb_tab, const long* row0, const int* len, const int* item,
+               int B, int T, int n_mel, int emb_dim, float* mel, float* f0, float* emb, void* stream) {
+    if (!mel_cat || !f0_cat || !emb_tab || !row0 || !len || !item || !mel || !f0 || !emb) return fail("ss_collate: null pointer");
+    if (B <= 0 || T <= 0 || n_mel <= 0 || emb_dim <= 0) return fail("ss_collate: bad shape");
+    HIPCHK(collate(mel_cat, f0_cat, emb_tab, row0, len, item, B, T, n_mel, emb_dim, mel, f0, emb, S(stream)));
+    return 0;
+}
+
 int ss_interp_forward(ss_engine* e, const float* x, const int* len_seq, const float* scales, const int* len_seg, int B, int T,
                       int C, float* y, int* i0, float* lam, int* counts, void* stream) {
     hipStream_t s = S(stream);

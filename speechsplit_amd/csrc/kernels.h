@@ -45,6 +45,9 @@ hipError_t gn_relu_bwd(const float* x, long x_ld, long x_bs, float* dy, long dy_
 hipError_t colsum_acc(const float* in, long ld, int R, int C, float* out, hipStream_t s);
 hipError_t copy_rows(const float* src, long s_ld, long s_bs, float* dst, long d_ld, long d_bs, int B, int T, int C,
                      hipStream_t s);
+// batch assembly from a device-resident corpus: see collate_kernel (crop rows, clip mel to [0,1], pad mel with 0 / F0 with -1e10)
+hipError_t collate(const float* mel_cat, const float* f0_cat, const float* emb_tab, const long* row0, const int* len,
+                   const int* item, int B, int T, int C, int E, float* mel, float* f0, float* emb, hipStream_t s);
 // conv weight [Co][Ci][5] -> forward pack [Co][5][Cp] (zero-filled for ci >= Ci) and input-grad pack [Ci][5][Co] (taps flipped)
 hipError_t conv_pack(const float* w, int Co, int Ci, int Cp, float* wf, float* wb, hipStream_t s);
 // packed weight grad [Co][5][Cp] -> grad arena [Co][Ci][5] (overwrite)

@@ -103,6 +103,82 @@ class MultiSampler(Sampler):
         return self.num_samples * self.n_repeats
 
 
+class DeviceCorpus(object):
+    """The whole corpus resident in HBM (the reference's ``Utterances`` keeps it in host RAM): mel [rows, 80] and F0 [rows]
+    of all utterances back to back, start rows, and the speaker-embedding table.  A few GB at most against 288 GB."""
+
+    def __init__(self, dataset, device='cuda'):
+        items = [dataset[i] for i in range(len(dataset))]
+        lens = np.asarray([len(it[0]) for it in items], np.int64)
+        self.lens = lens
+        self.starts = np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.int64)
+        self.mel = torch.from_numpy(np.concatenate([np.asarray(it[0], np.float32) for it in items])).to(device)
+        self.f0 = torch.from_numpy(np.concatenate([np.asarray(it[2], np.float32).reshape(-1) for it in items])).to(device)
+        self.emb = torch.from_numpy(np.stack([np.asarray(it[1], np.float32) for it in items])).to(device)
+        self.device = self.mel.device
+
+    def __len__(self):
+        return len(self.lens)
+
+
+class DeviceBatcher(object):
+    """Iterable with the loader's contract -- (melsp [B,192,80], spk_emb [B,82], pitch [B,192,1], len_org int64[B]) -- whose
+    batches are assembled ON the GPU from a DeviceCorpus by one kernel (ss_collate).  Per batch the host draws the crops
+    with exactly the collator's generator calls (two ``np.random.randint`` per utterance, data_loader.py:106-107) and sends
+    3*B integers; no mel / F0 crosses PCIe.  Same seeds + same sampler order => the same batches as MyCollator, bit for bit."""
+
+    def __init__(self, hparams, corpus, sampler=None, drop_last=True):
+        self.hp, self.corpus = hparams, corpus
+        self.sampler = sampler or MultiSampler(len(corpus), hparams.samplier, shuffle=hparams.shuffle)
+        self.B = hparams.batch_size
+        self.drop_last = drop_last
+
+    def __len__(self):
+        return len(self.sampler) // self.B
+
+    def assemble(self, indices):
+        from . import _capi
+        hp, c = self.hp, self.corpus
+        row0, lens = [], []
+        for i in indices:
+            n = int(np.random.randint(hp.min_len_seq, hp.max_len_seq + 1))
+            n = min(n, hp.max_len_pad)
+            left = int(np.random.randint(0, max(int(c.lens[i]) - n, 1)))
+            lens.append(min(n, int(c.lens[i]) - left))
+            row0.append(int(c.starts[i]) + left)
+        B, T, dev = len(indices), hp.max_len_pad, c.device
+        meta = torch.tensor([row0, lens, list(map(int, indices))], dtype=torch.int64).to(dev, non_blocking=True)
+        row0_d, len_d, item_d = meta[0].contiguous(), meta[1].to(torch.int32), meta[2].to(torch.int32)
+        mel = torch.empty(B, T, c.mel.shape[1], device=dev)
+        f0 = torch.empty(B, T, 1, device=dev)
+        emb = torch.empty(B, c.emb.shape[1], device=dev)
+        P = lambda t: _capi.C.c_void_p(t.data_ptr())
+        _capi.check(_capi.lib().ss_collate(P(c.mel), P(c.f0), P(c.emb), P(row0_d), P(len_d), P(item_d), B, T, c.mel.shape[1],
+                                           c.emb.shape[1], P(mel), P(f0), P(emb), _capi.C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return mel, emb, f0, meta[1]
+
+    def __iter__(self):
+        batch = []
+        for idx in self.sampler:
+            batch.append(int(idx))
+            if len(batch) == self.B:
+                yield self.assemble(batch)
+                batch = []
+        if batch and not self.drop_last:
+            yield self.assemble(batch)
+
+
+def get_device_loader(hparams, dataset=None, device='cuda'):
+    """Like get_loader, but the corpus lives in HBM and batches are assembled there (DeviceBatcher)."""
+    if dataset is None:
+        if os.path.exists(os.path.join(hparams.root_dir, 'train.pkl')):
+            dataset = Utterances(hparams.root_dir, hparams.feat_dir, hparams.mode)
+        else:
+            print(f'[speechsplit_amd] {hparams.root_dir}/train.pkl not found: using the synthetic corpus')
+            dataset = SyntheticUtterances(max(4 * hparams.batch_size, 64))
+    return DeviceBatcher(hparams, DeviceCorpus(dataset, device))
+
+
 def get_loader(hparams, dataset=None):
     """data_loader.py:156-175.  Falls back to the synthetic corpus when hparams.root_dir has no train.pkl."""
     if dataset is None:

@@ -177,6 +177,31 @@ def test_demo_conversion_seven_conditions(E):
         assert rel(mel, c[f'out_{cond}']) < TOL, cond
 
 
+def test_device_batcher_equals_host_collator(E):
+    """batches assembled on the GPU from an HBM-resident corpus (ss_collate) are bit-identical to the host
+    collator's (reference data_loader.py:101-128 semantics) under the same generator state, incl. utterances shorter than
+    the drawn crop."""
+    from speechsplit_amd import data_loader as DL, hparams as HPM
+    hp = HPM.default_hparams(batch_size=12)
+    ds = DL.SyntheticUtterances(40, seed=3)
+    ds.items[5] = (ds.items[5][0][:70], ds.items[5][1], ds.items[5][2][:70])      # shorter than most crops
+    ds.items[9] = (ds.items[9][0][:64] * 3 - 1, ds.items[9][1], ds.items[9][2][:64])   # values outside [0,1]: clip
+    corpus = DL.DeviceCorpus(ds, 'cuda')
+    batcher = DL.DeviceBatcher(hp, corpus)
+    coll = DL.MyCollator(hp)
+    for trial, idx in enumerate(([5, 9, 0, 1, 2, 3, 4, 6, 7, 8, 10, 11], [39, 5, 5, 9, 20, 21, 22, 23, 24, 25, 26, 27])):
+        np.random.seed(100 + trial)
+        host = coll([ds[i] for i in idx])
+        np.random.seed(100 + trial)
+        dev = batcher.assemble(idx)
+        for h, d in zip(host, dev):
+            assert h.shape == d.shape and h.dtype == d.dtype
+            assert torch.equal(h, d.cpu())
+    np.random.seed(7)
+    n = sum(1 for _ in batcher)
+    assert n == len(batcher) == len(ds) * hp.samplier // hp.batch_size
+
+
 def test_eval_forward_ragged_batch(E):
     """B not a multiple of the 16-utterance LSTM tile, T below max_len_pad (eval works at any T % 8 == 0)."""
     hp = W.default_hparams()
