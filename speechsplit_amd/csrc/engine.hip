@@ -72,6 +72,7 @@ struct LstmBlk {
     std::vector<LstmDir> pd;               // [L*2]
     std::vector<float*> gates, out, csave; // per layer
     float* bsum = nullptr;                 // [L][2][4H]
+    std::vector<float*> wcat;              // per layer: [W_ih forward ; W_ih reverse] stacked, [8H][In] (input-gradient GEMM over both directions)
     std::vector<float*> wfrag;             // per layer: fragment-major W_hh (forward) / W_hh^T (backward), 2*4H*H floats
     float* hf[2] = {nullptr, nullptr};     // per batch-half chain: ping-pong fragment-major h(t),  2 x [2][ceil16(B)][H]
     float* gf[2] = {nullptr, nullptr};     // per chain: ping-pong fragment-major da(t), 2 x [2][ceil16(B)][4H]
@@ -295,6 +296,8 @@ long ss_engine::carve(int B, int T, bool assign) {
             lb.csave[l] = slab((name + ".c" + std::to_string(l)).c_str(), 2L * lb.H);
         }
         lb.bsum = (float*)take((long)lb.L * 2 * 4 * lb.H * 4);
+        lb.wcat.assign(lb.L, nullptr);
+        for (int l = 0; l < lb.L; ++l) lb.wcat[l] = (float*)take(8L * lb.H * lb.in_of(l) * 4);
         if (lb.big()) {
             const long B16 = ((B + 15) / 16) * 16;
             lb.wfrag.assign(lb.L, nullptr);
@@ -555,6 +558,8 @@ int lstm_prep(ss_engine* e, LstmBlk& lb, hipStream_t s) {
         for (int dir = 0; dir < 2; ++dir) {
             const LstmDir& pd = lb.pd[l * 2 + dir];
             HIPCHK(add_vec(e->P + pd.bih, e->P + pd.bhh, lb.bsum + ((long)l * 2 + dir) * 4 * H, 4 * H, s));
+            const long n = 4L * H * lb.in_of(l);
+            HIPCHK(hipMemcpyAsync(lb.wcat[l] + dir * n, e->P + pd.wih, n * 4, hipMemcpyDeviceToDevice, s));
         }
         // fragment-major W_hh for the one-launch-per-step schedule (the persistent kernels read the parameters directly)
         if (lb.big() && !persist) HIPCHK(lstm_pack_w(e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.wfrag[l], H, 0, s));
@@ -694,22 +699,27 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, hipStream_t ws)
 
 // input gradient of one layer for the slab rows [r0, r0 + nr):  dX = dG . W_ih  (both directions accumulate)
 int lstm_input_grad(ss_engine* e, LstmBlk& lb, int l, Slab dxi, long r0, long nr, hipStream_t st) {
+    // dX[r][k] = sum over both directions' 8H gate units of dG[r][n] * W_ih[n][k]: ONE GEMM against the stacked weights
+    // (lstm_prep).  A narrow input (the decoder's 164 columns) is cut along the reduction so the launch still fills the chip.
     const int H = lb.H, In = lb.in_of(l);
-    for (int dir = 0; dir < 2; ++dir) {
-        const LstmDir& pd = lb.pd[l * 2 + dir];
-        GemmDesc g{};
-        g.A = {lb.gates[l] + r0 * 8L * H + dir * 4L * H, 8L * H, 0, 0, 0};
-        g.B = {e->P + pd.wih, In, 0, 0, 0};
-        g.C = dxi.p + r0 * dxi.ld;
-        g.ldc = dxi.ld;
-        g.M = (int)nr;
-        g.N = In;
-        g.K = 4 * H;
-        g.batch = 1;
-        g.flags = GEMM_TB | (dir ? GEMM_ACCUM : 0);
-        g.ksplit = 1;
-        GEMM_ON(g, st);
+    GemmDesc g{};
+    g.A = {lb.gates[l] + r0 * 8L * H, 8L * H, 0, 0, 0};
+    g.B = {lb.wcat[l], In, 0, 0, 0};
+    g.C = dxi.p + r0 * dxi.ld;
+    g.ldc = dxi.ld;
+    g.M = (int)nr;
+    g.N = In;
+    g.K = 8 * H;
+    g.batch = 1;
+    g.flags = GEMM_TB;
+    g.ksplit = 1;
+    const long tiles = (long)cdiv(g.M, 128) * cdiv(g.N, 64);
+    if (tiles < 512 && g.K >= 1024 && dxi.ld == In) {          // split-K needs a zeroed, dense C
+        g.ksplit = tiles < 256 ? 4 : 2;
+        g.flags |= GEMM_ACCUM;
+        HIPCHK(hipMemsetAsync(g.C, 0, nr * dxi.ld * 4, st));
     }
+    GEMM_ON(g, st);
     return 0;
 }
 
