@@ -170,7 +170,7 @@ def main():
 
 def gemm_roofline(eng, B, T, precision='f32'):
     """Roofline of the dominant kernel, measured INSIDE the timed region: the engine brackets every launch of the decoder
-    input-projection GEMM of layers 1-2 (gemm_bf16x3_kernel<128,128,NT>; per launch M = B*T rows, N = 2048, K = 1024, fp32
+    input-projection GEMM of layers 1-2 (gemm_bf16x3_kernel<128,128,NT>; per launch M = B*T rows, N = 4096 = both directions, K = 1024, fp32
     in / fp32 out / fp32 accumulate) with hipEvents on its launch stream (ss_profile in include/speechsplit_amd.h).
     achieved = algorithmic FLOPs of one launch (2*M*N*K) / mean launch duration.
 
@@ -188,7 +188,7 @@ def gemm_roofline(eng, B, T, precision='f32'):
     traffic = None
     try:
         rec = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'gemm_pmc.json')))[0]
-        if rec['shape'].startswith('proj NT 8192x2048x1024') and B * T == 8192 and 'bf16x3' in rec.get('kernel', ''):
+        if rec['shape'].startswith('proj NT 8192x4096x1024') and B * T == 8192 and 'bf16x3' in rec.get('kernel', ''):
             traffic = rec['hbm_read_bytes'] + rec['hbm_write_bytes']
     except Exception:
         pass

@@ -145,9 +145,10 @@ int ss_tune(const char* key, int value);
 #define SS_PRECISION_BF16 1
 int ss_set_precision(ss_engine* e, int precision);
 /* Live timing of the dominant kernel inside a caller's own timed region: while enabled, the engine brackets every launch
- * of the decoder input-projection GEMM of layers >= 1 (one launch per direction: M = B*T rows, N = 4H, K = 2H, H = decoder hidden size) with
+ * of the decoder input-projection GEMM of layers >= 1 (one launch per layer, both directions: M = B*T rows, N = 8H, K = 2H,
+ * H = decoder hidden size) with
  * hipEvents on the stream it is launched on.  A call returns the launches recorded since the previous call, their summed
- * duration and the algorithmic FLOPs of one launch (2*B*T*4H*2H), resets the record and sets the enable state.
+ * duration and the algorithmic FLOPs of one launch (2*B*T*8H*2H), resets the record and sets the enable state.
  * Synchronises on the recorded events.  At most 256 launches are kept between two calls.  Any out pointer may be null. */
 int ss_profile(ss_engine* e, int enable, int* launches, double* total_us, double* flops_per_launch);
 /* named internal slab of the last call ("enc1.xf2", "dec.out2", ...); layout [B, T+4, C], frame t at row t+2 */

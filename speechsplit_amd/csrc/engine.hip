@@ -583,17 +583,16 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
         Slab xi = l == 0 ? x : Slab{lb.out[l - 1], 2L * H};
         for (int c = 0; c < nch; ++c) {
             const long r0 = (long)ch[c].b0 * TP;
-            for (int dir = 0; dir < 2; ++dir) {
-                const LstmDir& pd = lb.pd[l * 2 + dir];
+            {   // both directions in one GEMM against the stacked W_ih / summed biases of lstm_prep (N = 8H)
                 GemmDesc d{};
                 d.A = {xi.p + (r0 + HALO) * xi.ld, xi.ld, TP * xi.ld, 0, 0};
-                d.B = {e->P + pd.wih, In, 0, 0, 0};
-                d.C = lb.gates[l] + (r0 + HALO) * 8L * H + dir * 4L * H;
+                d.B = {lb.wcat[l], In, 0, 0, 0};
+                d.C = lb.gates[l] + (r0 + HALO) * 8L * H;
                 d.ldc = 8L * H;
                 d.cstride = TP * 8L * H;
-                d.bias = lb.bsum + ((long)l * 2 + dir) * 4 * H;
+                d.bias = lb.bsum + (long)l * 8 * H;
                 d.M = T;
-                d.N = 4 * H;
+                d.N = 8 * H;
                 d.K = In;
                 d.batch = ch[c].nb;
                 d.ksplit = 1;
@@ -632,18 +631,16 @@ int lstm_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
     for (int l = 0; l < lb.L; ++l) {
         const int In = lb.in_of(l);
         Slab xi = l == 0 ? x : Slab{lb.out[l - 1], 2L * H};
-        for (int dir = 0; dir < 2; ++dir) {
-            const LstmDir& pd = lb.pd[l * 2 + dir];
-            float* bs = lb.bsum + ((long)l * 2 + dir) * 4 * H;     // lstm_prep
+        {   // both directions in one GEMM (stacked W_ih and summed biases from lstm_prep)
             GemmDesc d{};
             d.A = {xi.p + HALO * xi.ld, xi.ld, TP * xi.ld, 0, 0};
-            d.B = {e->P + pd.wih, In, 0, 0, 0};
-            d.C = lb.gates[l] + HALO * 8L * H + dir * 4L * H;
+            d.B = {lb.wcat[l], In, 0, 0, 0};
+            d.C = lb.gates[l] + HALO * 8L * H;
             d.ldc = 8L * H;
             d.cstride = TP * 8L * H;
-            d.bias = bs;
+            d.bias = lb.bsum + (long)l * 8 * H;
             d.M = T;
-            d.N = 4 * H;
+            d.N = 8 * H;
             d.K = In;
             d.batch = B;
             d.ksplit = 1;
@@ -1426,7 +1423,7 @@ int ss_profile(ss_engine* e, int enable, int* launches, double* total_us, double
         if (launches) *launches = e->prof_n;
         if (total_us) *total_us = us;
     }
-    if (flops_per_launch) *flops_per_launch = 2.0 * e->curB * e->curT * (4.0 * e->ld.H) * (2.0 * e->ld.H);
+    if (flops_per_launch) *flops_per_launch = 2.0 * e->curB * e->curT * (8.0 * e->ld.H) * (2.0 * e->ld.H);
     e->prof_n = 0;
     if (enable && e->prof_ev.empty()) {
         e->prof_ev.resize(2 * ss_engine::PROF_CAP);

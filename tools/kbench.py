@@ -143,7 +143,7 @@ def bench_lstm(B=64, T=128, H=512):
 def bench_gemm():
     dev = 'cuda'
     shapes = [  # (name, M, N, K, ta, tb, ksplit)
-        ('proj   NT 8192x2048x1024', 8192, 2048, 1024, False, False, 1),
+        ('proj   NT 8192x4096x1024', 8192, 4096, 1024, False, False, 1),
         ('conv   NT 8192x512x2560 ', 8192, 512, 2560, False, False, 1),
         ('dX     NN 8448x1024x2048', 8448, 1024, 2048, False, True, 1),
         ('dW_ih  TN 2048x1024x8448', 2048, 1024, 8448, True, True, 4),
@@ -171,7 +171,7 @@ def bench_gemm():
 
 def bench_gemm_diag():
     dev = 'cuda'
-    shapes = [('proj   NT 8192x2048x1024', 8192, 2048, 1024, False, False, 1), ('conv   NT 8192x512x2560', 8192, 512, 2560, False, False, 1),
+    shapes = [('proj   NT 8192x4096x1024', 8192, 4096, 1024, False, False, 1), ('conv   NT 8192x512x2560', 8192, 512, 2560, False, False, 1),
               ('dX     NN 8448x1024x2048', 8448, 1024, 2048, False, True, 1), ('dW_ih  TN 2048x1024x8448', 2048, 1024, 8448, True, True, 4),
               ('dW_hh  TN 2048x512x8447', 2048, 512, 8447, True, True, 8)]
     for name, M, N, K, ta, tb, ks in shapes:
