@@ -68,7 +68,18 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
         const int total = gx * gy * gridDim.z;
         if ((total & 7) == 0) {                               // XCD-aware tile order (see gemm_f32.hip)
             const int lin = bx + gx * (by + gy * bz);
-            const int rem = (lin & 7) * (total >> 3) + (lin >> 3);
+            const int chunk = total >> 3;                     // consecutive tiles of one XCD
+            int rem = (lin & 7) * chunk + (lin >> 3);
+            // Inside an XCD's chunk walk 8 columns x all of the chunk's rows before the next 8 columns: the ~64 workgroups
+            // resident on the XCD then share 8 column panels AND 8 row panels in its 4 MB L2, instead of streaming every
+            // column panel once per pair of rows (3.4x -> 1.6x the operand bytes from HBM on the projection shape).
+            constexpr int GW = 8;
+            if (!(d.diag & 8) && chunk % gx == 0 && gx % GW == 0 && chunk / gx >= 2) {
+                const int rows = chunk / gx, local = rem % chunk;
+                const int c = (local / (GW * rows)) * GW + local % GW;
+                const int r = (local / GW) % rows;
+                rem = rem - local + r * gx + c;
+            }
             bx = rem % gx;
             by = (rem / gx) % gy;
             bz = rem / (gx * gy);

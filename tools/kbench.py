@@ -180,7 +180,7 @@ def bench_gemm_diag():
         c = torch.zeros(M, N, device=dev)
         ref = ((A.t() if ta else A).double() @ (Bm if tb else Bm.t()).double())
         for rnd in range(2):
-            for diag, what in [(0, 'XCD order'), (1, 'linear order'), (4, 'no k advance (cache-hot)')]:
+            for diag, what in [(0, 'XCD order, grouped columns'), (8, 'XCD order, row-major'), (1, 'linear order')]:
                 tune('gemm_diag', diag)
                 c.zero_()
                 E.gemm(A, Bm, None, ta, tb, ks, out=c)
