@@ -201,15 +201,15 @@ def bench_step():
     eng = E.Engine('G3', hp, B, T)
     eng.load_weights(W.make_weights('G3', hp, 0))
     for rnd in range(2):
-        for ps, ov in [(1, 1), (0, 1)]:
-            tune('seq_prio', ps)          # s_setprio 3 in the persistent recurrences on / off
+        for ps, ov in [(1024, 1), (512, 1), (2048, 1)]:
+            tune('gemm_want', ps)         # tile preference: smallest tile count that still takes the larger tile
             tune('overlap', ov)
             t, tmin = timeit(lambda: eng.g3_train_step(mel, f0, emb, lens, (sc, ls)), iters=10, warm=3)
             eng.check()
-            say(f'train step seq_prio{ps} overlap{ov}: {t / 1e3:.3f} ms  ({B / t * 1e6:.0f} utt/s) min {tmin / 1e3:.3f}, loss {float(eng.loss):.6f}')
+            say(f'train step gemm_want{ps} overlap{ov}: {t / 1e3:.3f} ms  ({B / t * 1e6:.0f} utt/s) min {tmin / 1e3:.3f}, loss {float(eng.loss):.6f}')
     tune('persist', 1)
     tune('overlap', 1)
-    tune('seq_prio', 1)
+    tune('gemm_want', 1024)
 
 
 def bench_lstm_modes(B=64, T=128, H=512):
