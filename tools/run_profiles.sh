@@ -8,6 +8,12 @@ mkdir -p $O
 export TMPDIR=/tmp
 timeout -k 10 900 python -u -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1 || { tail -30 $O/pytest_gpu.txt; exit 1; }
 tail -3 $O/pytest_gpu.txt
+# counter passes first: bench.py reads the HBM traffic of its roofline kernel from profiles/<round>/gemm_pmc.json
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 tools/gemm_pmc.py 1024 > $O/pmc_f.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 tools/gemm_pmc.py 1024 > $O/pmc_w.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_sq -- python3 tools/gemm_pmc.py 1024 > $O/pmc_s.log 2>&1
+python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/gemm_pmc
+mkdir -p profiles/$R && cp $O/gemm_pmc.json $O/gemm_pmc.txt profiles/$R/
 timeout -k 10 400 python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err
 cat $O/bench_n1.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/prof.err
@@ -15,9 +21,5 @@ cp $(ls $O/prof/*/*kernel_stats.csv) $O/bench_kernel_stats.csv
 python3 tools/step_breakdown.py $(ls $O/prof/*/*kernel_trace.csv) > $O/step_breakdown.txt
 python3 tools/step_timeline.py $(ls $O/prof/*/*kernel_trace.csv) > $O/step_timeline.txt
 head -12 $O/step_breakdown.txt
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 tools/gemm_pmc.py 1024 > $O/pmc_f.log 2>&1
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 tools/gemm_pmc.py 1024 > $O/pmc_w.log 2>&1
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_sq -- python3 tools/gemm_pmc.py 1024 > $O/pmc_s.log 2>&1
-python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/gemm_pmc
 timeout -k 10 120 python3 tools/kbench.py seq 2>&1 | grep -v amdgpu.ids > $O/kbench_seq_ablation.txt
 rm -rf $O/prof/*/*.db
