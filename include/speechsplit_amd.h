@@ -151,6 +151,10 @@ int ss_set_precision(ss_engine* e, int precision);
  * duration and the algorithmic FLOPs of one launch (2*B*T*8H*2H), resets the record and sets the enable state.
  * Synchronises on the recorded events.  At most 256 launches are kept between two calls.  Any out pointer may be null. */
 int ss_profile(ss_engine* e, int enable, int* launches, double* total_us, double* flops_per_launch);
+/* timing experiment: with ss_tune("gemm_diag", 16) the 128x128 NT bf16x3 GEMM accumulates, for its first 64 workgroups, the
+ * s_memtime ticks every wave spends per k-loop phase; out24 = [4 waves][split+store, barrier, load issue, fragments+MFMA,
+ * barrier, k-tiles (wave 0 only)].  Synchronises the device. */
+int ss_debug_gemm_phases(unsigned long long* out24, int reset);
 /* named internal slab of the last call ("enc1.xf2", "dec.out2", ...); layout [B, T+4, C], frame t at row t+2 */
 int ss_debug_buffer(ss_engine* e, const char* name, float** ptr_dev, long* rows, long* cols);
 int ss_debug_names(ss_engine* e, char* buf, int cap);

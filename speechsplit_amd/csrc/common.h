@@ -42,6 +42,9 @@ struct GemmDesc {
 // C[b][m][n] (+)= sum_k A(m,k) * B(n,k) (+ bias[n]);  fp32 in, fp32 MFMA accumulate (exact fp32 fma chain)
 hipError_t launch_gemm(const GemmDesc& d, hipStream_t stream);
 
+// phase probe of the bf16x3 kernel (timing experiments): 4 waves x {5 phases, k-tile count} tick sums; see gemm_bf16x3.hip
+hipError_t gemm_phase_probe(unsigned long long out[24], bool reset);
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace ss

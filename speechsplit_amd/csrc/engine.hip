@@ -1434,6 +1434,13 @@ int ss_profile(ss_engine* e, int enable, int* launches, double* total_us, double
     return 0;
 }
 
+int ss_debug_gemm_phases(unsigned long long* out24, int reset) {
+    if (!out24) return fail("ss_debug_gemm_phases: null pointer");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(gemm_phase_probe(out24, reset != 0));
+    return 0;
+}
+
 int ss_tune(const char* key, int value) {
     const std::string k = key ? key : "";
     if (k == "lstm_nw" && (value == 4 || value == 8 || value == 16)) g_lstm_nw = value;
@@ -1448,7 +1455,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "gemm_bk" && (value == 16 || value == 32)) g_gemm_bk = value;
     else if (k == "gemm_want" && value >= 1) g_gemm_want = value;
     else if (k == "gemm_mode" && (value == 0 || value == 1)) g_gemm_mode = value;
-    else if (k == "gemm_diag" && value >= 0 && value < 16) g_gemm_diag = value;
+    else if (k == "gemm_diag" && value >= 0 && value < 32) g_gemm_diag = value;
     else return fail("ss_tune: unknown key or bad value: " + k);
     ++g_tune_epoch;
     return 0;

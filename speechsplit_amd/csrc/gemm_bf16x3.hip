@@ -50,7 +50,11 @@ __device__ __forceinline__ unsigned round2(float x0, float x1) {
 __device__ __forceinline__ int lds_off(int row, int k) { return row * 64 + (((k >> 3) ^ ((row >> 2) & 3)) << 4) + ((k & 7) << 1); }
 
 // NPL = 3: the exact split above (fp32-grade result).  NPL = 1 (GEMM_BF16): operands rounded once to bf16, one MFMA.
-template <int BM, int BN, bool TA, bool TB, int NPL>
+// Phase probe (ss_tune("gemm_diag", 16), 128x128 NT only): s_memtime ticks each wave spends in the phases of the k-loop,
+// summed over the first 64 workgroups: [wave][0 split+store, 1 barrier, 2 load issue, 3 fragments+MFMA, 4 barrier], [0][5] = k-tiles
+__device__ unsigned long long g_gemm_phase[4][6];
+
+template <int BM, int BN, bool TA, bool TB, int NPL, bool PROBE = false>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
     constexpr int MI = BM / 64, NI = BN / 64;
     constexpr int PA = BM * 64, PB = BN * 64;                 // bytes per plane
@@ -203,12 +207,17 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
     const int l31 = lane & 31, kg = lane >> 5;
     const int nfull = (kend - kbeg) / BK;           // k-tiles that need no bounds checks
     if (nk > 0) gload(kbeg, false);
+    unsigned long long ph[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
     for (int kt = 0; kt < nk; ++kt) {
+        if (PROBE) t0 = __builtin_readcyclecounter();
         sstore();                                   // tile kt: registers -> bf16 planes
+        if (PROBE) { t1 = __builtin_readcyclecounter(); ph[0] += t1 - t0; t0 = t1; }
         __syncthreads();
+        if (PROBE) { t1 = __builtin_readcyclecounter(); ph[1] += t1 - t0; t0 = t1; }
         // tile kt+1 in flight during the MFMAs
         if (kt + 1 < nfull) gload(kbeg + (kt + 1) * BK, true);
         else if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK, false);
+        if (PROBE) { t1 = __builtin_readcyclecounter(); ph[2] += t1 - t0; t0 = t1; }
 #pragma unroll
         for (int ks16 = 0; ks16 < BK / 16; ++ks16) {
             bf16x8 a[NPL][MI], b[NPL][NI];
@@ -242,7 +251,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
                     acc[mi][ni] = c;
                 }
         }
+        if (PROBE) { t1 = __builtin_readcyclecounter(); ph[3] += t1 - t0; t0 = t1; }
         __syncthreads();                            // all fragment reads done before the planes are overwritten
+        if (PROBE) { t1 = __builtin_readcyclecounter(); ph[4] += t1 - t0; }
+    }
+    if (PROBE && lane == 0 && blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z) < 64) {
+        for (int i = 0; i < 5; ++i) atomicAdd(&g_gemm_phase[wave][i], ph[i]);
+        if (wave == 0) atomicAdd(&g_gemm_phase[0][5], (unsigned long long)nk);
     }
 
     float* Cb = d.C + (long)batch * d.cstride;
@@ -271,6 +286,8 @@ template <int BM, int BN, bool TA, bool TB>
 hipError_t launch_cfg(const GemmDesc& d, hipStream_t s) {
     dim3 grid(cdiv(d.N, BN), cdiv(d.M, BM), d.batch * d.ksplit);
     if (d.flags & GEMM_BF16) hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB, 1>), grid, dim3(256), 0, s, d);
+    else if ((d.diag & 16) && BM == 128 && BN == 128 && !TA && !TB)
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB, 3, (BM == 128 && BN == 128 && !TA && !TB)>), grid, dim3(256), 0, s, d);
     else hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB, 3>), grid, dim3(256), 0, s, d);
     return hipGetLastError();
 }
@@ -286,6 +303,15 @@ hipError_t launch_layout(const GemmDesc& d, hipStream_t s) {
 }
 
 }  // namespace
+
+hipError_t gemm_phase_probe(unsigned long long out[24], bool reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_phase), sizeof(unsigned long long) * 24);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[24] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_phase), z, sizeof(z));
+    }
+    return e;
+}
 
 // called by launch_gemm (gemm_f32.hip) for 16-byte-aligned operands
 hipError_t launch_gemm_bf16x3(const GemmDesc& d, hipStream_t s) {
