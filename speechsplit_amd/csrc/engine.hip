@@ -1455,7 +1455,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "gemm_bk" && (value == 16 || value == 32)) g_gemm_bk = value;
     else if (k == "gemm_want" && value >= 1) g_gemm_want = value;
     else if (k == "gemm_mode" && (value == 0 || value == 1)) g_gemm_mode = value;
-    else if (k == "gemm_diag" && value >= 0 && value < 32) g_gemm_diag = value;
+    else if (k == "gemm_diag" && value >= 0 && value < 512) g_gemm_diag = value;
     else return fail("ss_tune: unknown key or bad value: " + k);
     ++g_tune_epoch;
     return 0;

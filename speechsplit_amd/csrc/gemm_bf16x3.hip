@@ -210,28 +210,30 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
     unsigned long long ph[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
     for (int kt = 0; kt < nk; ++kt) {
         if (PROBE) t0 = __builtin_readcyclecounter();
-        sstore();                                   // tile kt: registers -> bf16 planes
+        if (!(d.diag & 64)) sstore();               // tile kt: registers -> bf16 planes   (diag 64 / 128 / 256: timing ablations)
         if (PROBE) { t1 = __builtin_readcyclecounter(); ph[0] += t1 - t0; t0 = t1; }
-        __syncthreads();
+        if (!(d.diag & 32)) __syncthreads();        // diag 32 (timing only, wrong results): no barriers in the k-loop
         if (PROBE) { t1 = __builtin_readcyclecounter(); ph[1] += t1 - t0; t0 = t1; }
         // tile kt+1 in flight during the MFMAs
-        if (kt + 1 < nfull) gload(kbeg + (kt + 1) * BK, true);
+        if (d.diag & 128) {
+        } else if (kt + 1 < nfull) gload(kbeg + (kt + 1) * BK, true);
         else if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK, false);
         if (PROBE) { t1 = __builtin_readcyclecounter(); ph[2] += t1 - t0; t0 = t1; }
 #pragma unroll
         for (int ks16 = 0; ks16 < BK / 16; ++ks16) {
             bf16x8 a[NPL][MI], b[NPL][NI];
+            const int fskip = (d.diag & 256) ? 0 : 1;    // 256: every fragment read hits the same LDS word (no bandwidth, same instruction count)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 const int row = wm * (BM / 2) + mi * 32 + l31;
-                const int o = lds_off(row, ks16 * 16 + kg * 8);
+                const int o = lds_off(row, ks16 * 16 + kg * 8) * fskip;
 #pragma unroll
                 for (int p = 0; p < NPL; ++p) a[p][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + p * PA + o));
             }
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 const int row = wn * (BN / 2) + ni * 32 + l31;
-                const int o = lds_off(row, ks16 * 16 + kg * 8);
+                const int o = lds_off(row, ks16 * 16 + kg * 8) * fskip;
 #pragma unroll
                 for (int p = 0; p < NPL; ++p) b[p][ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bs + p * PB + o));
             }
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
                 }
         }
         if (PROBE) { t1 = __builtin_readcyclecounter(); ph[3] += t1 - t0; t0 = t1; }
-        __syncthreads();                            // all fragment reads done before the planes are overwritten
+        if (!(d.diag & 32)) __syncthreads();        // all fragment reads done before the planes are overwritten
         if (PROBE) { t1 = __builtin_readcyclecounter(); ph[4] += t1 - t0; }
     }
     if (PROBE && lane == 0 && blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z) < 64) {

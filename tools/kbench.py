@@ -171,16 +171,15 @@ def bench_gemm():
 
 def bench_gemm_diag():
     dev = 'cuda'
-    shapes = [('proj   NT 8192x4096x1024', 8192, 4096, 1024, False, False, 1), ('conv   NT 8192x512x2560', 8192, 512, 2560, False, False, 1),
-              ('dX     NN 8448x1024x2048', 8448, 1024, 2048, False, True, 1), ('dW_ih  TN 2048x1024x8448', 2048, 1024, 8448, True, True, 4),
-              ('dW_hh  TN 2048x512x8447', 2048, 512, 8447, True, True, 8)]
+    shapes = [('proj   NT 8192x4096x1024', 8192, 4096, 1024, False, False, 1), ('dW_ih  TN 2048x1024x8448', 2048, 1024, 8448, True, True, 4)]
     for name, M, N, K, ta, tb, ks in shapes:
         A = torch.randn((K, M) if ta else (M, K), device=dev)
         Bm = torch.randn((K, N) if tb else (N, K), device=dev)
         c = torch.zeros(M, N, device=dev)
         ref = ((A.t() if ta else A).double() @ (Bm if tb else Bm.t()).double())
-        for rnd in range(2):
-            for diag, what in [(0, 'XCD order, grouped columns'), (8, 'XCD order, row-major'), (1, 'linear order')]:
+        for rnd in range(1):
+            for diag, what in [(0, 'full'), (0, 'full'), (32, 'no barriers'), (64, 'no split / LDS store'), (128, 'no global loads'), (256, 'fragment reads all to one address'),
+                               (192, 'no split, no loads'), (224, 'no split, loads, barriers'), (480, 'only fragment read issue + MFMA')]:
                 tune('gemm_diag', diag)
                 c.zero_()
                 E.gemm(A, Bm, None, ta, tb, ks, out=c)
@@ -201,15 +200,15 @@ def bench_step():
     eng = E.Engine('G3', hp, B, T)
     eng.load_weights(W.make_weights('G3', hp, 0))
     for rnd in range(2):
-        for ps, ov in [(1024, 1), (512, 1), (2048, 1)]:
-            tune('gemm_want', ps)         # tile preference: smallest tile count that still takes the larger tile
+        for ps, ov in [(1, 1), (0, 1)]:
+            tune('seq_prio', ps)          # s_setprio 3 in the persistent recurrences on / off
             tune('overlap', ov)
             t, tmin = timeit(lambda: eng.g3_train_step(mel, f0, emb, lens, (sc, ls)), iters=10, warm=3)
             eng.check()
-            say(f'train step gemm_want{ps} overlap{ov}: {t / 1e3:.3f} ms  ({B / t * 1e6:.0f} utt/s) min {tmin / 1e3:.3f}, loss {float(eng.loss):.6f}')
+            say(f'train step seq_prio{ps} overlap{ov}: {t / 1e3:.3f} ms  ({B / t * 1e6:.0f} utt/s) min {tmin / 1e3:.3f}, loss {float(eng.loss):.6f}')
     tune('persist', 1)
     tune('overlap', 1)
-    tune('gemm_want', 1024)
+    tune('seq_prio', 1)
 
 
 def bench_lstm_modes(B=64, T=128, H=512):
