@@ -141,6 +141,7 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
+    eng.check()                  # outside the timed region: no persistent kernel reported a bounded-wait expiry
     ms = dt / args.steps * 1e3
     value = B * world / (dt / args.steps)
 

@@ -177,6 +177,7 @@ class Solver(object):
             loss_dev = self.train_on_batch(batch)
             if (i + 1) % self.log_step == 0:
                 loss = {'G/loss_id': loss_dev.item()}             # the only device sync, on log steps
+                self.eng.check()                                  # a persistent kernel that gave up waiting would have said so here
                 if self.world > 1:
                     import torch.distributed as dist
                     t = loss_dev.clone()
