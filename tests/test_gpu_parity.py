@@ -348,7 +348,7 @@ def test_fused_train_step_against_reference_fixture(E, tag):
 
 
 @pytest.mark.parametrize('case', [(2, 64, 9, 46, True, 1), (4, 128, 9, 61, False, 1), (5, 192, 4, 70, False, 1),
-                                  (4, 128, 9, 61, False, 0), (3, 64, 9, 46, False, 2)])
+                                  (4, 128, 9, 61, False, 0), (3, 64, 9, 46, False, 2), (1, 128, 5, 33, False, 1), (17, 64, 2, 80, False, 1)])
 def test_fused_train_step_full_gradients(E, case):
     """Every element of all 86 gradients against the oracle's autograd.  The last field selects the decoder recurrence
     schedule: 1 = persistent kernels (default), 0 = one launch per time step, 2 = per-step launches captured in a hipGraph."""
@@ -370,7 +370,7 @@ def _full_gradients(E, B, T, wseed, bseed, want_safe):
     else:
         mel, f0, emb, lens = synth_batch(bseed, B, T, 64 if T <= 128 else 96)
         draws = draws_for(bseed + 100, B, 4)
-    eng = get_engine(E, 'G3', T, 8)
+    eng = get_engine(E, 'G3', T, max(8, B))
     eng.load_weights(w)
     loss = eng.g3_train_step(mel, f0, emb, lens, stack_draws(draws), no_adam=True)
     eng.check()                       # no persistent kernel gave up
