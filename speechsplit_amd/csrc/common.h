@@ -24,6 +24,7 @@ enum GemmFlags {
     GEMM_TA = 1,        // A is reduction-major:  A(m,k) stored at row k, col m   (else row m, col k)
     GEMM_TB = 2,        // B is reduction-major:  B(n,k) stored at row k, col n   (else row n, col k)
     GEMM_ACCUM = 4,     // C += result (plain read-modify-write; atomics when ksplit > 1)
+    GEMM_F16X2 = 16,    // fp32-grade for O(1)-ranged operands: fp16 x 2 split with a fixed power-of-two scale, 3 MFMAs per k-step
     GEMM_BF16 = 8,      // reduced precision: operands rounded to bf16 (nearest-even), ONE bf16 MFMA per k-step, fp32 accumulate
 };
 

@@ -19,6 +19,8 @@ using namespace ss;
 
 namespace ss {
 extern int g_lstm_nw, g_lstm_g, g_lstm_mode, g_gemm_bk, g_gemm_want, g_gemm_diag, g_seq_prio, g_gemm_mode;
+int g_fwd_f16x2 = 1;   // 1: forward contractions (operands bounded by construction: mel, one-hot, GroupNorm/ReLU outputs, |h| < 1, weights)
+                       //    use the fp16 x 2 split (3 MFMAs) instead of bf16 x 3 (6 MFMAs); gradients keep bf16 x 3 (their range is not bounded)
 int g_overlap = 1;     // 1: weight-gradient GEMMs on the side stream
 int g_side_prio = 0;   // 1: create the side stream with the lowest priority (read at ss_bind).  Measured: 2.3x SLOWER
                        //    (35 ms vs 14.8 ms per step): the low-priority queue starves behind 768 tiny step launches.
@@ -452,6 +454,12 @@ int pick_ksplit(int M, int N, long K) {
         if (e->precision == SS_PRECISION_BF16) (d).flags |= GEMM_BF16; \
         HIPCHK(launch_gemm(d, st));                     \
     } while (0)
+// forward contraction: both operands are O(1) by construction
+#define GEMM_FWD_ON(d, st)                              \
+    do {                                                \
+        if (g_fwd_f16x2) (d).flags |= GEMM_F16X2;       \
+        GEMM_ON(d, st);                                 \
+    } while (0)
 
 // make `to` wait for everything enqueued on `from` so far
 int fork_join(ss_engine* e, hipStream_t from, hipStream_t to) {
@@ -489,7 +497,7 @@ int conv_block_fwd(ss_engine* e, ConvBlk& cb, Slab x, Slab y, hipStream_t s) {
     d.K = 5 * cb.Cp;
     d.batch = B;
     d.ksplit = 1;
-    GEMM(d);
+    GEMM_FWD_ON(d, s);
     HIPCHK(gn_relu_fwd(cb.cout, cb.Co, TP * cb.Co, y.p, y.ld, TP * y.ld, e->P + cb.ga, e->P + cb.be, cb.stats, B, T, cb.Co, s));
     return 0;
 }
@@ -598,7 +606,7 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
                 d.ksplit = 1;
                 const bool timed = e->prof_on && !g_graph && l > 0 && nch == 1 && e->prof_n < ss_engine::PROF_CAP;
                 if (timed) HIPCHK(hipEventRecord(e->prof_ev[2 * e->prof_n], ch[c].st));
-                GEMM_ON(d, ch[c].st);
+                GEMM_FWD_ON(d, ch[c].st);
                 if (timed) HIPCHK(hipEventRecord(e->prof_ev[2 * e->prof_n++ + 1], ch[c].st));
             }
             if (!persist) {
@@ -644,7 +652,7 @@ int lstm_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
             d.K = In;
             d.batch = B;
             d.ksplit = 1;
-            GEMM(d);
+            GEMM_FWD_ON(d, s);
         }
         HIPCHK(lstm_small_fwd(lb.gates[l], e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.out[l], lb.csave[l], B, T, H,
                               s));
@@ -870,7 +878,7 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
     d.K = (int)HD;
     d.batch = B;
     d.ksplit = 1;
-    GEMM(d);
+    GEMM_FWD_ON(d, s);
     e->fwd_training = training;
     e->enc_plan0 = draw0;
     e->have_fwd = true;
@@ -1396,7 +1404,7 @@ int ss_op_gemm(const float* a, long lda, const float* b, long ldb, float* c, lon
     d.K = K;
     d.batch = 1;
     d.ksplit = ksplit < 1 ? 1 : ksplit;
-    d.flags = (flags & 1 ? GEMM_TA : 0) | (flags & 2 ? GEMM_TB : 0) | (flags & 8 ? GEMM_BF16 : 0) | (d.ksplit > 1 ? GEMM_ACCUM : 0);
+    d.flags = (flags & 1 ? GEMM_TA : 0) | (flags & 2 ? GEMM_TB : 0) | (flags & 8 ? GEMM_BF16 : 0) | (flags & 16 ? GEMM_F16X2 : 0) | (d.ksplit > 1 ? GEMM_ACCUM : 0);
     HIPCHK(launch_gemm(d, S(stream)));
     return 0;
 }
@@ -1455,6 +1463,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "gemm_bk" && (value == 16 || value == 32)) g_gemm_bk = value;
     else if (k == "gemm_want" && value >= 1) g_gemm_want = value;
     else if (k == "gemm_mode" && (value == 0 || value == 1)) g_gemm_mode = value;
+    else if (k == "fwd_f16x2" && (value == 0 || value == 1)) g_fwd_f16x2 = value;
     else if (k == "gemm_diag" && value >= 0 && value < 512) g_gemm_diag = value;
     else return fail("ss_tune: unknown key or bad value: " + k);
     ++g_tune_epoch;

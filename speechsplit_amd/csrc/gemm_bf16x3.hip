@@ -39,6 +39,19 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned
     l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
 }
 
+// fp16 x 2 split of two fp32 values pre-scaled by a power of two: y = s*x = h + l with h = fp16(y) (nearest), l = fp16(y - h).
+// 22 significand bits for values whose residual stays in fp16's normal range, an absolute floor of 2^-25 / s below it.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr float F16_SCALE = 16.0f;          // |x| up to 4094 survives; both operands carry it, the epilogue divides by its square
+__device__ __forceinline__ void split2_f16(float x0, float x1, unsigned& h, unsigned& l) {
+    const float y0 = x0 * F16_SCALE, y1 = x1 * F16_SCALE;
+    const f16x2 hh = {(_Float16)y0, (_Float16)y1};
+    const f16x2 ll = {(_Float16)(y0 - (float)hh[0]), (_Float16)(y1 - (float)hh[1])};
+    h = __builtin_bit_cast(unsigned, hh);
+    l = __builtin_bit_cast(unsigned, ll);
+}
+
 // two fp32 values -> packed bf16 pair, round to nearest even (element 0 in the low half)
 __device__ __forceinline__ unsigned round2(float x0, float x1) {
     unsigned r;
@@ -182,6 +195,14 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
             *reinterpret_cast<u32x2*>(S + o) = u32x2{round2(s[0], s[1]), round2(s[2], s[3])};
             return;
         }
+        if (NPL == 2) {
+            unsigned ha, la, hb, lb;
+            split2_f16(s[0], s[1], ha, la);
+            split2_f16(s[2], s[3], hb, lb);
+            *reinterpret_cast<u32x2*>(S + o) = u32x2{ha, hb};
+            *reinterpret_cast<u32x2*>(S + P + o) = u32x2{la, lb};
+            return;
+        }
         unsigned h0, m0_, l0, h1, m1, l1;
         split2(s[0], s[1], h0, m0_, l0);
         split2(s[2], s[3], h1, m1, l1);
@@ -242,6 +263,15 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     f32x16 c = acc[mi][ni];
+                    if constexpr (NPL == 2) {   // fp16 x 2: h.l, l.h, h.h (l.l is below 2^-22)
+                        const f16x8 ah = __builtin_bit_cast(f16x8, a[0][mi]), al = __builtin_bit_cast(f16x8, a[NPL - 1][mi]);
+                        const f16x8 bh = __builtin_bit_cast(f16x8, b[0][ni]), bl = __builtin_bit_cast(f16x8, b[NPL - 1][ni]);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+                        acc[mi][ni] = c;
+                        continue;
+                    }
                     if (NPL == 3) {   // smallest terms first
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NPL - 2][mi], b[NPL - 2][ni], c, 0, 0, 0);   // m.m
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], b[NPL - 1][ni], c, 0, 0, 0);         // h.l
@@ -276,7 +306,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
                 const int m = m0 + wm * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
                 if (m >= d.M) continue;
                 float* c = Cb + (long)m * d.ldc + n;
-                const float v = acc[mi][ni][r] + bv;
+                const float v = acc[mi][ni][r] * (NPL == 2 ? 1.0f / (F16_SCALE * F16_SCALE) : 1.0f) + bv;
                 if (d.ksplit > 1) atomicAdd(c, v);
                 else if (d.flags & GEMM_ACCUM) *c += v;
                 else *c = v;
@@ -288,6 +318,7 @@ template <int BM, int BN, bool TA, bool TB>
 hipError_t launch_cfg(const GemmDesc& d, hipStream_t s) {
     dim3 grid(cdiv(d.N, BN), cdiv(d.M, BM), d.batch * d.ksplit);
     if (d.flags & GEMM_BF16) hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB, 1>), grid, dim3(256), 0, s, d);
+    else if (d.flags & GEMM_F16X2) hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB, 2>), grid, dim3(256), 0, s, d);
     else if ((d.diag & 16) && BM == 128 && BN == 128 && !TA && !TB)
         hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB, 3, (BM == 128 && BN == 128 && !TA && !TB)>), grid, dim3(256), 0, s, d);
     else hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB, 3>), grid, dim3(256), 0, s, d);

@@ -247,7 +247,7 @@ def tune(key, value):
     _capi.check(_capi.lib().ss_tune(key.encode(), int(value)))
 
 
-def gemm(a, b, bias=None, ta=False, tb=False, ksplit=1, out=None, bf16=False):
+def gemm(a, b, bias=None, ta=False, tb=False, ksplit=1, out=None, bf16=False, f16x2=False):
     """Test hook for the MFMA GEMM: C[M,N] = A(m,k) B(n,k) (+bias).  a: [M,K] or [K,M] if ta; b: [N,K] or [K,N] if tb."""
     lib = _capi.lib()
     M = a.shape[1] if ta else a.shape[0]
@@ -256,5 +256,5 @@ def gemm(a, b, bias=None, ta=False, tb=False, ksplit=1, out=None, bf16=False):
     assert (b.shape[0] if tb else b.shape[1]) == K
     c = torch.zeros(M, N, device=a.device) if out is None else out
     _capi.check(lib.ss_op_gemm(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(c), N, _ptr(bias), M, N, K,
-                               (1 if ta else 0) | (2 if tb else 0) | (8 if bf16 else 0), ksplit, _stream()))
+                               (1 if ta else 0) | (2 if tb else 0) | (8 if bf16 else 0) | (16 if f16x2 else 0), ksplit, _stream()))
     return c

@@ -171,22 +171,21 @@ def bench_gemm():
 
 def bench_gemm_diag():
     dev = 'cuda'
-    shapes = [('proj   NT 8192x4096x1024', 8192, 4096, 1024, False, False, 1), ('dW_ih  TN 2048x1024x8448', 2048, 1024, 8448, True, True, 4)]
+    shapes = [('proj   NT 8192x4096x1024', 8192, 4096, 1024, False, False, 1), ('conv   NT 8192x512x2560', 8192, 512, 2560, False, False, 1),
+              ('dX     NN 8448x1024x4096', 8448, 1024, 4096, False, True, 1), ('dW_ih  TN 2048x1024x8448', 2048, 1024, 8448, True, True, 4)]
     for name, M, N, K, ta, tb, ks in shapes:
         A = torch.randn((K, M) if ta else (M, K), device=dev)
-        Bm = torch.randn((K, N) if tb else (N, K), device=dev)
+        Bm = torch.randn((K, N) if tb else (N, K), device=dev) * 0.05
+        A[0, :7] = torch.tensor([1e-3, 3e-5, 1e-6, 2e-8, 100.0, -250.0, 0.0])       # small and large magnitudes in one reduction
         c = torch.zeros(M, N, device=dev)
         ref = ((A.t() if ta else A).double() @ (Bm if tb else Bm.t()).double())
-        for rnd in range(1):
-            for diag, what in [(0, 'full'), (0, 'full'), (32, 'no barriers'), (64, 'no split / LDS store'), (128, 'no global loads'), (256, 'fragment reads all to one address'),
-                               (192, 'no split, no loads'), (224, 'no split, loads, barriers'), (480, 'only fragment read issue + MFMA')]:
-                tune('gemm_diag', diag)
+        for rnd in range(2):
+            for f16 in (False, True):
                 c.zero_()
-                E.gemm(A, Bm, None, ta, tb, ks, out=c)
+                E.gemm(A, Bm, None, ta, tb, ks, out=c, f16x2=f16)
                 err = float((c.double() - ref).abs().max() / ref.abs().max())
-                t, tmin = timeit(lambda: E.gemm(A, Bm, None, ta, tb, ks, out=c), iters=7)
-                say(f'gemm {name} [{what:26s}]: {t:8.1f} us  {2.0 * M * N * K / t / 1e6:6.1f} TF  err {err:.1e}')
-    tune('gemm_diag', 0)
+                t, tmin = timeit(lambda: E.gemm(A, Bm, None, ta, tb, ks, out=c, f16x2=f16), iters=7)
+                say(f'gemm {name} [{"fp16 x 2 (3 MFMA)" if f16 else "bf16 x 3 (6 MFMA)":20s}]: {t:8.1f} us  {2.0 * M * N * K / t / 1e6:6.1f} TF  err {err:.1e}')
 
 
 def bench_step():
