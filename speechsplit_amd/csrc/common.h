@@ -38,6 +38,10 @@ struct GemmDesc {
     int flags;
     int diag;               // timing experiments only (gemm_f32.hip g_gemm_diag); 0 in production
     int ksplit;             // >1: split the reduction over blockIdx.z, atomically accumulate into C (C pre-zeroed or ACCUM)
+    // GEMM_F16X2 only: device words holding max|A| / max|B| (as produced by the kernels that wrote the operand); the kernel
+    // scales the operand by the power of two that brings this maximum into [128, 256).  Null: the fixed scale for O(1) data.
+    const float* amax_a;
+    const float* amax_b;
 };
 
 // C[b][m][n] (+)= sum_k A(m,k) * B(n,k) (+ bias[n]);  fp32 in, fp32 MFMA accumulate (exact fp32 fma chain)

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ stats, float* __restrict__ g_gamma,
                                                           float* __restrict__ g_beta, float* __restrict__ g_bias,
-                                                          int B, int T, int C) {
+                                                          unsigned* __restrict__ amax, int B, int T, int C) {
     __shared__ float red[256];
     __shared__ float g4[4];
     __shared__ float colred[3][16][64];
@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
     const float m1 = block_group_sum(s1, red, g4, tid) * inv_n;
     const float m2 = block_group_sum(s2, red, g4, tid) * inv_n;
     f32x4 dbias = {0.f, 0.f, 0.f, 0.f};
+    float amx = 0.f;
 #pragma unroll
     for (int it = 0; it < GN_MAXIT; ++it) {
         const int t = rg + it * 16;
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
             for (int j = 0; j < 4; ++j) {
                 o[j] = rstd * (dh[it][j] - m1 - xh[it][j] * m2);
                 dbias[j] += o[j];
+                amx = fmaxf(amx, fabsf(o[j]));
             }
             *reinterpret_cast<f32x4*>(db + (long)t * dy_ld) = o;
         }
@@ -158,6 +160,11 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
         colred[0][rg][l16 * 4 + j] = dgam[j];
         colred[1][rg][l16 * 4 + j] = dbet[j];
         colred[2][rg][l16 * 4 + j] = dbias[j];
+    }
+    if (amax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o));
+        if ((tid & 63) == 0) atomicMax(amax, __float_as_uint(amx));
     }
     __syncthreads();
     if (tid < 192) {
@@ -432,11 +439,11 @@ hipError_t gn_relu_fwd(const float* x, long x_ld, long x_bs, float* y, long y_ld
 }
 
 hipError_t gn_relu_bwd(const float* x, long x_ld, long x_bs, float* dy, long dy_ld, long dy_bs, const float* gamma,
-                       const float* beta, const float* stats, float* g_gamma, float* g_beta, float* g_bias, int B, int T, int C,
-                       hipStream_t s) {
+                       const float* beta, const float* stats, float* g_gamma, float* g_beta, float* g_bias, float* amax, int B,
+                       int T, int C, hipStream_t s) {
     if (C % 64 != 0 || T > 16 * GN_MAXIT) return hipErrorInvalidValue;
     hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(C / 64, B), dim3(256), 0, s, x, x_ld, x_bs, dy, dy_ld, dy_bs, gamma, beta,
-                       stats, g_gamma, g_beta, g_bias, B, T, C);
+                       stats, g_gamma, g_beta, g_bias, reinterpret_cast<unsigned*>(amax), B, T, C);
     return hipGetLastError();
 }
 

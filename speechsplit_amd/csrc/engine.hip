@@ -21,6 +21,8 @@ namespace ss {
 extern int g_lstm_nw, g_lstm_g, g_lstm_mode, g_gemm_bk, g_gemm_want, g_gemm_diag, g_seq_prio, g_gemm_mode;
 int g_fwd_f16x2 = 1;   // 1: forward contractions (operands bounded by construction: mel, one-hot, GroupNorm/ReLU outputs, |h| < 1, weights)
                        //    use the fp16 x 2 split (3 MFMAs) instead of bf16 x 3 (6 MFMAs); gradients keep bf16 x 3 (their range is not bounded)
+int g_bwd_f16x2 = 1;   // 1: the decoder's and the conv trunk's gradient GEMMs also use fp16 x 2: the gradient operand is scaled by the power
+                       //    of two its producer kernel measured (max |value| of the slab), the activation / weight operand by the fixed one
 int g_overlap = 1;     // 1: weight-gradient GEMMs on the side stream
 int g_side_prio = 0;   // 1: create the side stream with the lowest priority (read at ss_bind).  Measured: 2.3x SLOWER
                        //    (35 ms vs 14.8 ms per step): the low-priority queue starves behind 768 tiny step launches.
@@ -62,6 +64,7 @@ struct ConvBlk {
     int Ci = 0, Co = 0, Cp = 0;
     long w = 0, b = 0, ga = 0, be = 0;     // arena offsets
     float *wf = nullptr, *wb = nullptr, *gp = nullptr, *cout = nullptr, *stats = nullptr;
+    int amax_i = -1;                       // slot in ss_engine::amax
     bool need_dx = false;
 };
 
@@ -87,6 +90,7 @@ struct LstmBlk {
     unsigned* sync_f(int l) const { return (unsigned*)zf + 128 * l; }
     unsigned* sync_b(int l) const { return (unsigned*)zb + 128 * l; }
     void* hf_l(int l) const { return zf + 512L * L + hf_bytes * l; }
+    int amax0 = -1;                        // first slot in ss_engine::amax (one per layer) when the block's gradient GEMMs may use fp16 x 2
     void* px = nullptr;                    // backward exchange tiles (shared by the layers, needs no initial state)
     float* dmid[2] = {nullptr, nullptr};   // gradient slabs of inner layer outputs [B,TP,2H]
     bool big() const { return H > 32; }
@@ -131,6 +135,7 @@ struct ss_engine {
     float *d_o1 = nullptr, *d_o2 = nullptr, *d_ot = nullptr;
     float *out_slab = nullptr, *d_out_slab = nullptr;
     float* gp_all = nullptr;               // packed conv weight-gradient images (all blocks)
+    float* amax = nullptr;                 // [16] max |gradient| of the slabs the fp16 x 2 gradient GEMMs read: decoder layers 0..2, then the 7 convs
     long gp_bytes = 0;
     float *loss_part = nullptr;
     int* qidx = nullptr;
@@ -253,6 +258,7 @@ void build_table(ss_engine* e) {
         e->head_b = tb.add("decoder.linear_projection.linear_layer.bias", h.dim_f0);
         e->CE = h.dim_enc_3;
     }
+    e->ld.amax0 = 0;                      // decoder layers: slots 0..2 of ss_engine::amax (the convs follow from 3)
     e->arena = align4(tb.off);
     e->f0p = (int)align4(h.dim_f0);
     for (int i = 0; i < 3; ++i) {
@@ -358,8 +364,11 @@ long ss_engine::carve(int B, int T, bool assign) {
         float* p = (float*)take(tot * 4);
         gp_all = p;
         gp_bytes = tot * 4;
+        amax = (float*)take(16 * 4);
+        int slot = 3;
         for (ConvBlk* cb : all) {
             cb->gp = cb->Co ? p : nullptr;
+            cb->amax_i = slot++;
             p += align4((long)cb->Co * 5 * cb->Cp);
         }
     }
@@ -507,8 +516,9 @@ int conv_block_fwd(ss_engine* e, ConvBlk& cb, Slab x, Slab y, hipStream_t s) {
 int conv_block_bwd(ss_engine* e, ConvBlk& cb, Slab dy, Slab x, Slab dx, hipStream_t s) {
     const int B = e->curB, T = e->curT;
     const long TP = T + 2 * HALO, R = (long)B * TP;
+    float* am = (g_bwd_f16x2 && cb.amax_i >= 0) ? e->amax + cb.amax_i : nullptr;
     HIPCHK(gn_relu_bwd(cb.cout, cb.Co, TP * cb.Co, dy.p, dy.ld, TP * dy.ld, e->P + cb.ga, e->P + cb.be, cb.stats,
-                       e->G + cb.ga, e->G + cb.be, e->G + cb.b, B, T, cb.Co, s));
+                       e->G + cb.ga, e->G + cb.be, e->G + cb.b, am, B, T, cb.Co, s));
     // weight gradient: one reduction over every slab row (halo rows of dy are zero); cb.gp was zeroed by zero_conv_grads
     GemmDesc d{};
     d.A = {dy.p + 2 * dy.ld, dy.ld, 0, 0, 0};
@@ -519,7 +529,8 @@ int conv_block_bwd(ss_engine* e, ConvBlk& cb, Slab dy, Slab x, Slab dx, hipStrea
     d.N = 5 * cb.Cp;
     d.K = (int)(R - 4);
     d.batch = 1;
-    d.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM;
+    d.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM | (am ? GEMM_F16X2 : 0);
+    d.amax_a = am;                                  // gradient operand: measured scale; the block input is O(1)
     d.ksplit = pick_ksplit(d.M, d.N, d.K);
     GEMM(d);
     HIPCHK(conv_unpack_grad(cb.gp, cb.Co, cb.Ci, cb.Cp, e->G + cb.w, s));
@@ -535,6 +546,8 @@ int conv_block_bwd(ss_engine* e, ConvBlk& cb, Slab dy, Slab x, Slab dx, hipStrea
         g.K = 5 * cb.Co;
         g.batch = B;
         g.ksplit = 1;
+        g.flags = am ? GEMM_F16X2 : 0;
+        g.amax_a = am;
         GEMM(g);
     }
     return 0;
@@ -662,7 +675,7 @@ int lstm_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
 
 // d_top: gradient slab of the last layer's output [B,TP,2H]; x: forward input; dx: input-gradient view or null
 // weight / bias gradients of one layer from its finished pre-activation gradient slab (full batch, flat over all rows)
-int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, hipStream_t ws) {
+int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am, hipStream_t ws) {
     const int B = e->curB, T = e->curT, H = lb.H;
     const long TP = T + 2 * HALO, R = (long)B * TP;
     const int In = lb.in_of(l);
@@ -680,7 +693,8 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, hipStream_t ws)
         a.N = In;
         a.K = (int)R;
         a.batch = 1;
-        a.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM;
+        a.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM | (am ? GEMM_F16X2 : 0);
+        a.amax_a = am;                              // gradient slab: measured scale; the layer input is O(1)
         a.ksplit = pick_ksplit(a.M, a.N, a.K);
         GEMM_ON(a, ws);
         // dW_hh[n][k] = sum_r dG[r][n] * h_prev[r][k];  h_prev = out one row earlier (fwd) / later (reverse)
@@ -693,7 +707,8 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, hipStream_t ws)
         h.N = H;
         h.K = (int)(R - 1);
         h.batch = 1;
-        h.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM;
+        h.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM | (am ? GEMM_F16X2 : 0);
+        h.amax_a = am;
         h.ksplit = pick_ksplit(h.M, h.N, h.K);
         GEMM_ON(h, ws);
         HIPCHK(colsum_acc(dGd, 8L * H, (int)R, 4 * H, e->G + pd.bih, ws));
@@ -703,7 +718,7 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, hipStream_t ws)
 }
 
 // input gradient of one layer for the slab rows [r0, r0 + nr):  dX = dG . W_ih  (both directions accumulate)
-int lstm_input_grad(ss_engine* e, LstmBlk& lb, int l, Slab dxi, long r0, long nr, hipStream_t st) {
+int lstm_input_grad(ss_engine* e, LstmBlk& lb, int l, Slab dxi, long r0, long nr, const float* am, hipStream_t st) {
     // dX[r][k] = sum over both directions' 8H gate units of dG[r][n] * W_ih[n][k]: ONE GEMM against the stacked weights
     // (lstm_prep).  A narrow input (the decoder's 164 columns) is cut along the reduction so the launch still fills the chip.
     const int H = lb.H, In = lb.in_of(l);
@@ -716,7 +731,8 @@ int lstm_input_grad(ss_engine* e, LstmBlk& lb, int l, Slab dxi, long r0, long nr
     g.N = In;
     g.K = 8 * H;
     g.batch = 1;
-    g.flags = GEMM_TB;
+    g.flags = GEMM_TB | (am ? GEMM_F16X2 : 0);
+    g.amax_a = am;                                  // gradient slab: measured scale; the stacked weights are O(1)
     g.ksplit = 1;
     const long tiles = (long)cdiv(g.M, 128) * cdiv(g.N, 64);
     if (tiles < 512 && g.K >= 1024 && dxi.ld == In) {          // split-K needs a zeroed, dense C
@@ -743,6 +759,8 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
         Slab dxi = l == 0 ? dx : Slab{lb.dmid[l & 1], 2L * H};
         float* dG = lb.gates[l];
         hipStream_t ws = s;
+        // fp16 x 2 gradient GEMMs need the slab's maximum, which only the persistent kernel measures
+        float* am = (persist && g_bwd_f16x2 && lb.amax0 >= 0) ? e->amax + lb.amax0 + l : nullptr;
         if (lb.big()) {
             for (int c = 0; c < nch && !persist; ++c) {
                 const long half = 2L * (((ch[c].nb + 15) / 16) * 16) * 4 * H;
@@ -751,7 +769,7 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
             // persistent: start state zeroed by backward_decoder
             if (persist)
                 HIPCHK(lstm_seq_bwd(dG, e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.px, dcur, lb.csave[l], lb.sync_b(l),
-                                    B, T, H, false, s));
+                                    am, B, T, H, false, s));
             for (int st = 0; st < T && !persist; ++st)
                 for (int c = 0; c < nch; ++c) {
                     const long r0 = (long)ch[c].b0 * TP;
@@ -773,8 +791,8 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
         // input gradient first (the next layer's recurrence needs it), per chain on its own rows
         if (dxi.p)
             for (int c = 0; c < nch; ++c)
-                CHK(lstm_input_grad(e, lb, l, dxi, (long)ch[c].b0 * TP, nch == 2 ? (long)ch[c].nb * TP : R, ch[c].st));
-        CHK(lstm_weight_grads(e, lb, l, xi, ws));
+                CHK(lstm_input_grad(e, lb, l, dxi, (long)ch[c].b0 * TP, nch == 2 ? (long)ch[c].nb * TP : R, am, ch[c].st));
+        CHK(lstm_weight_grads(e, lb, l, xi, am, ws));
         dcur = dxi.p;
     }
     if (nch == 2) CHK(fork_join(e, ch[1].st, s));
@@ -891,6 +909,7 @@ int backward_decoder(ss_engine* e, hipStream_t s) {
     const int B = e->curB, T = e->curT;
     const long TP = T + 2 * HALO, R = (long)B * TP;
     HIPCHK(hipMemsetAsync(e->G, 0, e->arena * 4, s));
+    HIPCHK(hipMemsetAsync(e->amax, 0, 16 * 4, s));
     // fragment-major W_hh^T of the decoder recurrences (overwrites the forward layout, no longer needed), beside the head
     const bool par = e->side2 && g_overlap;
     hipStream_t b2 = par ? e->side2 : s;
@@ -1464,6 +1483,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "gemm_want" && value >= 1) g_gemm_want = value;
     else if (k == "gemm_mode" && (value == 0 || value == 1)) g_gemm_mode = value;
     else if (k == "fwd_f16x2" && (value == 0 || value == 1)) g_fwd_f16x2 = value;
+    else if (k == "bwd_f16x2" && (value == 0 || value == 1)) g_bwd_f16x2 = value;
     else if (k == "gemm_diag" && value >= 0 && value < 512) g_gemm_diag = value;
     else return fail("ss_tune: unknown key or bad value: " + k);
     ++g_tune_epoch;
@@ -1502,7 +1522,7 @@ int ss_op_lstm_bwd(float* gates, const float* whh_f, const float* whh_b, const f
         float* dc = gf + 2 * half;
         const long xbytes = lstm_seq_xbytes(B, H, true);
         if (g_persist && lstm_seq_supported(B, H) && scratch_floats * 4 >= xbytes + 512) {     // [exchange tiles][counters]
-            HIPCHK(lstm_seq_bwd(gates, whh_f, whh_b, scratch, d_out, csave, (unsigned*)((char*)scratch + xbytes), B, T, H, true, s));
+            HIPCHK(lstm_seq_bwd(gates, whh_f, whh_b, scratch, d_out, csave, (unsigned*)((char*)scratch + xbytes), nullptr, B, T, H, true, s));
             return 0;
         }
         HIPCHK(lstm_pack_w(whh_f, whh_b, scratch, H, 1, s));

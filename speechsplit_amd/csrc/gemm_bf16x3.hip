@@ -43,9 +43,17 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned
 // 22 significand bits for values whose residual stays in fp16's normal range, an absolute floor of 2^-25 / s below it.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-constexpr float F16_SCALE = 16.0f;          // |x| up to 4094 survives; both operands carry it, the epilogue divides by its square
-__device__ __forceinline__ void split2_f16(float x0, float x1, unsigned& h, unsigned& l) {
-    const float y0 = x0 * F16_SCALE, y1 = x1 * F16_SCALE;
+constexpr float F16_SCALE = 16.0f;          // operands bounded by construction: |x| up to 4094 survives
+// operand with a measured maximum m: the power of two that brings m into [128, 256) (256x headroom below fp16's 65504),
+// capped at 2^60 so that an all-zero / denormal tensor cannot produce an infinite scale
+__device__ __forceinline__ float pow2_scale(float m) {
+    const int e = (int)((__float_as_uint(m) >> 23) & 0xFFu);
+    int se = 261 - e;
+    se = se < 1 ? 1 : (se > 187 ? 187 : se);
+    return __uint_as_float((unsigned)se << 23);
+}
+__device__ __forceinline__ void split2_f16(float x0, float x1, float scale, unsigned& h, unsigned& l) {
+    const float y0 = x0 * scale, y1 = x1 * scale;
     const f16x2 hh = {(_Float16)y0, (_Float16)y1};
     const f16x2 ll = {(_Float16)(y0 - (float)hh[0]), (_Float16)(y1 - (float)hh[1])};
     h = __builtin_bit_cast(unsigned, hh);
@@ -141,6 +149,9 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
     for (int i = 0; i < NB; ++i) setup(d.B, Bb, TB, n0, d.N, BN, tid + i * 256, pb[i], wb[i], okb[i]);
 
     typedef f32x4 Slot;
+    // fp16 x 2 only: per-operand power-of-two scales (measured maximum or the fixed one), undone in the epilogue
+    const float sc_a = NPL == 2 ? (d.amax_a ? pow2_scale(*d.amax_a) : F16_SCALE) : 1.0f;
+    const float sc_b = NPL == 2 ? (d.amax_b ? pow2_scale(*d.amax_b) : F16_SCALE) : 1.0f;
     // full: the whole k-tile lies inside [kbeg, kend), so the load needs no predicate at all (rows / columns past the
     // matrix edge read row / column 0: their products land in accumulator entries the epilogue never stores).
     auto fetch = [&](const Operand& op, bool T, const float*& p, int& w, bool ok, int kpos, bool full) -> Slot {
@@ -187,7 +198,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
         }
     };
     // split the prefetched fp32 values and write the three bf16 planes
-    auto sstore_one = [&](unsigned char* S, int P, bool T, int BX, int f, const Slot& s) {
+    auto sstore_one = [&](unsigned char* S, int P, bool T, int BX, int f, const Slot& s, float scale) {
         const int row = T ? f % BX : f / 8;
         const int k = T ? (f / BX) * 4 : (f % 8) * 4;
         const int o = lds_off(row, k);
@@ -197,8 +208,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
         }
         if (NPL == 2) {
             unsigned ha, la, hb, lb;
-            split2_f16(s[0], s[1], ha, la);
-            split2_f16(s[2], s[3], hb, lb);
+            split2_f16(s[0], s[1], scale, ha, la);
+            split2_f16(s[2], s[3], scale, hb, lb);
             *reinterpret_cast<u32x2*>(S + o) = u32x2{ha, hb};
             *reinterpret_cast<u32x2*>(S + P + o) = u32x2{la, lb};
             return;
@@ -212,9 +223,9 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
     };
     auto sstore = [&]() {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) sstore_one(As, PA, TA, BM, tid + i * 256, ra[i]);
+        for (int i = 0; i < NA; ++i) sstore_one(As, PA, TA, BM, tid + i * 256, ra[i], sc_a);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) sstore_one(Bs, PB, TB, BN, tid + i * 256, rb[i]);
+        for (int i = 0; i < NB; ++i) sstore_one(Bs, PB, TB, BN, tid + i * 256, rb[i], sc_b);
     };
 
     f32x16 acc[MI][NI];
@@ -294,6 +305,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
 
     float* Cb = d.C + (long)batch * d.cstride;
     const bool add_bias = d.bias != nullptr && ks == 0;
+    const float unscale = (1.0f / sc_a) * (1.0f / sc_b);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -306,7 +318,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
                 const int m = m0 + wm * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
                 if (m >= d.M) continue;
                 float* c = Cb + (long)m * d.ldc + n;
-                const float v = acc[mi][ni][r] * (NPL == 2 ? 1.0f / (F16_SCALE * F16_SCALE) : 1.0f) + bv;
+                const float v = acc[mi][ni][r] * unscale + bv;
                 if (d.ksplit > 1) atomicAdd(c, v);
                 else if (d.flags & GEMM_ACCUM) *c += v;
                 else *c = v;

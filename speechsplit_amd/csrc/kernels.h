@@ -38,9 +38,10 @@ hipError_t gn_relu_fwd(const float* x, long x_ld, long x_bs, float* y, long y_ld
                        const float* beta, float* stats /*[B, C/16, 2] mean, rstd*/, int B, int T, int C, hipStream_t s);
 // dy (grad of the ReLU output) is replaced in place by the grad of the GroupNorm input (= conv output).
 // g_gamma / g_beta / g_bias [C]: every utterance's d_gamma, d_beta, d_convbias are ACCUMULATED here (f32 atomics).
+// amax (nullable): receives max |conv-output gradient| written, as for lstm_seq_bwd.
 hipError_t gn_relu_bwd(const float* x, long x_ld, long x_bs, float* dy, long dy_ld, long dy_bs, const float* gamma,
-                       const float* beta, const float* stats, float* g_gamma, float* g_beta, float* g_bias, int B, int T, int C,
-                       hipStream_t s);
+                       const float* beta, const float* stats, float* g_gamma, float* g_beta, float* g_bias, float* amax, int B,
+                       int T, int C, hipStream_t s);
 // out[c] += sum_r in[r*ld + c]   (atomic accumulate)
 hipError_t colsum_acc(const float* in, long ld, int R, int C, float* out, hipStream_t s);
 hipError_t copy_rows(const float* src, long s_ld, long s_bs, float* dst, long d_ld, long d_bs, int B, int T, int C,
@@ -111,7 +112,9 @@ bool lstm_seq_supported(int B, int H);
 long lstm_seq_xbytes(int B, int H, bool backward);
 hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, float* out, float* csave,
                         unsigned* sync, int B, int T, int H, bool zero_state, hipStream_t s);
+// amax (nullable): device word that receives max |pre-activation gradient| written (atomic max of the float's bit pattern;
+// zero it first) -- the scale the fp16 x 2 GEMMs that consume the gradient slab need
 hipError_t lstm_seq_bwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, const float* d_out,
-                        const float* csave, unsigned* sync, int B, int T, int H, bool zero_state, hipStream_t s);
+                        const float* csave, unsigned* sync, float* amax, int B, int T, int H, bool zero_state, hipStream_t s);
 
 }  // namespace ss
