@@ -171,14 +171,15 @@ def main():
 
 def gemm_roofline(eng, B, T, precision='f32'):
     """Roofline of the dominant kernel, measured INSIDE the timed region: the engine brackets every launch of the decoder
-    input-projection GEMM of layers 1-2 (gemm_bf16x3_kernel<128,128,NT>; per launch M = B*T rows, N = 4096 = both directions, K = 1024, fp32
-    in / fp32 out / fp32 accumulate) with hipEvents on its launch stream (ss_profile in include/speechsplit_amd.h).
-    achieved = algorithmic FLOPs of one launch (2*M*N*K) / mean launch duration.
+    input-projection GEMM of layers 1-2 (gemm_bf16x3_kernel<128,128,NT>; per launch M = B*T rows, N = 4096 = both directions,
+    K = 1024, fp32 in / fp32 out / fp32 accumulate) with hipEvents on its launch stream (ss_profile in
+    include/speechsplit_amd.h).  achieved = algorithmic FLOPs of one launch (2*M*N*K) / mean launch duration.
 
-    The kernel forms every fp32 product from an exact 3-way bf16 split of both operands: 6 v_mfma_f32_32x32x16_bf16 per
-    fp32 multiply-add (the 3 lowest-order cross terms are dropped, error <= fp32's own rounding).  Its pipe is therefore the
-    dense bf16 MFMA pipe (2.5 PFLOP/s) and its ceiling in algorithmic fp32 FLOP/s is 2500 / 6 = 416.7 TFLOP/s; the fp32 MFMA
-    peak (157.3 TFLOP/s) is reported beside it."""
+    The kernel forms every fp32 product on the 16-bit matrix pipe (dense peak 2.5 PFLOP/s for fp16 and bf16 alike) from a
+    split of both operands: forward contractions, whose operands are bounded by construction, use fp16 x 2 = 3
+    v_mfma_f32_32x32x16_f16 per multiply-add (22 significand bits relative to the operand's maximum); the general path is
+    bf16 x 3 = 6 MFMAs.  The ceiling in algorithmic fp32 FLOP/s is therefore 2500 / 3 = 833 TFLOP/s for this kernel; the
+    fp32 MFMA peak (157.3 TFLOP/s) is reported beside it."""
     n, us, flops = eng.profile(False)
     if n == 0:
         return None
@@ -197,11 +198,12 @@ def gemm_roofline(eng, B, T, precision='f32'):
         return {'bound': 'mfma', 'kernel': 'gemm_bf16x3_kernel<128,128,NT,1 plane> (decoder input projection, layers 1-2; bf16 operands, fp32 accumulate)',
                 'achieved': round(ach, 2), 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
                 'launches_timed': n, 'flops_per_launch': flops, 'us_per_launch': round(sec * 1e6, 2), 'traffic': None}
-    peak = PEAK_BF16_MFMA_TFLOPS / 6.0
-    return {'bound': 'mfma', 'kernel': 'gemm_bf16x3_kernel<128,128,NT> (decoder input projection, layers 1-2; fp32 via 6 bf16 MFMAs per product)',
+    products = 3
+    peak = PEAK_BF16_MFMA_TFLOPS / products
+    return {'bound': 'mfma', 'kernel': 'gemm_bf16x3_kernel<128,128,NT,fp16x2> (decoder input projection, layers 1-2; fp32 via 3 fp16 MFMAs per product)',
             'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-            'peak_basis': 'dense bf16 MFMA 2500 TFLOP/s / 6 MFMA products per fp32 multiply-add',
-            'mfma_tflops_executed': round(6 * ach, 1), 'fp32_mfma_peak': PEAK_F32_MFMA_TFLOPS,
+            'peak_basis': 'dense 16-bit MFMA 2500 TFLOP/s / 3 MFMA products per fp32 multiply-add',
+            'mfma_tflops_executed': round(products * ach, 1), 'fp32_mfma_peak': PEAK_F32_MFMA_TFLOPS,
             'vs_fp32_mfma_peak': round(ach / PEAK_F32_MFMA_TFLOPS, 4),
             'launches_timed': n, 'flops_per_launch': flops, 'us_per_launch': round(sec * 1e6, 2), 'traffic': traffic}
 

@@ -135,7 +135,9 @@ int ss_op_lstm_fwd(float* gates_dev, const float* whh_f_dev, const float* whh_b_
 int ss_op_lstm_bwd(float* gates_dev, const float* whh_f_dev, const float* whh_b_dev, const float* d_out_dev,
                    const float* csave_dev, float* scratch_dev, long scratch_floats, int B, int T, int H, void* stream);
 /* tuning knobs (process-global): "lstm_nw" 4|8|16, "lstm_g" 0..16, "gemm_bk" 16|32, "gemm_want" >= 1,
- * "overlap" 0|1, "graph" 0|1, "persist" 0|1, "split" 0|1; "lstm_mode" / "gemm_diag" are timing experiments that produce wrong results */
+ * "overlap" 0|1, "graph" 0|1, "persist" 0|1, "split" 0|1, "gemm_mode" 0 (fp32 MFMA) | 1 (split arithmetic on the 16-bit pipe),
+ * "fwd_f16x2" / "bwd_f16x2" 0|1 (fp16 x 2 instead of bf16 x 3 for the forward / the scaled gradient contractions);
+ * "lstm_mode" / "gemm_diag" / "seq_prio" > 1 are timing experiments that produce wrong results */
 int ss_tune(const char* key, int value);
 /* Arithmetic of the contractions (convolutions, LSTM input projections, all weight / input gradients, head).
  * SS_PRECISION_F32 (default): fp32-grade products (exact 3-way bf16 split, 6 MFMAs) -- the 1e-4 parity mode.

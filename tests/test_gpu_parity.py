@@ -280,6 +280,45 @@ def test_gemm_bf16_mode(E):
             assert 1e-4 < rel(c, ref32) < 1e-2
 
 
+def test_gemm_fp16x2_mode(E):
+    """GEMM_F16X2 (forward contractions, and gradient contractions with a measured scale): fp16 x 2 split, 3 MFMAs, fp32
+    accumulation.  fp32-grade against fp64 also when one reduction mixes magnitudes from 2e-8 to 250."""
+    g = torch.Generator().manual_seed(6)
+    for M, N, K, ta, tb in [(256, 512, 400, False, False), (384, 256, 1024, False, True), (1024, 512, 2560, True, True)]:
+        A = torch.randn((K, M) if ta else (M, K), generator=g)
+        Bm = torch.randn((K, N) if tb else (N, K), generator=g) * 0.05
+        A.view(-1)[:7] = torch.tensor([1e-3, 3e-5, 1e-6, 2e-8, 100.0, -250.0, 0.0])
+        ref = (A.t() if ta else A).double() @ (Bm if tb else Bm.t()).double()
+        for ks in (1, 4):
+            c = E.gemm(A.cuda(), Bm.cuda(), None, ta, tb, ks, f16x2=True)
+            assert rel(c, ref) < 5e-6, (M, N, K, ta, tb, ks)
+
+
+def test_gradient_scale_invariance_of_fp16x2(E):
+    """The gradient GEMMs scale their gradient operand by the power of two measured by the producing kernel, so the size of
+    the incoming gradient must not matter: backward of d_out * 2^-30 and of d_out * 2^20, divided back, equals backward of d_out
+    (a fixed fp16 scale would flush the first to zero and overflow the second)."""
+    B, T = 4, 192
+    hp = W.default_hparams(max_len_pad=T)
+    eng = get_engine(E, 'G3', T, 8)
+    eng.load_weights(W.make_weights('G3', hp, 2))
+    mel, f0, emb, lens = synth_batch(19, B, T, 96)
+    onehot = torch.from_numpy(interp_np.onehot(interp_np.quantize_f0(f0[:, :, 0].numpy())))
+    x_f0 = torch.cat((mel, onehot), -1)
+    draws = stack_draws(draws_for(20, B, 3))
+    d_out = torch.randn(B, T, 80, generator=torch.Generator().manual_seed(3))
+    got = {}
+    for gs in (1.0, 2.0 ** -30, 2.0 ** 20):
+        eng.g3_forward(x_f0, mel, emb, draws, training=True)
+        eng.g3_backward(d_out * gs)
+        got[gs] = {n: v.double().cpu() / gs for n, v in eng.grad_views().items()}
+    eng.check()
+    for gs in (2.0 ** -30, 2.0 ** 20):
+        for n, v in got[1.0].items():
+            assert torch.isfinite(got[gs][n]).all(), (gs, n)
+            assert rel(got[gs][n], v) < 1e-5, (gs, n)
+
+
 def test_bf16_precision_train_step(E):
     """BASELINE configs 2-4 name bf16.  ss_set_precision(BF16) rounds the operands of every contraction to bf16 (fp32
     accumulate, fp32 storage / recurrent state / GroupNorm / Adam).  Stated bounds against the fp32 reference fixture and

@@ -16,6 +16,6 @@ for M, N, K, ta, tb, ks in shapes:
     B = torch.randn((K, N) if tb else (N, K), device='cuda')
     c = torch.zeros(M, N, device='cuda')
     for _ in range(4):
-        E.gemm(A, B, None, ta, tb, ks, out=c)
+        E.gemm(A, B, None, ta, tb, ks, out=c, f16x2=True)      # the variant the training step runs (fp16 x 2; fixed scale here)
     torch.cuda.synchronize()
 print('ok')
