@@ -94,6 +94,48 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& fh, bf16x8& 
     fl = __builtin_bit_cast(bf16x8, L4);
 }
 
+// fp16 x 2 split (forward recurrence: |h| < 1 and the weights are bounded, so fixed power-of-two scales are safe):
+// y = scale * x = h + l, h = fp16(y) to nearest, l = fp16(y - h): 22 significand bits where the residual is a normal fp16
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float HSCALE = 16384.0f;      // hidden state: |h| < 1  ->  below 2^14
+constexpr float WSCALE = 16.0f;         // recurrent weights: up to 4094 in magnitude survive
+__device__ __forceinline__ void split1_f16(float y, unsigned& h, unsigned& l) {
+    const _Float16 hh = (_Float16)y;
+    const _Float16 ll = (_Float16)(y - (float)hh);
+    h = (unsigned)__builtin_bit_cast(unsigned short, hh);
+    l = (unsigned)__builtin_bit_cast(unsigned short, ll);
+}
+__device__ __forceinline__ void split8_f16(const float (&x)[8], float scale, f16x8& fh, f16x8& fl) {
+    u32x4 H4, L4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned h0, l0, h1, l1;
+        split1_f16(x[2 * i] * scale, h0, l0);
+        split1_f16(x[2 * i + 1] * scale, h1, l1);
+        H4[i] = h0 | (h1 << 16);
+        L4[i] = l0 | (l1 << 16);
+    }
+    fh = __builtin_bit_cast(f16x8, H4);
+    fl = __builtin_bit_cast(f16x8, L4);
+}
+__device__ __forceinline__ f32x4 mfma3(const f16x8 (&a)[2], const f16x8 (&b)[2], f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[1], acc, 0, 0, 0);     // h.l
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], b[0], acc, 0, 0, 0);     // l.h
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[0], acc, 0, 0, 0);     // h.h   (l.l is below 2^-22)
+    return acc;
+}
+__device__ __forceinline__ void load2x2_sc1(const unsigned char* p0, const unsigned char* p1, u32x4 (&r)[2][2]) {
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off sc1\n\t"
+        "global_load_dwordx4 %1, %5, off sc1\n\t"
+        "global_load_dwordx4 %2, %4, off offset:1024 sc1\n\t"
+        "global_load_dwordx4 %3, %5, off offset:1024 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[1][0]), "=&v"(r[1][1])
+        : "v"(p0), "v"(p1)
+        : "memory");
+}
+
 // N 16-byte write-through-coherent loads 1 KiB apart from each base, issued and waited for inside ONE asm statement:
 // hipcc does not track asm loads, so the destination registers must not be visible to it before the data has landed.
 __device__ __forceinline__ void load2x3_sc1(const unsigned char* p0, const unsigned char* p1, const unsigned char* p2, u32x4 (&r)[2][3]) {
@@ -162,30 +204,27 @@ __device__ __forceinline__ int group_locality(unsigned* cnt, unsigned* mask, uns
     return (m & (m - 1)) == 0 ? 1 : 0;
 }
 
-// Exchange buffer ("xbuf"): what one group hands from step to step, stored as the three bf16 pieces of every value in the
-// A-fragment order of v_mfma_f32_16x16x32_bf16, so a consumer wave's loads are whole 1 KiB fragments and nobody re-splits:
-//     [2 ping-pong][2 dir][nbt][3 pieces][KC k-chunks of 32][64 lanes][8 bf16]        lane = 16 * (k % 32 / 8) + (b % 16)
-// KC = H/32 for h(t) (forward), 4H/32 for da(t) (backward).  Byte offset helpers:
-__device__ __forceinline__ long xb_half(int nbt, int KC) { return 2L * nbt * 3 * KC * 1024; }
-__device__ __forceinline__ long xb_group(int dir, int nbt, int bt, int KC) { return ((long)dir * nbt + bt) * 3 * KC * 1024; }
+// Forward exchange buffer ("xbuf"): h(t) of one group, stored as the two fp16 pieces of every value in the A-fragment
+// order of v_mfma_f32_16x16x32_f16, so a consumer wave's loads are whole 1 KiB fragments and nobody re-splits:
+//     [2 ping-pong][2 dir][nbt][2 pieces][KC = H/32 k-chunks][64 lanes][8 fp16]        lane = 16 * (k % 32 / 8) + (b % 16)
+__device__ __forceinline__ long xb_half(int nbt, int KC) { return 2L * nbt * 2 * KC * 1024; }
+__device__ __forceinline__ long xb_group(int dir, int nbt, int bt, int KC) { return ((long)dir * nbt + bt) * 2 * KC * 1024; }
 
 // one lane's bf16 pieces of value (b % 16 = bi, k) go to chunk k/32, lane 16*(k%32/8)+bi, element k%8.  Two lanes with
 // adjacent k (even, odd) combine their 16-bit pieces so that the even one stores whole dwords (write-through).
 __device__ __forceinline__ void xb_store(unsigned char* xb_plane0, long plane_stride, int k, int bi, float v, bool local) {
-    unsigned h, m, l;
-    split1(v, h, m, l);
-    const unsigned ph = __shfl_xor((int)h, 1), pm = __shfl_xor((int)m, 1), pl = __shfl_xor((int)l, 1);
+    unsigned h, l;
+    split1_f16(v * HSCALE, h, l);
+    const unsigned ph = __shfl_xor((int)h, 1), pl = __shfl_xor((int)l, 1);
     if ((k & 1) == 0) {
         unsigned char* q = xb_plane0 + (long)(k >> 5) * 1024 + ((((k & 31) >> 3) * 16 + bi) << 4) + ((k & 7) << 1);
         if (local) {                                   // group on one XCD: ordinary stores reach the shared L2
             *reinterpret_cast<unsigned*>(q) = h | (ph << 16);
-            *reinterpret_cast<unsigned*>(q + plane_stride) = m | (pm << 16);
-            *reinterpret_cast<unsigned*>(q + 2 * plane_stride) = l | (pl << 16);
+            *reinterpret_cast<unsigned*>(q + plane_stride) = l | (pl << 16);
             return;
         }
         __hip_atomic_store(reinterpret_cast<unsigned*>(q), h | (ph << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(reinterpret_cast<unsigned*>(q + plane_stride), m | (pm << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(reinterpret_cast<unsigned*>(q + 2 * plane_stride), l | (pl << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<unsigned*>(q + plane_stride), l | (pl << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -216,9 +255,9 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
     const bool local = s_ok == 1 || (diag & 32);
     __syncthreads();                                       // s_ok is reused by the step loop
 
-    // this wave's slice of W_hh as bf16 pieces, resident in registers for the whole sequence:
+    // this wave's slice of W_hh as fp16 pieces, resident in registers for the whole sequence:
     // B fragment of gate g, k-step ks: lane holds W_hh[g*H + jt*16 + li][(w*KS + ks)*32 + 8*lq .. +7]
-    bf16x8 bw[4][KS][3];
+    f16x8 bw[4][KS][2];
     {
         const float* W = dir == 0 ? whh_f : whh_b;
 #pragma unroll
@@ -228,7 +267,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
                 const float* src = W + (long)(g * H + jt * 16 + li) * H + (w * KS + ks) * 32 + 8 * lq;
                 const f32x4 v0 = ld4(src), v1 = ld4(src + 4);
                 const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                split8(x, bw[g][ks][0], bw[g][ks][1], bw[g][ks][2]);
+                split8_f16(x, WSCALE, bw[g][ks][0], bw[g][ks][1]);
             }
     }
 
@@ -279,19 +318,18 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
             if (!s_ok) return;                          // uniform: every thread reads the same LDS word
             const unsigned char* p0 = xrd + (st & 1) * half;
             const unsigned char* p1 = p0 + plane;
-            const unsigned char* p2 = p1 + plane;
-            u32x4 r[KS][3];
-            load2x3_sc1(p0, p1, p2, r);
+            u32x4 r[KS][2];
+            load2x2_sc1(p0, p1, r);
             flush_slabs();                              // last step's slab copies: their acks hide behind the products below
             {
-                const bf16x8 a[3] = {__builtin_bit_cast(bf16x8, r[0][0]), __builtin_bit_cast(bf16x8, r[0][1]), __builtin_bit_cast(bf16x8, r[0][2])};
+                const f16x8 a[2] = {__builtin_bit_cast(f16x8, r[0][0]), __builtin_bit_cast(f16x8, r[0][1])};
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = mfma6(a, bw[g][0], acc[g]);
+                for (int g = 0; g < 4; ++g) acc[g] = mfma3(a, bw[g][0], acc[g]);
             }
             {
-                const bf16x8 a[3] = {__builtin_bit_cast(bf16x8, r[1][0]), __builtin_bit_cast(bf16x8, r[1][1]), __builtin_bit_cast(bf16x8, r[1][2])};
+                const f16x8 a[2] = {__builtin_bit_cast(f16x8, r[1][0]), __builtin_bit_cast(f16x8, r[1][1])};
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = mfma6(a, bw[g][1], acc[g]);
+                for (int g = 0; g < 4; ++g) acc[g] = mfma3(a, bw[g][1], acc[g]);
             }
         }
 #pragma unroll
@@ -306,7 +344,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
                 float s = 0.f;
 #pragma unroll
                 for (int ww = 0; ww < NW; ++ww) s += red[ww][g][bi][jj];
-                pre[g] = xg[g] + s;
+                pre[g] = xg[g] + s * (1.0f / (HSCALE * WSCALE));
             }
             const float gi = sigmoidf_(pre[0]), gf = sigmoidf_(pre[1]), gg = tanhf(pre[2]), go = sigmoidf_(pre[3]);
             c_state = gf * c_state + gi * gg;
@@ -535,7 +573,7 @@ bool lstm_seq_supported(int B, int H) {
 
 long lstm_seq_xbytes(int B, int H, bool backward) {
     const long nbt = (B + 15) / 16, JT = H / 16;
-    return backward ? 2 * (2 * nbt * JT * JT * 1024) : 2 * (2 * nbt * 3 * (H / 32) * 1024);
+    return backward ? 2 * (2 * nbt * JT * JT * 1024) : 2 * (2 * nbt * 2 * (H / 32) * 1024);
 }
 
 hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, float* out, float* csave,
