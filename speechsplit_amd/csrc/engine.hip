@@ -782,9 +782,12 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
         }
         // the pre-activation gradients of this layer are complete once every chain has passed this point
         if (e->side && g_overlap) {
-            for (int c = 0; c < nch; ++c) CHK(fork_join(e, ch[c].st, e->side));
-            ws = e->side;
-            e->side_used = true;
+            // decoder: the side stream.  Encoder BLSTMs (a string of ~36 tiny split-K launches): the third branch stream, so
+            // that they do not queue behind the decoder's weight gradients, which drain on the side stream until late
+            ws = (!lb.big() && e->side3) ? e->side3 : e->side;
+            for (int c = 0; c < nch; ++c)
+                if (ch[c].st != ws) CHK(fork_join(e, ch[c].st, ws));
+            if (ws == e->side) e->side_used = true;
         } else if (nch == 2) {
             CHK(fork_join(e, ch[1].st, s));        // weight gradients run on s and need both halves
         }
