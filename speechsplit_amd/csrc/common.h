@@ -50,6 +50,22 @@ hipError_t launch_gemm(const GemmDesc& d, hipStream_t stream);
 // phase probe of the bf16x3 kernel (timing experiments): 4 waves x {5 phases, k-tile count} tick sums; see gemm_bf16x3.hip
 hipError_t gemm_phase_probe(unsigned long long out[24], bool reset);
 
+// Gate non-linearities of the recurrence kernels.  They sit on the per-time-step critical path, where libdevice's expf /
+// tanhf (range reduction, branches) cost a few hundred cycles per step; these use the hardware exp2 / rcp.  Absolute error
+// <= 2e-7 (sigmoid) and <= 3e-7 (tanh, with a series below |x| = 0.08 where the quotient form would cancel).
+#ifdef __HIPCC__
+__device__ __forceinline__ float ss_sigmoid(float x) {
+    return __frcp_rn(1.0f + __expf(-x));
+}
+__device__ __forceinline__ float ss_tanh(float x) {
+    const float e = __expf(2.0f * x);                       // inf for large x -> 1 - 0;  0 for very negative x -> 1 - 2
+    const float q = 1.0f - 2.0f * __frcp_rn(e + 1.0f);
+    const float x2 = x * x;
+    const float p = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * -0.05396825f)));
+    return fabsf(x) < 0.08f ? p : q;
+}
+#endif
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace ss

@@ -41,7 +41,7 @@ int g_seq_prio = 1;    // 1: persistent recurrence waves run at s_setprio 3
 
 namespace {
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return ss_sigmoid(x); }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 constexpr unsigned SPIN_LIMIT = 1u << 18;     // ~ tens of ms of polling before giving up
@@ -346,9 +346,9 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
                 for (int ww = 0; ww < NW; ++ww) s += red[ww][g][bi][jj];
                 pre[g] = xg[g] + s * (1.0f / (HSCALE * WSCALE));
             }
-            const float gi = sigmoidf_(pre[0]), gf = sigmoidf_(pre[1]), gg = tanhf(pre[2]), go = sigmoidf_(pre[3]);
+            const float gi = sigmoidf_(pre[0]), gf = sigmoidf_(pre[1]), gg = ss_tanh(pre[2]), go = sigmoidf_(pre[3]);
             c_state = gf * c_state + gi * gg;
-            h_val = go * tanhf(c_state);
+            h_val = go * ss_tanh(c_state);
             sv[0] = gi;
             sv[1] = gf;
             sv[2] = gg;
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
 #pragma unroll
             for (int ww = 0; ww < NW; ++ww) s += red[ww][bi][jj];
             const float dh = cur.d_o + s;
-            const float tc = tanhf(cur.cc);
+            const float tc = ss_tanh(cur.cc);
             const float d_o = dh * tc;
             const float dc = dc_rec + dh * cur.go * (1.0f - tc * tc);
             dc_rec = dc * cur.gf;

@@ -15,7 +15,7 @@ namespace ss {
 
 namespace {
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return ss_sigmoid(x); }
 
 template <int H>
 __global__ __launch_bounds__((4 * H > 64 ? 4 * H : 64)) void lstm_small_fwd_kernel(float* __restrict__ gates,
@@ -46,14 +46,14 @@ __global__ __launch_bounds__((4 * H > 64 ? 4 * H : 64)) void lstm_small_fwd_kern
             float acc = xn;
 #pragma unroll
             for (int k = 0; k < H; ++k) acc += w[k] * hs[k];
-            const float act = (n / H == 2) ? tanhf(acc) : sigmoidf_(acc);
+            const float act = (n / H == 2) ? ss_tanh(acc) : sigmoidf_(acc);
             gs[n] = act;
             grow[(long)tau * (8 * H)] = act;
         }
         __syncthreads();
         if (n < H) {
             c = gs[H + n] * c + gs[n] * gs[2 * H + n];
-            const float h = gs[3 * H + n] * tanhf(c);
+            const float h = gs[3 * H + n] * ss_tanh(c);
             hs[n] = h;
             const long o = ((long)b * TP + tau) * (2 * H) + dir * H + n;
             out[o] = h;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__((4 * H > 64 ? 4 * H : 64)) void lstm_small_bwd_kern
             const float dh = p_do + dh_rec;
             const float gi = p_i, gf = p_f, gg = p_g, go = p_o, cc = p_c, cp = p_cp;
             if (s + 1 < T) fetch(s + 1, cp, true);               // c of the next processed step == this step's c_prev
-            const float tc = tanhf(cc);
+            const float tc = ss_tanh(cc);
             const float d_o = dh * tc;
             const float dc = dc_rec + dh * go * (1.0f - tc * tc);
             dc_rec = dc * gf;
