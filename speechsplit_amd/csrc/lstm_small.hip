@@ -1,6 +1,6 @@
 // Bidirectional LSTM recurrences with a tiny hidden size (the encoder bottlenecks: hidden 1, 8 and 32;
 // reference model.py:71, 119, 174, 189).  W_hh is at most 128 x 32 floats, so one workgroup per (utterance,
-// direction) keeps its gate row of W_hh in registers (forward) / the whole matrix in LDS (backward) and walks all
+// direction) keeps its gate row (forward) / gate column (backward) of W_hh in registers and walks all
 // T steps in a single launch: no per-step launch, no inter-workgroup traffic.  These recurrences are pure latency;
 // the next step's global operands are fetched while the current step computes.
 //
@@ -69,13 +69,15 @@ __global__ __launch_bounds__((4 * H > 64 ? 4 * H : 64)) void lstm_small_bwd_kern
                                                                                    const float* __restrict__ whh_b,
                                                                                    const float* __restrict__ d_out,
                                                                                    const float* __restrict__ csave, int T) {
-    __shared__ float W[4 * H * H];
     __shared__ float dg[4 * H];
     __shared__ float part[4 * H];
     const int b = blockIdx.x, dir = blockIdx.y, n = threadIdx.x;
     const int TP = T + 2 * HALO;
     const float* whh = dir ? whh_b : whh_f;
-    for (int i = n; i < 4 * H * H; i += blockDim.x) W[i] = whh[i];
+    // thread n = (gate p, hidden k) owns column k of gate p's H x H block of W_hh: H registers, no LDS traffic for the weights
+    float wcol[H];
+#pragma unroll
+    for (int q = 0; q < H; ++q) wcol[q] = n < 4 * H ? whh[((n / H) * H + q) * H + n % H] : 0.f;
     const bool cell_thread = n < H;
     float* grow = gates + (long)b * TP * (8 * H) + dir * 4 * H + n;
     const long obase = (long)b * TP * (2 * H) + dir * H + n;
@@ -122,10 +124,10 @@ __global__ __launch_bounds__((4 * H > 64 ? 4 * H : 64)) void lstm_small_bwd_kern
         }
         __syncthreads();
         if (n < 4 * H) {
-            const int k = n % H, p = n / H;
+            const int p = n / H;
             float acc = 0.f;
 #pragma unroll
-            for (int q = 0; q < H; ++q) acc += dg[p * H + q] * W[(p * H + q) * H + k];
+            for (int q = 0; q < H; ++q) acc += dg[p * H + q] * wcol[q];
             part[n] = acc;
         }
         __syncthreads();
