@@ -675,7 +675,7 @@ int lstm_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
 
 // d_top: gradient slab of the last layer's output [B,TP,2H]; x: forward input; dx: input-gradient view or null
 // weight / bias gradients of one layer from its finished pre-activation gradient slab (full batch, flat over all rows)
-int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am, hipStream_t ws) {
+int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am, bool bias_done, hipStream_t ws) {
     const int B = e->curB, T = e->curT, H = lb.H;
     const long TP = T + 2 * HALO, R = (long)B * TP;
     const int In = lb.in_of(l);
@@ -711,8 +711,10 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
         h.amax_a = am;
         h.ksplit = pick_ksplit(h.M, h.N, h.K);
         GEMM_ON(h, ws);
-        HIPCHK(colsum_acc(dGd, 8L * H, (int)R, 4 * H, e->G + pd.bih, ws));
-        HIPCHK(hipMemcpyAsync(e->G + pd.bhh, e->G + pd.bih, 4L * H * 4, hipMemcpyDeviceToDevice, ws));
+        if (!bias_done) {     // the persistent backward kernel accumulates both bias gradients itself
+            HIPCHK(colsum_acc(dGd, 8L * H, (int)R, 4 * H, e->G + pd.bih, ws));
+            HIPCHK(hipMemcpyAsync(e->G + pd.bhh, e->G + pd.bih, 4L * H * 4, hipMemcpyDeviceToDevice, ws));
+        }
     }
     return 0;
 }
@@ -761,6 +763,9 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
         hipStream_t ws = s;
         // fp16 x 2 gradient GEMMs need the slab's maximum, which only the persistent kernel measures
         float* am = (persist && g_bwd_f16x2 && lb.amax0 >= 0) ? e->amax + lb.amax0 + l : nullptr;
+        // b_ih and b_hh gradients sit back to back in the arena (registration order): the persistent kernel fills both
+        const bool bias_in_kernel = persist && lb.pd[l * 2].bhh == lb.pd[l * 2].bih + 4L * H &&
+                                    lb.pd[l * 2 + 1].bhh == lb.pd[l * 2 + 1].bih + 4L * H;
         if (lb.big()) {
             for (int c = 0; c < nch && !persist; ++c) {
                 const long half = 2L * (((ch[c].nb + 15) / 16) * 16) * 4 * H;
@@ -769,7 +774,8 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
             // persistent: start state zeroed by backward_decoder
             if (persist)
                 HIPCHK(lstm_seq_bwd(dG, e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.px, dcur, lb.csave[l], lb.sync_b(l),
-                                    am, B, T, H, false, s));
+                                    am, bias_in_kernel ? e->G + lb.pd[l * 2].bih : nullptr,
+                                    bias_in_kernel ? e->G + lb.pd[l * 2 + 1].bih : nullptr, B, T, H, false, s));
             for (int st = 0; st < T && !persist; ++st)
                 for (int c = 0; c < nch; ++c) {
                     const long r0 = (long)ch[c].b0 * TP;
@@ -795,7 +801,7 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
         if (dxi.p)
             for (int c = 0; c < nch; ++c)
                 CHK(lstm_input_grad(e, lb, l, dxi, (long)ch[c].b0 * TP, nch == 2 ? (long)ch[c].nb * TP : R, am, ch[c].st));
-        CHK(lstm_weight_grads(e, lb, l, xi, am, ws));
+        CHK(lstm_weight_grads(e, lb, l, xi, am, bias_in_kernel, ws));
         dcur = dxi.p;
     }
     if (nch == 2) CHK(fork_join(e, ch[1].st, s));
@@ -1525,7 +1531,8 @@ int ss_op_lstm_bwd(float* gates, const float* whh_f, const float* whh_b, const f
         float* dc = gf + 2 * half;
         const long xbytes = lstm_seq_xbytes(B, H, true);
         if (g_persist && lstm_seq_supported(B, H) && scratch_floats * 4 >= xbytes + 512) {     // [exchange tiles][counters]
-            HIPCHK(lstm_seq_bwd(gates, whh_f, whh_b, scratch, d_out, csave, (unsigned*)((char*)scratch + xbytes), nullptr, B, T, H, true, s));
+            HIPCHK(lstm_seq_bwd(gates, whh_f, whh_b, scratch, d_out, csave, (unsigned*)((char*)scratch + xbytes), nullptr, nullptr, nullptr, B, T, H,
+                                true, s));
             return 0;
         }
         HIPCHK(lstm_pack_w(whh_f, whh_b, scratch, H, 1, s));

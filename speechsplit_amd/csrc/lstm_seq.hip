@@ -396,7 +396,8 @@ template <int H, int NW>
 __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict__ gates, const float* __restrict__ whh_f,
                                                                const float* __restrict__ whh_b, unsigned char* __restrict__ xb,
                                                                const float* __restrict__ d_out, const float* __restrict__ csave,
-                                                               unsigned* __restrict__ sync, unsigned* __restrict__ amax, int B, int T,
+                                                               unsigned* __restrict__ sync, unsigned* __restrict__ amax,
+                                                               float* __restrict__ gbias_f, float* __restrict__ gbias_b, int B, int T,
                                                                int nbt, int prio) {
     constexpr int JT = H / 16, CT = JT / NW, PW = JT / NW;      // column tiles (= consumers) / producers handled per wave
     static_assert(CT == 4 || CT == 2, "the persistent backward kernel is written for 2 or 4 column tiles per wave");
@@ -471,6 +472,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
     float da_p[4] = {0.f, 0.f, 0.f, 0.f};
     int tau_p = -1;
     float amx = 0.f;                                  // max |da| this thread has produced (for the consumers' fp16 scaling)
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};             // sum over time of this thread's da: the bias gradient of its (utterance, unit)
     auto flush_slab = [&]() {
         if (cell && b < B && tau_p >= 0 && !(diag & 8)) {
             float* gr = gates + ((long)b * TP + tau_p) * (8 * H) + dir * 4 * H + j;
@@ -518,7 +520,11 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
             da[1] = dc * cur.cp * cur.gf * (1.0f - cur.gf);
             da[2] = dc * cur.gi * (1.0f - cur.gg * cur.gg);
             da[3] = d_o * cur.go * (1.0f - cur.go);
-            if (b < B) amx = fmaxf(fmaxf(amx, fmaxf(fabsf(da[0]), fabsf(da[1]))), fmaxf(fabsf(da[2]), fabsf(da[3])));
+            if (b < B) {
+                amx = fmaxf(fmaxf(amx, fmaxf(fabsf(da[0]), fabsf(da[1]))), fmaxf(fabsf(da[2]), fabsf(da[3])));
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bsum[g] += da[g];
+            }
             // own gate units as A fragments in LDS: k = g*16 + jj  ->  k-step g/2, lane 16*((g%2)*2 + jj/8) + bi, element jj%8
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -562,6 +568,26 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
         for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o));
         if (lane == 0) atomicMax(amax, __float_as_uint(amx));
     }
+    // bias gradients d b_ih = d b_hh = sum over utterances and time of da (gbias_*: [2][4H] = b_ih then b_hh gradient of one
+    // direction, nullable): the 16 utterances of the tile meet in LDS, one atomic per (gate, unit) and workgroup
+    float* gbias = dir == 0 ? gbias_f : gbias_b;
+    if (gbias) {
+        __syncthreads();
+        float* sums = &red[0][0][0];                  // [4][16 utterances][16 units], NW * 256 >= 1024 floats
+        if (cell) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) sums[(g * 16 + bi) * 16 + jj] = bsum[g];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int g = tid >> 4, u = tid & 15;
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += sums[(g * 16 + r) * 16 + u];
+            atomicAdd(gbias + g * H + jt * 16 + u, t);
+            atomicAdd(gbias + 4 * H + g * H + jt * 16 + u, t);
+        }
+    }
 }
 
 }  // namespace
@@ -592,7 +618,8 @@ hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, vo
 }
 
 hipError_t lstm_seq_bwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, const float* d_out,
-                        const float* csave, unsigned* sync, float* amax, int B, int T, int H, bool zero_state, hipStream_t s) {
+                        const float* csave, unsigned* sync, float* amax, float* gbias_f, float* gbias_b, int B, int T, int H,
+                        bool zero_state, hipStream_t s) {
     const int nbt = (B + 15) / 16;
     if (!lstm_seq_supported(B, H)) return hipErrorInvalidValue;
     if (zero_state) {
@@ -600,8 +627,8 @@ hipError_t lstm_seq_bwd(float* gates, const float* whh_f, const float* whh_b, vo
         if (e != hipSuccess) return e;
     }
     unsigned char* xb = static_cast<unsigned char*>(xbuf);
-    if (H == 512) hipLaunchKernelGGL((lstm_seq_bwd_kernel<512, 8>), dim3(2 * nbt * 32), dim3(512), 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, reinterpret_cast<unsigned*>(amax), B, T, nbt, g_seq_prio);
-    else          hipLaunchKernelGGL((lstm_seq_bwd_kernel<256, 8>), dim3(2 * nbt * 16), dim3(512), 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, reinterpret_cast<unsigned*>(amax), B, T, nbt, g_seq_prio);
+    if (H == 512) hipLaunchKernelGGL((lstm_seq_bwd_kernel<512, 8>), dim3(2 * nbt * 32), dim3(512), 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, reinterpret_cast<unsigned*>(amax), gbias_f, gbias_b, B, T, nbt, g_seq_prio);
+    else          hipLaunchKernelGGL((lstm_seq_bwd_kernel<256, 8>), dim3(2 * nbt * 16), dim3(512), 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, reinterpret_cast<unsigned*>(amax), gbias_f, gbias_b, B, T, nbt, g_seq_prio);
     return hipGetLastError();
 }
 
