@@ -34,7 +34,7 @@ int g_lstm_mode = 0;  // diagnostics only: 1 = skip MFMAs, 2 = skip operand load
 
 namespace {
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return ss_sigmoid(x); }
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
@@ -134,9 +134,9 @@ __global__ __launch_bounds__(64 * NW) void lstm_step_fwd_kernel(float* __restric
             pre[g] = xg[g] + s;
         }
         const long o = ((long)b * TP + tau) * (2 * H) + dir * H + j;
-        const float gi = sigmoidf_(pre[0]), gf = sigmoidf_(pre[1]), gg = tanhf(pre[2]), go = sigmoidf_(pre[3]);
+        const float gi = sigmoidf_(pre[0]), gf = sigmoidf_(pre[1]), gg = ss_tanh(pre[2]), go = sigmoidf_(pre[3]);
         const float c = gf * cp + gi * gg;
-        const float h = go * tanhf(c);
+        const float h = go * ss_tanh(c);
         grow[0] = gi;
         grow[H] = gf;
         grow[2 * H] = gg;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_step_bwd_kernel(float* __restric
 #pragma unroll
         for (int ww = 0; ww < NW; ++ww) s += red[ww][bi][jj];
         const float dh = p_do + s;
-        const float tc = tanhf(cc);
+        const float tc = ss_tanh(cc);
         const float d_o = dh * tc;
         const float dc = dc_rec + dh * go * (1.0f - tc * tc);
         *dcp = dc * gf;
