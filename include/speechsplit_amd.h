@@ -128,7 +128,7 @@ int ss_op_gemm(const float* a_dev, long lda, const float* b_dev, long ldb, float
  * single-launch kernel, H in {64,128,256,512} one launch per time step and needs scratch of at least
  * 8*H*H + 4*ceil16(B)*H floats (forward) / 8*H*H + 16*ceil16(B)*H + 2*B*H floats (backward).  H in {256,512} with
  * 2*ceil(B/16)*(H/16) <= 256 runs as ONE persistent launch (the engine's schedule) when, for the backward, scratch also
- * holds its exchange tiles: 4*ceil(B/16)*(H/16)^2*1024 + 512 bytes. */
+ * holds its exchange tiles and flags: 4*ceil(B/16)*(H/16)^2*1024 + 8192 bytes. */
 int ss_op_lstm_fwd(float* gates_dev, const float* whh_f_dev, const float* whh_b_dev, float* out_dev, float* csave_dev,
                    float* scratch_dev, long scratch_floats, int B, int T, int H, void* stream);
 /* BPTT of the same: d_out [B,T+4,2H]; gates is replaced by the pre-activation gradients. */

@@ -84,12 +84,12 @@ struct LstmBlk {
     float* dc[2] = {nullptr, nullptr};     // per chain: [2][B][H]
     unsigned* sync = nullptr;              // persistent kernels: group counters + abort word (one-off ops path)
     // persistent schedule: per-layer start state, contiguous so ONE memset per pass readies every layer's launch.
-    //   zf = [L][128 sync words] ++ [L][hf]      (forward)        zb = [L][128 sync words]   (backward)
+    //   zf = [L][LSTM_SEQ_SYNC_WORDS] ++ [L][hf]      (forward)        zb = [L][LSTM_SEQ_SYNC_WORDS]   (backward)
     char *zf = nullptr, *zb = nullptr;
     long zf_bytes = 0, zb_bytes = 0, hf_bytes = 0, gf_bytes = 0;
-    unsigned* sync_f(int l) const { return (unsigned*)zf + 128 * l; }
-    unsigned* sync_b(int l) const { return (unsigned*)zb + 128 * l; }
-    void* hf_l(int l) const { return zf + 512L * L + hf_bytes * l; }
+    unsigned* sync_f(int l) const { return (unsigned*)zf + LSTM_SEQ_SYNC_WORDS * l; }
+    unsigned* sync_b(int l) const { return (unsigned*)zb + LSTM_SEQ_SYNC_WORDS * l; }
+    void* hf_l(int l) const { return zf + 4L * LSTM_SEQ_SYNC_WORDS * L + hf_bytes * l; }
     int amax0 = -1;                        // first slot in ss_engine::amax (one per layer) when the block's gradient GEMMs may use fp16 x 2
     void* px = nullptr;                    // backward exchange tiles (shared by the layers, needs no initial state)
     float* dmid[2] = {nullptr, nullptr};   // gradient slabs of inner layer outputs [B,TP,2H]
@@ -315,11 +315,11 @@ long ss_engine::carve(int B, int T, bool assign) {
                 lb.gf[c] = (float*)take(2L * 2 * B16 * 4 * lb.H * 4);
                 lb.dc[c] = (float*)take(2L * B * lb.H * 4);
             }
-            lb.sync = (unsigned*)take(128 * 4);
+            lb.sync = (unsigned*)take(LSTM_SEQ_SYNC_WORDS * 4);
             lb.hf_bytes = lstm_seq_xbytes(B, lb.H, false);       // exchange buffers of the persistent kernels
             lb.gf_bytes = lstm_seq_xbytes(B, lb.H, true);
-            lb.zf_bytes = lb.L * (512L + lb.hf_bytes);
-            lb.zb_bytes = lb.L * 512L;
+            lb.zf_bytes = lb.L * (4L * LSTM_SEQ_SYNC_WORDS + lb.hf_bytes);
+            lb.zb_bytes = lb.L * 4L * LSTM_SEQ_SYNC_WORDS;
             lb.zf = (char*)take(lb.zf_bytes);
             lb.zb = (char*)take(lb.zb_bytes);
             lb.px = take(lb.gf_bytes);
@@ -1530,7 +1530,7 @@ int ss_op_lstm_bwd(float* gates, const float* whh_f, const float* whh_b, const f
         float* gf = scratch + wn;
         float* dc = gf + 2 * half;
         const long xbytes = lstm_seq_xbytes(B, H, true);
-        if (g_persist && lstm_seq_supported(B, H) && scratch_floats * 4 >= xbytes + 512) {     // [exchange tiles][counters]
+        if (g_persist && lstm_seq_supported(B, H) && scratch_floats * 4 >= xbytes + 4L * LSTM_SEQ_SYNC_WORDS) {     // [exchange tiles][flags]
             HIPCHK(lstm_seq_bwd(gates, whh_f, whh_b, scratch, d_out, csave, (unsigned*)((char*)scratch + xbytes), nullptr, nullptr, nullptr, B, T, H,
                                 true, s));
             return 0;
@@ -1552,7 +1552,7 @@ int ss_check(ss_engine* e, void* stream) {
         if (!lb->zf) continue;
         for (int l = 0; l < 2 * lb->L; ++l) {
             unsigned flag = 0;
-            HIPCHK(hipMemcpy(&flag, (l < lb->L ? lb->sync_f(l) : lb->sync_b(l - lb->L)) + 64, 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(&flag, l < lb->L ? lb->sync_f(l) : lb->sync_b(l - lb->L), 4, hipMemcpyDeviceToHost));
             if (flag) return fail("persistent LSTM kernel gave up waiting for its group (bounded spin expired): results are invalid");
         }
     }

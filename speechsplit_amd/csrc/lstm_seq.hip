@@ -15,9 +15,11 @@
 // blockIdx % ngroups: with B = 64 that is 8 groups = the 8 XCDs under the observed round-robin placement.
 //
 // Hand-off protocol (CDNA guide Guideline 16 / MI355X_MICROARCH "Valid forms", counter row), placement-independent:
-//   producer: payload stores -> every storing wave s_waitcnt vmcnt(0) -> workgroup barrier -> one lane adds 1 to the
-//             group counter (relaxed, agent scope)
-//   consumer: one lane polls the counter -> workgroup barrier -> every payload load is an sc1 load
+//   producer: payload stores -> every storing wave s_waitcnt vmcnt(0) -> workgroup barrier -> one lane stores the step number
+//             into the workgroup's own flag word (relaxed, agent scope; 32 flags of a group share one 128-byte line)
+//   consumer: one wave polls the flag line (one load, lane = member) -> workgroup barrier -> every payload load is an sc1 load
+// Flags instead of a shared arrival counter because same-address atomics serialise in the L2 (measured: 4 -> 8 adds per
+// workgroup and step tripled the step time), a store to an own word and a one-line poll do not.
 // Payload stores are write-through (sc1) in general.  Round 0 of every launch has each member publish the XCD it runs on
 // (s_getreg XCC_ID) in a group mask: if the whole group shares one XCD -- hence one L2 -- ordinary stores suffice, and
 // that is worth 1.8 us per backward step (8 MB of sc1 traffic per step otherwise).  Measured, never assumed: a group that
@@ -46,17 +48,26 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 
 constexpr unsigned SPIN_LIMIT = 1u << 18;     // ~ tens of ms of polling before giving up
 
-// wait until *cnt >= want (one lane); returns false on abort / timeout
-__device__ __forceinline__ bool wait_count(unsigned* cnt, unsigned want, unsigned* abortp) {
+// Group hand-off without read-modify-write traffic: every member owns one word of its group's flag line (32 words = one
+// 128-byte line) and publishes "my step s is complete" by storing s there; a consumer wave reads the whole line with ONE load
+// (lane i = member i) and is done when every member's value has reached `want`.  (A shared arrival counter costs one
+// same-address atomic per member and step, and those serialise in the L2: measured, it was most of the step's latency.)
+// Called by all 64 lanes of one wave; returns false on abort / timeout.
+__device__ __forceinline__ bool wait_flags(const unsigned* flags, int members, unsigned want, unsigned* abortp) {
+    const int lane = threadIdx.x & 63;
     for (unsigned spins = 0;; ++spins) {
-        if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
+        const unsigned v = lane < members ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
+        if (__all((int)(v - want) >= 0)) return true;
         if ((spins & 63) == 63 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
         if (spins > SPIN_LIMIT) {
-            __hip_atomic_store(abortp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(abortp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
         __builtin_amdgcn_s_sleep(1);
     }
+}
+__device__ __forceinline__ void publish(unsigned* flag, unsigned v) {
+    __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ void store_sc1(float* p, float v) {
@@ -192,14 +203,17 @@ __device__ __forceinline__ unsigned xcc_id() {
     return v & 15u;
 }
 
-// Round 0 of the group protocol (one lane): publish my XCD in the group's mask word, arrive, wait for the JT members,
-// read the mask back.  Returns 1 if the group is XCD-local, 0 if it spans XCDs, -1 on abort.  After this round the arrival
-// counter stands at JT, so step st waits for JT * (st + 1).
-__device__ __forceinline__ int group_locality(unsigned* cnt, unsigned* mask, unsigned* abortp, unsigned JT) {
-    const unsigned old = __hip_atomic_fetch_or(mask, 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("" ::"v"(old) : "memory");          // the returned value forces the OR to have been performed before the arrival
-    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!wait_count(cnt, JT, abortp)) return -1;
+// Round 0 of the group protocol (wave 0 of the workgroup): put my XCD into the group's mask word, publish flag 1, wait for
+// all members, read the mask back.  Returns 1 if the group is XCD-local, 0 if it spans XCDs, -1 on abort.  Completion of
+// step s is then published as s + 2, and step st waits for st + 1.
+__device__ __forceinline__ int group_locality(unsigned* flags, int me, int members, unsigned* mask, unsigned* abortp) {
+    const int lane = threadIdx.x & 63;
+    if (lane == 0) {
+        const unsigned old = __hip_atomic_fetch_or(mask, 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(old) : "memory");      // the returned value forces the OR to have been performed before the flag
+        publish(flags + me, 1u);
+    }
+    if (!wait_flags(flags, members, 1u, abortp)) return -1;
     const unsigned m = __hip_atomic_load(mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return (m & (m - 1)) == 0 ? 1 : 0;
 }
@@ -228,8 +242,8 @@ __device__ __forceinline__ void xb_store(unsigned char* xb_plane0, long plane_st
     }
 }
 
-// grid = ngroups * (H/16), block = 64*NW.   sync: [0..ngroups) arrival counters, [64] abort word,
-// [65..65+ngroups) XCD masks; xb and sync all zero on entry
+// grid = ngroups * (H/16), block = 64*NW.   sync (LSTM_SEQ_SYNC_WORDS, all zero on entry, like xb): [0] abort word,
+// [1 + group] XCD masks, [64 + 32 * group + member] completion flags
 template <int H, int NW>
 __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict__ gates, const float* __restrict__ whh_f,
                                                                const float* __restrict__ whh_b, unsigned char* __restrict__ xb,
@@ -246,10 +260,13 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
     const int dir = grp / nbt, bt = grp % nbt;
     const int TP = T + 2 * HALO;
     const int li = lane & 15, lq = lane >> 4;
-    unsigned* cnt = sync + grp;
-    unsigned* abortp = sync + 64;
+    unsigned* flags = sync + 64 + 32 * grp;
+    unsigned* abortp = sync;
     const int diag = prio >> 1;                            // 32: ordinary stores regardless (timing experiment)
-    if (tid == 0) s_ok = group_locality(cnt, sync + 65 + grp, abortp, JT);
+    if (w == 0) {
+        const int r = group_locality(flags, jt, JT, sync + 1 + grp, abortp);
+        if (lane == 0) s_ok = r;
+    }
     __syncthreads();
     if (s_ok < 0) return;
     const bool local = s_ok == 1 || (diag & 32);
@@ -313,7 +330,10 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (st > 0) {                                   // h(-1) = 0: nothing to multiply at the first step
-            if (tid == 0) s_ok = wait_count(cnt, (unsigned)(JT * (st + 1)), abortp) ? 1 : 0;
+            if (w == 0) {
+                const bool ok = wait_flags(flags, JT, (unsigned)(st + 1), abortp);
+                if (lane == 0) s_ok = ok ? 1 : 0;
+            }
             __syncthreads();
             if (!s_ok) return;                          // uniform: every thread reads the same LDS word
             const unsigned char* p0 = xrd + (st & 1) * half;
@@ -360,7 +380,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains before the barrier
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) publish(flags + jt, (unsigned)(st + 2));
         // slab copies (consumed only by later kernels) are held back until the next step's fragments have arrived: issued
         // right here, their acknowledgements would sit in front of those loads' s_waitcnt vmcnt(0)
 #pragma unroll
@@ -391,7 +411,7 @@ __device__ __forceinline__ void store16_plain(unsigned char* p, f32x4 v) {      
 // a workgroup writes H/16 KB and reads H/16 KB per step.  Every tile read was written one step earlier: no zeroing needed.
 // Tiles are stored write-through (sc1) unless round 0 found the whole group on one XCD (group_locality): then ordinary
 // stores are used, which is what makes this formulation pay (8 MB of sc1 traffic per step costs ~1.8 us of every step).
-// sync: [0..ngroups) arrival counters, [64] abort word, [65..65+ngroups) XCD masks.
+// sync: as in the forward kernel.
 template <int H, int NW>
 __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict__ gates, const float* __restrict__ whh_f,
                                                                const float* __restrict__ whh_b, unsigned char* __restrict__ xb,
@@ -414,9 +434,12 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
     const int dir = grp / nbt, bt = grp % nbt;
     const int TP = T + 2 * HALO;
     const int li = lane & 15, lq = lane >> 4;
-    unsigned* cnt = sync + grp;
-    unsigned* abortp = sync + 64;
-    if (tid == 0) s_ok = (diag & 16) ? 1 : group_locality(cnt, sync + 65 + grp, abortp, JT);
+    unsigned* flags = sync + 64 + 32 * grp;
+    unsigned* abortp = sync;
+    if (w == 0) {
+        const int r = (diag & 16) ? 1 : group_locality(flags, jt, JT, sync + 1 + grp, abortp);
+        if (lane == 0) s_ok = r;
+    }
     __syncthreads();
     if (s_ok < 0) return;
     const bool local = s_ok == 1 || (diag & 32);
@@ -487,7 +510,10 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
         if (cell && st + 1 < T && !(diag & 4)) nxt = fetch((diag & 64) ? (st & 1) : st + 1);     // 64: always the same two rows (cache-hot)
         f32x4 part = {0.f, 0.f, 0.f, 0.f};
         if (st > 0) {
-            if (tid == 0) s_ok = (diag & 16) ? 1 : (wait_count(cnt, (unsigned)(JT * (st + 1)), abortp) ? 1 : 0);
+            if (w == 0) {
+                const bool ok = (diag & 16) ? true : wait_flags(flags, JT, (unsigned)(st + 1), abortp);
+                if (lane == 0) s_ok = ok ? 1 : 0;
+            }
             __syncthreads();
             if (!s_ok) return;
             const unsigned char* p = xrd + (st & 1) * half;
@@ -556,7 +582,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) publish(flags + jt, (unsigned)(st + 2));
         // the slab copy for the weight-gradient GEMMs is held back until the next step's tiles have arrived (see forward)
 #pragma unroll
         for (int g = 0; g < 4; ++g) da_p[g] = da[g];
@@ -594,7 +620,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
 
 bool lstm_seq_supported(int B, int H) {
     const int nbt = (B + 15) / 16;
-    return (H == 512 || H == 256) && 2 * nbt * (H / 16) <= 256 && 2 * nbt <= 60;     // counters, abort word and masks share 128 words
+    return (H == 512 || H == 256) && 2 * nbt * (H / 16) <= 256 && 2 * nbt <= 60;     // abort word, masks and 32 flags per group fit LSTM_SEQ_SYNC_WORDS
 }
 
 long lstm_seq_xbytes(int B, int H, bool backward) {
@@ -607,7 +633,7 @@ hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, vo
     const int nbt = (B + 15) / 16;
     if (!lstm_seq_supported(B, H)) return hipErrorInvalidValue;
     if (zero_state) {
-        hipError_t e = hipMemsetAsync(sync, 0, 128 * sizeof(unsigned), s);
+        hipError_t e = hipMemsetAsync(sync, 0, LSTM_SEQ_SYNC_WORDS * sizeof(unsigned), s);
         if (e == hipSuccess) e = hipMemsetAsync(xbuf, 0, lstm_seq_xbytes(B, H, false), s);
         if (e != hipSuccess) return e;
     }
@@ -623,7 +649,7 @@ hipError_t lstm_seq_bwd(float* gates, const float* whh_f, const float* whh_b, vo
     const int nbt = (B + 15) / 16;
     if (!lstm_seq_supported(B, H)) return hipErrorInvalidValue;
     if (zero_state) {
-        hipError_t e = hipMemsetAsync(sync, 0, 128 * sizeof(unsigned), s);      // the exchange tiles need no initial state
+        hipError_t e = hipMemsetAsync(sync, 0, LSTM_SEQ_SYNC_WORDS * sizeof(unsigned), s);      // the exchange tiles need no initial state
         if (e != hipSuccess) return e;
     }
     unsigned char* xb = static_cast<unsigned char*>(xbuf);

@@ -238,7 +238,7 @@ def bench_seq(B=64, T=128, H=512):
     xproj = (torch.randn(B, T, 2, 4 * H, generator=g) * 0.5).to(dev)
     whh = (torch.rand(2, 4 * H, H, generator=g) * 2 - 1).to(dev) / H ** 0.5
     d_out = (torch.randn(B, T, 2 * H, generator=g) * 0.1).to(dev)
-    scratch = torch.zeros(max(8 * H * H + 16 * B * H + 2 * B * H + 1024, ((B + 15) // 16) * (H // 16) ** 2 * 1024 + 256), device=dev)
+    scratch = torch.zeros(max(8 * H * H + 16 * B * H + 2 * B * H + 1024, ((B + 15) // 16) * (H // 16) ** 2 * 1024 + 4096), device=dev)
     gates = torch.zeros(B, T + 4, 8 * H, device=dev)
     gates[:, 2:2 + T] = xproj.reshape(B, T, 8 * H)
     xp_keep = gates.clone()

@@ -15,7 +15,7 @@ dev = 'cuda'
 xproj = (torch.randn(B, T, 2, 4 * H, generator=g) * 0.5).to(dev)
 whh = ((torch.rand(2, 4 * H, H, generator=g) * 2 - 1) / H ** 0.5).to(dev)
 d_out = (torch.randn(B, T, 2 * H, generator=g) * 0.1).to(dev)
-scratch = torch.zeros(max(8 * H * H + 16 * B * H + 2 * B * H + 1024, ((B + 15) // 16) * (H // 16) ** 2 * 1024 + 256), device=dev)
+scratch = torch.zeros(max(8 * H * H + 16 * B * H + 2 * B * H + 1024, ((B + 15) // 16) * (H // 16) ** 2 * 1024 + 4096), device=dev)
 res = {}
 for ps in (0, 1):
     E.tune('persist', ps)
