@@ -83,6 +83,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--precision', choices=['f32', 'bf16'], default='f32',
                     help="f32 (default): the 1e-4 parity mode the headline is quoted on; bf16: BASELINE configs 2-4's arithmetic")
+    ap.add_argument('--tune', action='append', default=[], metavar='KEY=VALUE', help='experiment knob of the HIP library (ss_tune)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -100,7 +101,10 @@ def main():
     dev = torch.device(f'cuda:{local}')
 
     from oracle import weights as W            # weight generator only (frozen-stream seeds); not on the timed path
-    from speechsplit_amd.engine import Engine, draw_interp
+    from speechsplit_amd.engine import Engine, draw_interp, tune
+    for kv in args.tune:
+        k, v = kv.split('=')
+        tune(k, int(v))
     B, T = args.batch, args.frames
     hp = W.default_hparams(max_len_pad=T)
     eng = Engine('G3', hp, B, T, device=dev)

@@ -24,6 +24,7 @@ int g_fwd_f16x2 = 1;   // 1: forward contractions (operands bounded by construct
 int g_bwd_f16x2 = 1;   // 1: the decoder's and the conv trunk's gradient GEMMs also use fp16 x 2: the gradient operand is scaled by the power
                        //    of two its producer kernel measured (max |value| of the slab), the activation / weight operand by the fixed one
 int g_overlap = 1;     // 1: weight-gradient GEMMs on the side stream
+int g_defer_dw = 1;    // 1: the decoder's weight-gradient GEMMs start after its last input gradient (see lstm_bwd)
 int g_side_prio = 0;   // 1: create the side stream with the lowest priority (read at ss_bind).  Measured: 2.3x SLOWER
                        //    (35 ms vs 14.8 ms per step): the low-priority queue starves behind 768 tiny step launches.
 int g_persist = 1;     // 1: decoder recurrences run as ONE persistent launch per layer (lstm_seq.hip) when the batch fits
@@ -786,6 +787,17 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
         } else {
             HIPCHK(lstm_small_bwd(dG, e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, dcur, lb.csave[l], B, T, H, s));
         }
+        // Decoder on the persistent kernels: its weight-gradient GEMMs are held back until the whole recurrence chain
+        // (layer L-1 .. 0 and the input gradients between them) is through.  Co-scheduled they do not fill idle cycles:
+        // they stretch the latency-bound recurrence steps and halve the rate of the input-gradient GEMMs on the critical
+        // path (measured: chain 2.95 ms with the GEMMs beside it against 1.93 ms alone + 0.78 ms of GEMMs), whereas the
+        // encoder backward that follows is a string of small launches they can run beside.
+        const bool defer = persist && e->side && g_overlap && g_defer_dw;
+        if (defer) {
+            if (dxi.p) CHK(lstm_input_grad(e, lb, l, dxi, 0, R, am, s));
+            dcur = dxi.p;
+            continue;
+        }
         // the pre-activation gradients of this layer are complete once every chain has passed this point
         if (e->side && g_overlap) {
             // decoder: the side stream.  Encoder BLSTMs (a string of ~36 tiny split-K launches): the third branch stream, so
@@ -805,6 +817,16 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
         dcur = dxi.p;
     }
     if (nch == 2) CHK(fork_join(e, ch[1].st, s));
+    if (persist && e->side && g_overlap && g_defer_dw) {
+        CHK(fork_join(e, s, e->side));
+        e->side_used = true;
+        for (int l = lb.L - 1; l >= 0; --l) {
+            Slab xi = l == 0 ? x : Slab{lb.out[l - 1], 2L * H};
+            float* am = (g_bwd_f16x2 && lb.amax0 >= 0) ? e->amax + lb.amax0 + l : nullptr;
+            const bool bias_in_kernel = lb.pd[l * 2].bhh == lb.pd[l * 2].bih + 4L * H && lb.pd[l * 2 + 1].bhh == lb.pd[l * 2 + 1].bih + 4L * H;
+            CHK(lstm_weight_grads(e, lb, l, xi, am, bias_in_kernel, e->side));
+        }
+    }
     return 0;
 }
 
@@ -1483,6 +1505,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "lstm_g" && value >= 0 && value <= 16) g_lstm_g = value;
     else if (k == "lstm_mode" && value >= 0 && value <= 4) g_lstm_mode = value;
     else if (k == "overlap" && (value == 0 || value == 1)) g_overlap = value;
+    else if (k == "defer_dw" && (value == 0 || value == 1)) g_defer_dw = value;
     else if (k == "graph" && (value == 0 || value == 1)) g_graph = value;
     else if (k == "split" && (value == 0 || value == 1)) g_split = value;
     else if (k == "persist" && (value == 0 || value == 1)) g_persist = value;

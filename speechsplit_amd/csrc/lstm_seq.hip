@@ -135,6 +135,15 @@ __device__ __forceinline__ f32x4 mfma3(const f16x8 (&a)[2], const f16x8 (&b)[2],
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[0], acc, 0, 0, 0);     // h.h   (l.l is below 2^-22)
     return acc;
 }
+// max over the 16 lanes of a row (all lanes get it); v >= 0, so the bit patterns order like the values
+__device__ __forceinline__ float row16_max(float v) {
+    int x = __float_as_int(v);
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));       // quad_perm [1,0,3,2]
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true));       // quad_perm [2,3,0,1]
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x124, 0xF, 0xF, true));      // row_ror:4
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, true));      // row_ror:8
+    return __int_as_float(x);
+}
 __device__ __forceinline__ void load2x2_sc1(const unsigned char* p0, const unsigned char* p1, u32x4 (&r)[2][2]) {
     asm volatile(
         "global_load_dwordx4 %0, %4, off sc1\n\t"
@@ -392,19 +401,20 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
     flush_slabs();
 }
 
-// One 16-byte write-through store per lane (whole 1 KiB tiles per wave: no partial sectors).  The value comes straight
-// out of an MFMA and hipcc inserts the MFMA -> VMEM-read wait states only for consumers it can see, so the asm carries
-// its own: 2 x s_nop 15 = 32 wait states, above the 18 the longest MFMA needs.
+// One 16-byte write-through store per lane (whole 1 KiB tiles per wave: no partial sectors).  NOTE: hipcc inserts the
+// MFMA -> VMEM-read wait states only for consumers it can see, so the value handed in must come from a VALU instruction
+// (here: the accumulator times the row's unscale factor), never straight out of an MFMA.
 __device__ __forceinline__ void store16_sc1(unsigned char* p, f32x4 v) {
-    asm volatile("s_nop 15\n\ts_nop 15\n\tglobal_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void store16_plain(unsigned char* p, f32x4 v) {      // XCD-local groups only
-    asm volatile("s_nop 15\n\ts_nop 15\n\tglobal_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
 }
 
 // Backward: dh(t) = d_out(t) + da(t+1) . W_hh.  The reduction runs over all 4H gate units, which live 64 per workgroup,
 // so instead of every workgroup fetching all of da(t+1) (128 KB) each one multiplies ITS OWN 64 gate units -- straight
-// from LDS, as bf16 pieces -- into a partial dh for all H hidden units and hands 16x16 fp32 tiles to their owners:
+// from LDS, as fp16 x 2 pieces scaled per utterance row by a power of two taken from the row's own maximum, so gradients
+// of any magnitude keep 22 significand bits -- into a partial dh for all H hidden units and hands 16x16 fp32 tiles to their owners:
 //     producer jt:  P_jt[b, :] = da(t+1)[b, units of jt] . W_hh[units of jt, :]        [16 x 64] . [64 x H]
 //     consumer jt': dh(t)[b, j in jt'] = d_out + sum over the JT producers of P_jt[b, j]
 // Exchange buffer: [2 ping-pong][2 dir][nbt][JT consumers][JT producers][64 lanes][4 f32] (a tile in MFMA accumulator order);
@@ -422,7 +432,8 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
     constexpr int JT = H / 16, CT = JT / NW, PW = JT / NW;      // column tiles (= consumers) / producers handled per wave
     static_assert(CT == 4 || CT == 2, "the persistent backward kernel is written for 2 or 4 column tiles per wave");
     __shared__ float red[NW][16][16];
-    __shared__ __attribute__((aligned(16))) unsigned short a_lds[2][3][64][8];      // own da(t) as A fragments: [k-step][piece]
+    __shared__ __attribute__((aligned(16))) unsigned short a_lds[2][2][64][8];      // own da(t) as A fragments: [k-step][piece]
+    __shared__ __attribute__((aligned(16))) float row_unscale[16];                  // 1 / (row scale * WSCALE) per utterance
     __shared__ int s_ok;
     if (prio & 1) __builtin_amdgcn_s_setprio(3);
     // timing experiments (wrong results unless noted): 1 no exchange loads, 2 no products, 4 no operand fetch, 8 no slab stores,
@@ -447,7 +458,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
 
     // B fragments, resident for the whole sequence.  Local reduction index k = gate*16 + unit (64 per workgroup): k-step ks,
     // lane (li = column, lq) holds k = 32*ks + 8*lq + e  ->  W_hh[(2*ks + lq/2)*H + jt*16 + 8*(lq%2) + e][(w*CT + ct)*16 + li]
-    bf16x8 bw[2][CT][3];
+    f16x8 bw[2][CT][2];
     {
         const float* W = dir == 0 ? whh_f : whh_b;
 #pragma unroll
@@ -458,7 +469,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
                 float x[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) x[i] = src[(long)i * H];
-                split8(x, bw[ks][ct][0], bw[ks][ct][1], bw[ks][ct][2]);
+                split8_f16(x, WSCALE, bw[ks][ct][0], bw[ks][ct][1]);
             }
     }
 
@@ -551,31 +562,38 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
 #pragma unroll
                 for (int g = 0; g < 4; ++g) bsum[g] += da[g];
             }
+            // power-of-two scale of this utterance's 64 gate units (16 lanes x 4 gates): its maximum lands in [2^7, 2^8)
+            const float rmax = row16_max(fmaxf(fmaxf(fabsf(da[0]), fabsf(da[1])), fmaxf(fabsf(da[2]), fabsf(da[3]))));
+            int se = 261 - (int)(__float_as_uint(rmax) >> 23);
+            se = se < 1 ? 1 : (se > 187 ? 187 : se);
+            const float rsc = __uint_as_float((unsigned)se << 23);
+            if (jj == 0) row_unscale[bi] = __uint_as_float((unsigned)(250 - se) << 23);      // 2^(127 - se) / WSCALE
             // own gate units as A fragments in LDS: k = g*16 + jj  ->  k-step g/2, lane 16*((g%2)*2 + jj/8) + bi, element jj%8
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                unsigned h, m, l;
-                split1(da[g], h, m, l);
+                unsigned h, l;
+                split1_f16(da[g] * rsc, h, l);
                 const int la = ((g & 1) * 2 + (jj >> 3)) * 16 + bi;
                 a_lds[g >> 1][0][la][jj & 7] = (unsigned short)h;
-                a_lds[g >> 1][1][la][jj & 7] = (unsigned short)m;
-                a_lds[g >> 1][2][la][jj & 7] = (unsigned short)l;
+                a_lds[g >> 1][1][la][jj & 7] = (unsigned short)l;
             }
             cur = nxt;
         }
         __syncthreads();
         if (st + 1 < T && !(diag & 2)) {                  // partial dh(t-1) of my gate units for every hidden unit
-            bf16x8 a[2][3];
+            f16x8 a[2][2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) a[ks][pc] = *reinterpret_cast<const bf16x8*>(&a_lds[ks][pc][lane][0]);
+                for (int pc = 0; pc < 2; ++pc) a[ks][pc] = *reinterpret_cast<const f16x8*>(&a_lds[ks][pc][lane][0]);
+            const f32x4 us = *reinterpret_cast<const f32x4*>(&row_unscale[lq * 4]);      // accumulator rows 4*lq + r
             unsigned char* q = xwr + ((st + 1) & 1) * half;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                acc = mfma6(a[0], bw[0][ct], acc);
-                acc = mfma6(a[1], bw[1][ct], acc);
+                acc = mfma3(a[0], bw[0][ct], acc);
+                acc = mfma3(a[1], bw[1][ct], acc);
+                acc *= us;
                 if (local) store16_plain(q + (long)ct * JT * 1024, acc);     // hand-off payload, group on one XCD: the shared L2 has it
                 else store16_sc1(q + (long)ct * JT * 1024, acc);              // group spans XCDs: write-through
             }
