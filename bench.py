@@ -83,6 +83,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--precision', choices=['f32', 'bf16'], default='f32',
                     help="f32 (default): the 1e-4 parity mode the headline is quoted on; bf16: BASELINE configs 2-4's arithmetic")
+    ap.add_argument('--stream', choices=['default', 'own'], default='default', help='launch the steps on the default stream or on a stream of their own')
     ap.add_argument('--tune', action='append', default=[], metavar='KEY=VALUE', help='experiment knob of the HIP library (ss_tune)')
     args = ap.parse_args()
 
@@ -132,6 +133,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.stream == 'own':
+        own = torch.cuda.Stream(dev)
+        own.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(own)
     for _ in range(args.warmup):
         step()
     barrier()

@@ -278,6 +278,31 @@ __global__ __launch_bounds__(256) void add_vec_kernel(const float* __restrict__ 
     if (i < n) out[i] = a[i] + b[i];
 }
 
+// Per-step parameter re-layouts of every LSTM block in ONE launch (they used to be ~30 launches of a few microseconds
+// each, a chain the streams beside it ended up waiting for): task t is  dst = a + b  (b == nullptr: a copy).
+// grid = (PREP_BLOCKS, number of tasks), block 256
+constexpr int PREP_BLOCKS = 64;
+__global__ __launch_bounds__(256) void prep_kernel(PrepTable tb) {
+    const PrepTask t = tb.t[blockIdx.y];
+    const long stride = (long)PREP_BLOCKS * 256;
+    const bool vec = (t.n & 3) == 0 && (((size_t)t.a | (size_t)t.b | (size_t)t.dst) & 15) == 0;
+    if (vec) {
+        const float4* a = reinterpret_cast<const float4*>(t.a);
+        const float4* b = reinterpret_cast<const float4*>(t.b);
+        float4* d = reinterpret_cast<float4*>(t.dst);
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < t.n / 4; i += stride) {
+            float4 v = a[i];
+            if (b) {
+                const float4 w = b[i];
+                v.x += w.x, v.y += w.y, v.z += w.z, v.w += w.w;
+            }
+            d[i] = v;
+        }
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < t.n; i += stride) t.dst[i] = t.a[i] + (t.b ? t.b[i] : 0.f);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ decoder input
 struct CodeSrcPack {
     CodeSrc s[4];
@@ -495,6 +520,12 @@ hipError_t transpose2d(const float* in, int R, int C, float* out, hipStream_t s)
 
 hipError_t add_vec(const float* a, const float* b, float* out, int n, hipStream_t s) {
     hipLaunchKernelGGL(add_vec_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, a, b, out, n);
+    return hipGetLastError();
+}
+
+hipError_t prep_run(const PrepTable& tb, hipStream_t s) {
+    if (tb.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(prep_kernel, dim3(PREP_BLOCKS, tb.n), dim3(256), 0, s, tb);
     return hipGetLastError();
 }
 

@@ -573,15 +573,16 @@ int make_chains(ss_engine* e, int B, hipStream_t s, Chain ch[2]) {
 
 // Per-step re-layouts of one BLSTM block's weights: b_ih + b_hh per (layer, direction) and, for the decoder-size blocks,
 // the fragment-major W_hh of the forward recurrence.  Independent of the activations, so the schedule runs it on a branch.
-int lstm_prep(ss_engine* e, LstmBlk& lb, hipStream_t s) {
+int lstm_prep(ss_engine* e, LstmBlk& lb, PrepTable& tb, hipStream_t s) {
     const int H = lb.H;
     const bool persist = lb.big() && g_persist && lstm_seq_supported(e->curB, H);
     for (int l = 0; l < lb.L; ++l) {
         for (int dir = 0; dir < 2; ++dir) {
             const LstmDir& pd = lb.pd[l * 2 + dir];
-            HIPCHK(add_vec(e->P + pd.bih, e->P + pd.bhh, lb.bsum + ((long)l * 2 + dir) * 4 * H, 4 * H, s));
             const long n = 4L * H * lb.in_of(l);
-            HIPCHK(hipMemcpyAsync(lb.wcat[l] + dir * n, e->P + pd.wih, n * 4, hipMemcpyDeviceToDevice, s));
+            if (tb.n + 2 > PREP_MAX) return fail("lstm_prep: task table full");
+            tb.t[tb.n++] = {e->P + pd.bih, e->P + pd.bhh, lb.bsum + ((long)l * 2 + dir) * 4 * H, 4L * H};       // summed biases
+            tb.t[tb.n++] = {e->P + pd.wih, nullptr, lb.wcat[l] + dir * n, n};                                    // stacked W_ih
         }
         // fragment-major W_hh for the one-launch-per-step schedule (the persistent kernels read the parameters directly)
         if (lb.big() && !persist) HIPCHK(lstm_pack_w(e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.wfrag[l], H, 0, s));
@@ -866,16 +867,24 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
         e->ev_next = (e->ev_next + 1) & 15;
         HIPCHK(hipEventRecord(packed, b2));
     }
-    if (g3) CHK(lstm_prep(e, e->l1, b2));
-    CHK(lstm_prep(e, e->l2, b2));
-    CHK(lstm_prep(e, e->lt, b2));
-    CHK(lstm_prep(e, e->ld, b2));
-    // Encoder_t (model.py:74-89)
-    CHK(conv_block_fwd(e, e->ct, Slab{e->org, e->hp.dim_freq}, Slab{e->act_t, e->hp.dim_enc_2}, b2));
-    CHK(lstm_fwd(e, e->lt, Slab{e->act_t, e->hp.dim_enc_2}, b2));
     for (int i = 0; i < 3; ++i) {
         float* y = training ? e->act : e->xf[i];
-        if (i == 1 && packed) HIPCHK(hipStreamWaitEvent(s, packed, 0));
+        if (i == 1) {
+            // Issue order matters: a cross-stream wait on ROCm holds for everything the other stream had been handed when
+            // the WAIT was issued, not only up to the recorded event (measured: the trunk stalled ~250 us behind the tiny
+            // launches below).  So: first trunk layer, the wait for the re-layouts, and only then the rest of b2's work.
+            if (packed) HIPCHK(hipStreamWaitEvent(s, packed, 0));
+            PrepTable tb;
+            tb.n = 0;
+            if (g3) CHK(lstm_prep(e, e->l1, tb, b2));
+            CHK(lstm_prep(e, e->l2, tb, b2));
+            CHK(lstm_prep(e, e->lt, tb, b2));
+            CHK(lstm_prep(e, e->ld, tb, b2));
+            HIPCHK(prep_run(tb, b2));
+            // Encoder_t (model.py:74-89)
+            CHK(conv_block_fwd(e, e->ct, Slab{e->org, e->hp.dim_freq}, Slab{e->act_t, e->hp.dim_enc_2}, b2));
+            CHK(lstm_fwd(e, e->lt, Slab{e->act_t, e->hp.dim_enc_2}, b2));
+        }
         if (g3) {
             Slab x1 = i == 0 ? Slab{e->in_mel, e->hp.dim_freq} : Slab{e->xf[i - 1], CE};
             CHK(conv_block_fwd(e, e->c1[i], x1, Slab{y, CE}, s));
@@ -1267,7 +1276,10 @@ int ss_g3_rhythm(ss_engine* e, const float* x_org, int B, int T, float* codes, v
     HIPCHK(copy_rows(x_org, h.dim_freq, (long)T * h.dim_freq, e->org + HALO * h.dim_freq, h.dim_freq, TP * h.dim_freq, B, T,
                      h.dim_freq, s));
     CHK(conv_pack_all(e, e->ct, s));
-    CHK(lstm_prep(e, e->lt, s));
+    PrepTable tb;
+    tb.n = 0;
+    CHK(lstm_prep(e, e->lt, tb, s));
+    HIPCHK(prep_run(tb, s));
     CHK(conv_block_fwd(e, e->ct, Slab{e->org, h.dim_freq}, Slab{e->act_t, h.dim_enc_2}, s));
     CHK(lstm_fwd(e, e->lt, Slab{e->act_t, h.dim_enc_2}, s));
     // codes = cat(fwd[:, 7::8], bwd[:, ::8]) (model.py:84-87): reuse the decoder-input assembler on a 2H-wide row and pick t % freq == 0

@@ -56,6 +56,19 @@ hipError_t conv_unpack_grad(const float* gp, int Co, int Ci, int Cp, float* g, h
 hipError_t transpose2d(const float* in, int R, int C, float* out, hipStream_t s);   // out[c][r] = in[r][c]
 // out[i] = a[i] + b[i]
 hipError_t add_vec(const float* a, const float* b, float* out, int n, hipStream_t s);
+// dst = a + b (b null: copy) for a table of up to PREP_MAX vectors, one launch
+constexpr int PREP_MAX = 48;
+struct PrepTask {
+    const float* a;
+    const float* b;
+    float* dst;
+    long n;
+};
+struct PrepTable {
+    PrepTask t[PREP_MAX];
+    int n;
+};
+hipError_t prep_run(const PrepTable& tb, hipStream_t s);
 
 struct CodeSrc {          // one encoder BLSTM output feeding the decoder input (model.py:87, 223-227, 301-309)
     const float* o;       // [B, TP, 2*H]
