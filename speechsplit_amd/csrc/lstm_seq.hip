@@ -423,7 +423,7 @@ __device__ __forceinline__ void store16_plain(unsigned char* p, f32x4 v) {      
 // stores are used, which is what makes this formulation pay (8 MB of sc1 traffic per step costs ~1.8 us of every step).
 // sync: as in the forward kernel.
 template <int H, int NW>
-__global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict__ gates, const float* __restrict__ whh_f,
+__global__ __launch_bounds__(64 * (NW + 1)) void lstm_seq_bwd_kernel(float* __restrict__ gates, const float* __restrict__ whh_f,
                                                                const float* __restrict__ whh_b, unsigned char* __restrict__ xb,
                                                                const float* __restrict__ d_out, const float* __restrict__ csave,
                                                                unsigned* __restrict__ sync, unsigned* __restrict__ amax,
@@ -437,9 +437,15 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
     __shared__ int s_ok;
     if (prio & 1) __builtin_amdgcn_s_setprio(3);
     // timing experiments (wrong results unless noted): 1 no exchange loads, 2 no products, 4 no operand fetch, 8 no slab stores,
-    // 16 no waits, 32 ordinary tile stores even if the group spans XCDs, 64 operands from two hot rows
+    // 16 no waits, 32 ordinary tile stores even if the group spans XCDs, 64 operands from two hot rows, 128 idle helper wave
+    // (results stay right)
     const int diag = prio >> 1;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // Wave NW is a helper: it owns no tile and no cell, it only touches the operand rows the cell threads will fetch a few
+    // steps later, so that those fetches come out of the L2 (and a warm TLB) instead of HBM.  The memory counter is per
+    // wave: the helper can afford the ~2 us an HBM + TLB miss costs, the waves on the hand-off path cannot (whatever they
+    // have outstanding sits in front of their next s_waitcnt vmcnt(0)).
+    const bool helper = w == NW;
     const int ngroups = 2 * nbt;
     const int grp = blockIdx.x % ngroups, jt = blockIdx.x / ngroups;
     const int dir = grp / nbt, bt = grp % nbt;
@@ -458,8 +464,8 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
 
     // B fragments, resident for the whole sequence.  Local reduction index k = gate*16 + unit (64 per workgroup): k-step ks,
     // lane (li = column, lq) holds k = 32*ks + 8*lq + e  ->  W_hh[(2*ks + lq/2)*H + jt*16 + 8*(lq%2) + e][(w*CT + ct)*16 + li]
-    f16x8 bw[2][CT][2];
-    {
+    f16x8 bw[2][CT][2] = {};
+    if (!helper) {
         const float* W = dir == 0 ? whh_f : whh_b;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -516,9 +522,36 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
         tau_p = -1;
     };
 
-    for (int st = 0; st < T; ++st) {
+    if (helper) {
+        constexpr int AHEAD = 3;                       // the cell threads fetch step st + 1 during step st
+        const int u = lane & 15, q = lane >> 4;        // lane -> (utterance, 64-byte segment): 4 gate segments, d_out, c
+        const int bu = bt * 16 + u < B ? bt * 16 + u : B - 1;
+        float v0 = 0.f, v1 = 0.f, sink = 0.f;
+        for (int st = 0; st < T; ++st) {
+            sink += v0 + v1;                           // consumes last step's loads: nothing is in flight past this point
+            if (st + AHEAD < T && !(diag & 128)) {
+                const int tau = tau_of(st + AHEAD);
+                v0 = gates[((long)bu * TP + tau) * (8 * H) + dir * 4 * H + q * H + jt * 16];
+                const long oo = ((long)bu * TP + tau) * (2 * H) + dir * H + jt * 16;
+                if (q == 0) v1 = d_out[oo];
+                if (q == 1) v1 = csave[oo];
+            }
+            if (st > 0) {                              // the same barriers as the working waves, in the same order
+                __syncthreads();
+                if (!s_ok) return;
+            }
+            __syncthreads();
+            __syncthreads();
+            __syncthreads();
+        }
+        if (sink == 1.2345e-30f && T < 0) gates[0] = sink;      // never true: keeps the loads alive
+    }
+    for (int st = 0; st < T && !helper; ++st) {
         const int tau = tau_of(st);
-        if (cell && st + 1 < T && !(diag & 4)) nxt = fetch((diag & 64) ? (st & 1) : st + 1);     // 64: always the same two rows (cache-hot)
+        // next step's operands: requested behind this step's tile loads (see the forward kernel)
+        auto prefetch = [&]() {
+            if (cell && st + 1 < T && !(diag & 4)) nxt = fetch((diag & 64) ? (st & 1) : st + 1);     // 64: always the same two rows (cache-hot)
+        };
         f32x4 part = {0.f, 0.f, 0.f, 0.f};
         if (st > 0) {
             if (w == 0) {
@@ -534,12 +567,15 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(float* __restrict
                 for (int i = 0; i < PW; ++i) r[i] = u32x4{0u, 0u, 0u, 0u};
             } else if constexpr (PW == 4) load4_sc1(p, r);
             else load2_sc1(p, r);
+            prefetch();
             flush_slab();                               // last step's slab copy: its acks hide behind the cell math and products
 #pragma unroll
             for (int i = 0; i < PW; ++i) {
                 const f32x4 v = __builtin_bit_cast(f32x4, r[i]);
                 part += v;
             }
+        } else {
+            prefetch();
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[w][lq * 4 + r][li] = part[r];
@@ -671,8 +707,8 @@ hipError_t lstm_seq_bwd(float* gates, const float* whh_f, const float* whh_b, vo
         if (e != hipSuccess) return e;
     }
     unsigned char* xb = static_cast<unsigned char*>(xbuf);
-    if (H == 512) hipLaunchKernelGGL((lstm_seq_bwd_kernel<512, 8>), dim3(2 * nbt * 32), dim3(512), 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, reinterpret_cast<unsigned*>(amax), gbias_f, gbias_b, B, T, nbt, g_seq_prio);
-    else          hipLaunchKernelGGL((lstm_seq_bwd_kernel<256, 8>), dim3(2 * nbt * 16), dim3(512), 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, reinterpret_cast<unsigned*>(amax), gbias_f, gbias_b, B, T, nbt, g_seq_prio);
+    if (H == 512) hipLaunchKernelGGL((lstm_seq_bwd_kernel<512, 8>), dim3(2 * nbt * 32), dim3(576), 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, reinterpret_cast<unsigned*>(amax), gbias_f, gbias_b, B, T, nbt, g_seq_prio);
+    else          hipLaunchKernelGGL((lstm_seq_bwd_kernel<256, 8>), dim3(2 * nbt * 16), dim3(576), 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, reinterpret_cast<unsigned*>(amax), gbias_f, gbias_b, B, T, nbt, g_seq_prio);
     return hipGetLastError();
 }
 

@@ -274,7 +274,7 @@ def bench_seq(B=64, T=128, H=512):
     tune('persist', 1)
     # where a backward step's time goes: seq_prio bit 0 = s_setprio, bits 1.. = ablations (wrong results)
     for dg, what in [(0, 'full'), (1, 'no exchange loads'), (2, 'no products / tile stores'), (4, 'no operand fetch'), (8, 'no slab stores'),
-                     (16, 'no wait'), (31, 'nothing but the barriers + cell math'), (32, 'tile stores without sc1'), (64, 'operand fetch from two hot rows'), (96, 'plain tile stores + hot operand rows'), (36, 'plain tile stores + no operand fetch'),
+                     (16, 'no wait'), (128, 'idle helper wave (results right)'), (31, 'nothing but the barriers + cell math'), (32, 'tile stores without sc1'), (64, 'operand fetch from two hot rows'), (96, 'plain tile stores + hot operand rows'), (36, 'plain tile stores + no operand fetch'),
                      (44, 'plain tile stores, no fetch, no slab stores')]:
         tune('seq_prio', 1 | (dg << 1))
         tb = timeit(bwd)[0] - timeit(copy_only)[0]
