@@ -24,6 +24,7 @@ int g_fwd_f16x2 = 1;   // 1: forward contractions (operands bounded by construct
 int g_bwd_f16x2 = 1;   // 1: the decoder's and the conv trunk's gradient GEMMs also use fp16 x 2: the gradient operand is scaled by the power
                        //    of two its producer kernel measured (max |value| of the slab), the activation / weight operand by the fixed one
 int g_overlap = 1;     // 1: weight-gradient GEMMs on the side stream
+int g_dx_batched = 2;  // input-gradient GEMMs per utterance without halo rows; 2: with 128 x 128 tiles from 512 workgroups on
 int g_defer_dw = 1;    // 1: the decoder's weight-gradient GEMMs start after its last input gradient (see lstm_bwd)
 int g_side_prio = 0;   // 1: create the side stream with the lowest priority (read at ss_bind).  Measured: 2.3x SLOWER
                        //    (35 ms vs 14.8 ms per step): the low-priority queue starves behind 768 tiny step launches.
@@ -725,7 +726,8 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
 int lstm_input_grad(ss_engine* e, LstmBlk& lb, int l, Slab dxi, long r0, long nr, const float* am, hipStream_t st) {
     // dX[r][k] = sum over both directions' 8H gate units of dG[r][n] * W_ih[n][k]: ONE GEMM against the stacked weights
     // (lstm_prep).  A narrow input (the decoder's 164 columns) is cut along the reduction so the launch still fills the chip.
-    const int H = lb.H, In = lb.in_of(l);
+    const int H = lb.H, In = lb.in_of(l), T = e->curT;
+    const long TPr = T + 2 * HALO;
     GemmDesc g{};
     g.A = {lb.gates[l] + r0 * 8L * H, 8L * H, 0, 0, 0};
     g.B = {lb.wcat[l], In, 0, 0, 0};
@@ -743,6 +745,15 @@ int lstm_input_grad(ss_engine* e, LstmBlk& lb, int l, Slab dxi, long r0, long nr
         g.ksplit = tiles < 256 ? 4 : 2;
         g.flags |= GEMM_ACCUM;
         HIPCHK(hipMemsetAsync(g.C, 0, nr * dxi.ld * 4, st));
+    } else if (g_dx_batched && nr % TPr == 0 && r0 % TPr == 0 && T % 128 == 0) {
+        // whole utterances: leave the halo rows out (nobody reads them in a gradient slab) -- one batch entry per
+        // utterance, T rows each, which also makes the 128 x 128 tiling come out at exactly 2 workgroups per CU for B = 64
+        g.A = {lb.gates[l] + (r0 + HALO) * 8L * H, 8L * H, TPr * 8L * H, 0, 0};
+        g.C = dxi.p + (r0 + HALO) * dxi.ld;
+        g.cstride = TPr * dxi.ld;
+        g.M = T;
+        g.batch = (int)(nr / TPr);
+        g.want = g_dx_batched == 2 ? 512 : 0;
     }
     GEMM_ON(g, st);
     return 0;
@@ -1518,6 +1529,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "lstm_mode" && value >= 0 && value <= 4) g_lstm_mode = value;
     else if (k == "overlap" && (value == 0 || value == 1)) g_overlap = value;
     else if (k == "defer_dw" && (value == 0 || value == 1)) g_defer_dw = value;
+    else if (k == "dx_batched" && value >= 0 && value <= 2) g_dx_batched = value;
     else if (k == "graph" && (value == 0 || value == 1)) g_graph = value;
     else if (k == "split" && (value == 0 || value == 1)) g_split = value;
     else if (k == "persist" && (value == 0 || value == 1)) g_persist = value;

@@ -341,7 +341,7 @@ template <bool TA, bool TB>
 hipError_t launch_layout(const GemmDesc& d, hipStream_t s) {
     auto tiles = [&](int bm, int bn) { return (long)cdiv(d.M, bm) * cdiv(d.N, bn) * d.batch * d.ksplit; };
     // reduction-major operands pay more per staged element, so they prefer the largest tile sooner
-    const long want = (TA && TB && g_gemm_want > 256) ? 256 : g_gemm_want;
+    const long want = d.want > 0 ? d.want : ((TA && TB && g_gemm_want > 256) ? 256 : g_gemm_want);
     if (d.N > 64 && d.M > 64 && tiles(128, 128) >= want) return launch_cfg<128, 128, TA, TB>(d, s);
     if (d.M > 64 && tiles(128, 64) >= want) return launch_cfg<128, 64, TA, TB>(d, s);
     return launch_cfg<64, 64, TA, TB>(d, s);
