@@ -55,6 +55,13 @@ hipError_t gemm_phase_probe(unsigned long long out[24], bool reset);
 // tanhf (range reduction, branches) cost a few hundred cycles per step; these use the hardware exp2 / rcp.  Absolute error
 // <= 2e-7 (sigmoid) and <= 3e-7 (tanh, with a series below |x| = 0.08 where the quotient form would cancel).
 #ifdef __HIPCC__
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a release fence over ALL memory, for which
+// hipcc emits s_waitcnt vmcnt(0): every barrier then also waits for the outstanding global stores / loads of the wave
+// (~1 us each trip).  In the recurrence kernels the step barriers only hand LDS data between waves; what leaves for
+// global memory is fire-and-forget (or is waited for explicitly where a hand-off needs it).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 __device__ __forceinline__ float ss_sigmoid(float x) {
     return __frcp_rn(1.0f + __expf(-x));
 }

@@ -18,6 +18,7 @@
 using namespace ss;
 
 namespace ss {
+extern int g_small_lds;
 extern int g_lstm_nw, g_lstm_g, g_lstm_mode, g_gemm_bk, g_gemm_want, g_gemm_diag, g_seq_prio, g_gemm_mode;
 int g_fwd_f16x2 = 1;   // 1: forward contractions (operands bounded by construction: mel, one-hot, GroupNorm/ReLU outputs, |h| < 1, weights)
                        //    use the fp16 x 2 split (3 MFMAs) instead of bf16 x 3 (6 MFMAs); gradients keep bf16 x 3 (their range is not bounded)
@@ -25,6 +26,7 @@ int g_bwd_f16x2 = 1;   // 1: the decoder's and the conv trunk's gradient GEMMs a
                        //    of two its producer kernel measured (max |value| of the slab), the activation / weight operand by the fixed one
 int g_overlap = 1;     // 1: weight-gradient GEMMs on the side stream
 int g_dx_batched = 2;  // input-gradient GEMMs per utterance without halo rows; 2: with 128 x 128 tiles from 512 workgroups on
+int g_conv_want = 0;    // experiment: workgroup target of the conv GEMMs' tile choice (0: library default)
 int g_defer_dw = 1;    // 1: the decoder's weight-gradient GEMMs start after its last input gradient (see lstm_bwd)
 int g_side_prio = 0;   // 1: create the side stream with the lowest priority (read at ss_bind).  Measured: 2.3x SLOWER
                        //    (35 ms vs 14.8 ms per step): the low-priority queue starves behind 768 tiny step launches.
@@ -508,6 +510,7 @@ int conv_block_fwd(ss_engine* e, ConvBlk& cb, Slab x, Slab y, hipStream_t s) {
     d.K = 5 * cb.Cp;
     d.batch = B;
     d.ksplit = 1;
+    d.want = g_conv_want;
     GEMM_FWD_ON(d, s);
     HIPCHK(gn_relu_fwd(cb.cout, cb.Co, TP * cb.Co, y.p, y.ld, TP * y.ld, e->P + cb.ga, e->P + cb.be, cb.stats, B, T, cb.Co, s));
     return 0;
@@ -550,6 +553,7 @@ int conv_block_bwd(ss_engine* e, ConvBlk& cb, Slab dy, Slab x, Slab dx, hipStrea
         g.ksplit = 1;
         g.flags = am ? GEMM_F16X2 : 0;
         g.amax_a = am;
+        g.want = g_conv_want;
         GEMM(g);
     }
     return 0;
@@ -1530,6 +1534,8 @@ int ss_tune(const char* key, int value) {
     else if (k == "overlap" && (value == 0 || value == 1)) g_overlap = value;
     else if (k == "defer_dw" && (value == 0 || value == 1)) g_defer_dw = value;
     else if (k == "dx_batched" && value >= 0 && value <= 2) g_dx_batched = value;
+    else if (k == "conv_want" && value >= 0) g_conv_want = value;
+    else if (k == "small_lds" && (value == 0 || value == 1)) g_small_lds = value;
     else if (k == "graph" && (value == 0 || value == 1)) g_graph = value;
     else if (k == "split" && (value == 0 || value == 1)) g_split = value;
     else if (k == "persist" && (value == 0 || value == 1)) g_persist = value;
