@@ -63,11 +63,11 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 __device__ __forceinline__ float ss_sigmoid(float x) {
-    return __frcp_rn(1.0f + __expf(-x));
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));        // v_rcp_f32 (1 ulp); the IEEE division sequence is ~10 dependent instructions
 }
 __device__ __forceinline__ float ss_tanh(float x) {
     const float e = __expf(2.0f * x);                       // inf for large x -> 1 - 0;  0 for very negative x -> 1 - 2
-    const float q = 1.0f - 2.0f * __frcp_rn(e + 1.0f);
+    const float q = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
     const float x2 = x * x;
     const float p = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * -0.05396825f)));
     return fabsf(x) < 0.08f ? p : q;

@@ -144,6 +144,17 @@ __device__ __forceinline__ float row16_max(float v) {
     x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, true));      // row_ror:8
     return __int_as_float(x);
 }
+// The same three products for N independent accumulators, interleaved so that consecutive MFMAs never depend on each other;
+// per accumulator the order of the terms is that of mfma3 (bit-identical results).
+template <int N, typename BF>
+__device__ __forceinline__ void mfma3_each(const f16x8 (&a)[2], BF&& b, f32x4 (&acc)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b(i, 1), acc[i], 0, 0, 0);     // h.l
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], b(i, 0), acc[i], 0, 0, 0);     // l.h
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b(i, 0), acc[i], 0, 0, 0);     // h.h
+}
 __device__ __forceinline__ void load2x2_sc1(const unsigned char* p0, const unsigned char* p1, u32x4 (&r)[2][2]) {
     asm volatile(
         "global_load_dwordx4 %0, %4, off sc1\n\t"
@@ -260,7 +271,9 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
                                                                unsigned* __restrict__ sync, int B, int T, int nbt, int prio) {
     constexpr int JT = H / 16, KC = H / 32, KS = H / NW / 32;       // KS k-steps of 32 per wave
     static_assert(KS == 2, "the persistent forward kernel is written for 64 reduction elements per wave");
-    __shared__ float red[NW][4][16][16];
+    // per-wave partial sums, [unit column][utterance row], rows padded to 20 floats: a lane writes its four accumulator rows
+    // with one ds_write_b128 and the cell threads' reads spread over all 32 banks
+    __shared__ __attribute__((aligned(16))) float red[NW][4][16][20];
     __shared__ int s_ok;
     if (prio & 1) __builtin_amdgcn_s_setprio(3);  // the recurrence is the critical path; co-resident GEMM waves are filler
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -271,7 +284,9 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
     const int li = lane & 15, lq = lane >> 4;
     unsigned* flags = sync + 64 + 32 * grp;
     unsigned* abortp = sync;
-    const int diag = prio >> 1;                            // 32: ordinary stores regardless (timing experiment)
+    // timing experiments (wrong results): 1 no exchange loads, 2 no payload stores, 4 no input prefetch, 8 no slab stores,
+    // 16 no waiting, 32 ordinary stores regardless
+    const int diag = prio >> 1;
     if (w == 0) {
         const int r = group_locality(flags, jt, JT, sync + 1 + grp, abortp);
         if (lane == 0) s_ok = r;
@@ -317,7 +332,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
     float sv_p[4] = {0.f, 0.f, 0.f, 0.f}, c_p = 0.f, h_p = 0.f;
     int tau_p = -1;
     auto flush_slabs = [&]() {
-        if (cell && b < B && tau_p >= 0) {
+        if (cell && b < B && tau_p >= 0 && !(diag & 8)) {
             float* gr = grow_of(tau_p);
 #pragma unroll
             for (int g = 0; g < 4; ++g) gr[g * H] = sv_p[g];
@@ -330,7 +345,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
 
     for (int st = 0; st < T; ++st) {
         const int tau = tau_of(st);
-        if (cell && st + 1 < T) {                       // next step's input projection, requested before the wait
+        if (cell && st + 1 < T && !(diag & 4)) {        // next step's input projection, requested before the wait
             const float* gn = grow_of(tau_of(st + 1));
 #pragma unroll
             for (int g = 0; g < 4; ++g) xn[g] = gn[g * H];
@@ -340,7 +355,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
         for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (st > 0) {                                   // h(-1) = 0: nothing to multiply at the first step
             if (w == 0) {
-                const bool ok = wait_flags(flags, JT, (unsigned)(st + 1), abortp);
+                const bool ok = (diag & 16) ? true : wait_flags(flags, JT, (unsigned)(st + 1), abortp);
                 if (lane == 0) s_ok = ok ? 1 : 0;
             }
             __syncthreads();
@@ -348,23 +363,22 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
             const unsigned char* p0 = xrd + (st & 1) * half;
             const unsigned char* p1 = p0 + plane;
             u32x4 r[KS][2];
-            load2x2_sc1(p0, p1, r);
+            if (diag & 1) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) r[ks][0] = r[ks][1] = u32x4{0u, 0u, 0u, 0u};
+            } else load2x2_sc1(p0, p1, r);
             flush_slabs();                              // last step's slab copies: their acks hide behind the products below
             {
                 const f16x8 a[2] = {__builtin_bit_cast(f16x8, r[0][0]), __builtin_bit_cast(f16x8, r[0][1])};
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = mfma3(a, bw[g][0], acc[g]);
+                mfma3_each<4>(a, [&](int g, int pc) -> const f16x8& { return bw[g][0][pc]; }, acc);
             }
             {
                 const f16x8 a[2] = {__builtin_bit_cast(f16x8, r[1][0]), __builtin_bit_cast(f16x8, r[1][1])};
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = mfma3(a, bw[g][1], acc[g]);
+                mfma3_each<4>(a, [&](int g, int pc) -> const f16x8& { return bw[g][1][pc]; }, acc);
             }
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[w][g][lq * 4 + r][li] = acc[g][r];
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(&red[w][g][li][lq * 4]) = acc[g];
         __syncthreads();
         if (cell) {
             float pre[4];
@@ -372,7 +386,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
             for (int g = 0; g < 4; ++g) {
                 float s = 0.f;
 #pragma unroll
-                for (int ww = 0; ww < NW; ++ww) s += red[ww][g][bi][jj];
+                for (int ww = 0; ww < NW; ++ww) s += red[ww][g][jj][bi];
                 pre[g] = xg[g] + s * (1.0f / (HSCALE * WSCALE));
             }
             const float gi = sigmoidf_(pre[0]), gf = sigmoidf_(pre[1]), gg = ss_tanh(pre[2]), go = sigmoidf_(pre[3]);
@@ -383,7 +397,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
             sv[2] = gg;
             sv[3] = go;
             // the hand-off payload: write-through, first (rows past B carry garbage nobody stores downstream)
-            xb_store(xwr + ((st + 1) & 1) * half, plane, j, bi, h_val, local);
+            if (!(diag & 2)) xb_store(xwr + ((st + 1) & 1) * half, plane, j, bi, h_val, local);
 #pragma unroll
             for (int g = 0; g < 4; ++g) xg[g] = xn[g];
         }
@@ -403,12 +417,14 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
 
 // One 16-byte write-through store per lane (whole 1 KiB tiles per wave: no partial sectors).  NOTE: hipcc inserts the
 // MFMA -> VMEM-read wait states only for consumers it can see, so the value handed in must come from a VALU instruction
-// (here: the accumulator times the row's unscale factor), never straight out of an MFMA.
+// (here: the accumulator times the row's unscale factor), never straight out of an MFMA.  The trailing s_nop covers the other
+// hazard hipcc cannot see through the asm: the data registers of a store wider than 64 bits must not be rewritten in the two
+// wait states after it.
 __device__ __forceinline__ void store16_sc1(unsigned char* p, f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void store16_plain(unsigned char* p, f32x4 v) {      // XCD-local groups only
-    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
 // Backward: dh(t) = d_out(t) + da(t+1) . W_hh.  The reduction runs over all 4H gate units, which live 64 per workgroup,
@@ -431,7 +447,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_seq_bwd_kernel(float* __re
                                                                int nbt, int prio) {
     constexpr int JT = H / 16, CT = JT / NW, PW = JT / NW;      // column tiles (= consumers) / producers handled per wave
     static_assert(CT == 4 || CT == 2, "the persistent backward kernel is written for 2 or 4 column tiles per wave");
-    __shared__ float red[NW][16][16];
+    __shared__ __attribute__((aligned(16))) float red[NW][16][20];      // [unit column][utterance row, padded], see the forward kernel
     __shared__ __attribute__((aligned(16))) unsigned short a_lds[2][2][64][8];      // own da(t) as A fragments: [k-step][piece]
     __shared__ __attribute__((aligned(16))) float row_unscale[16];                  // 1 / (row scale * WSCALE) per utterance
     __shared__ int s_ok;
@@ -577,13 +593,12 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_seq_bwd_kernel(float* __re
         } else {
             prefetch();
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[w][lq * 4 + r][li] = part[r];
+        *reinterpret_cast<f32x4*>(&red[w][li][lq * 4]) = part;
         __syncthreads();
         if (cell) {
             float s = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < NW; ++ww) s += red[ww][bi][jj];
+            for (int ww = 0; ww < NW; ++ww) s += red[ww][jj][bi];
             const float dh = cur.d_o + s;
             const float tc = ss_tanh(cur.cc);
             const float d_o = dh * tc;

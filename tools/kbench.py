@@ -280,6 +280,14 @@ def bench_seq(B=64, T=128, H=512):
         tb = timeit(bwd)[0] - timeit(copy_only)[0]
         say(f'   bwd ablation [{what:40s}]: {tb / T:.2f} us/step')
     tune('seq_prio', 1)
+    # forward: 16 = no waiting (one load pass, tags unchecked), 1 = no loads, 2 = no payload stores, 8... unused
+    def fwd_only():
+        _capi.check(lib.ss_op_lstm_fwd(P(gates), P(whh[0]), P(whh[1]), P(out), P(cs), P(scratch), scratch.numel(), B, T, H, S()))
+    for dg, what in [(0, 'full'), (16, 'no waiting'), (17, 'no waiting, no exchange loads'), (19, '... and no payload stores'), (23, '... and no input prefetch'), (31, '... and no slab stores'), (4, 'no input prefetch only'), (8, 'no slab stores only')]:
+        tune('seq_prio', 1 | (dg << 1))
+        tf = timeit(fwd_only)[0]
+        say(f'   fwd ablation [{what:40s}]: {tf / T:.2f} us/step')
+    tune('seq_prio', 1)
 
 
 if __name__ == '__main__':
