@@ -18,7 +18,7 @@
 using namespace ss;
 
 namespace ss {
-extern int g_small_lds;
+extern int g_small_lds, g_gemm_tr;
 extern int g_lstm_nw, g_lstm_g, g_lstm_mode, g_gemm_bk, g_gemm_want, g_gemm_diag, g_seq_prio, g_gemm_mode;
 int g_fwd_f16x2 = 1;   // 1: forward contractions (operands bounded by construction: mel, one-hot, GroupNorm/ReLU outputs, |h| < 1, weights)
                        //    use the fp16 x 2 split (3 MFMAs) instead of bf16 x 3 (6 MFMAs); gradients keep bf16 x 3 (their range is not bounded)
@@ -1536,6 +1536,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "dx_batched" && value >= 0 && value <= 2) g_dx_batched = value;
     else if (k == "conv_want" && value >= 0) g_conv_want = value;
     else if (k == "small_lds" && (value == 0 || value == 1)) g_small_lds = value;
+    else if (k == "gemm_tr" && value >= 0 && value <= 2) g_gemm_tr = value;
     else if (k == "graph" && (value == 0 || value == 1)) g_graph = value;
     else if (k == "split" && (value == 0 || value == 1)) g_split = value;
     else if (k == "persist" && (value == 0 || value == 1)) g_persist = value;

@@ -16,6 +16,7 @@
 namespace ss {
 
 extern int g_gemm_want;
+int g_gemm_tr = 2;       // transposing LDS reads for reduction-major operands of 128-wide tiles: 1 wherever possible, 2 not for TN, 0 never
 int g_gemm_mode = 1;      // 0: exact-fp32 MFMA kernel (gemm_f32.hip), 1: bf16x3 kernel whenever operands are 16-byte aligned
 
 namespace {
@@ -75,8 +76,26 @@ __device__ __forceinline__ int lds_off(int row, int k) { return row * 64 + (((k 
 // summed over the first 64 workgroups: [wave][0 split+store, 1 barrier, 2 load issue, 3 fragments+MFMA, 4 barrier], [0][5] = k-tiles
 __device__ unsigned long long g_gemm_phase[4][6];
 
-template <int BM, int BN, bool TA, bool TB, int NPL, bool PROBE = false>
+// Image of a reduction-major (T) operand when TR is set (128-wide tiles only): the tile is kept in its SOURCE orientation,
+// [32 k-rows][128 tile rows] of 16-bit pieces, 256-byte rows with the 16-byte chunks XOR-swizzled; it is filled with one
+// float4 load per slot along the contiguous axis (as for a K-contiguous operand; the other image needs four dword loads
+// down the source rows per slot) and conflict-free 8-byte LDS writes, and the MFMA fragments come out of it through
+// gfx950's transposing LDS read (ds_read_b64_tr_b16: per 16 lanes a block of 4 k-rows x 16 tile rows, delivered
+// k-contiguous per lane), two per 8-element fragment.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int lds_off_t(int k, int x) { return k * 256 + (((x >> 3) ^ (((k & 3) << 2) | ((k >> 2) & 3))) << 4) + ((x & 7) << 1); }
+// o_lo / o_hi: this lane's byte offsets of its two 4-row blocks (k .. k+3, k+4 .. k+7) inside a plane
+__device__ __forceinline__ u32x4 tr_frag(const unsigned char* plane, int o_lo, int o_hi) {
+    typedef __attribute__((address_space(3))) s16x4* lptr;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(plane + o_lo));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(plane + o_hi));
+    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+    return u32x4{l2[0], l2[1], h2[0], h2[1]};
+}
+
+template <int BM, int BN, bool TA, bool TB, int NPL, bool PROBE = false, bool TR = false>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
+    constexpr bool TRA = TR && TA && BM == 128, TRB = TR && TB && BN == 128;
     constexpr int MI = BM / 64, NI = BN / 64;
     constexpr int PA = BM * 64, PB = BN * 64;                 // bytes per plane
     __shared__ __attribute__((aligned(16))) unsigned char As[NPL * PA];
@@ -127,8 +146,15 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
     const float* pb[NB];
     int wa[NA], wb[NB];
     bool oka[NA], okb[NB];
-    auto setup = [&](const Operand& op, const float* base, bool T, int x0, int X, int BX, int f, const float*& p, int& w, bool& ok) {
-        if (!T) {            // row = x0 + f/8, 4 consecutive k starting at (f%8)*4
+    auto setup = [&](const Operand& op, const float* base, bool T, bool TRX, int x0, int X, int BX, int f, const float*& p, int& w, bool& ok) {
+        if (TRX) {           // source row k = f / 32, 4 consecutive tile rows (source columns) from 4 * (f % 32)
+            const int c = x0 + 4 * (f % 32);
+            ok = c < X;                                        // X % 4 == 0 (launcher): a quad is inside or outside as a whole
+            const int cc = ok ? c : 0;
+            const int sg = op.seglen ? cc / op.seglen : 0;
+            w = 0;
+            p = base + (long)(kbeg + f / 32) * op.ld + (long)sg * op.segstride + (op.seglen ? cc - sg * op.seglen : cc);
+        } else if (!T) {     // row = x0 + f/8, 4 consecutive k starting at (f%8)*4
             const int r = x0 + f / 8, c = kbeg + (f % 8) * 4;
             ok = r < X;
             const int sg = op.seglen ? c / op.seglen : 0;
@@ -144,9 +170,9 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
         }
     };
 #pragma unroll
-    for (int i = 0; i < NA; ++i) setup(d.A, Ab, TA, m0, d.M, BM, tid + i * 256, pa[i], wa[i], oka[i]);
+    for (int i = 0; i < NA; ++i) setup(d.A, Ab, TA, TRA, m0, d.M, BM, tid + i * 256, pa[i], wa[i], oka[i]);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) setup(d.B, Bb, TB, n0, d.N, BN, tid + i * 256, pb[i], wb[i], okb[i]);
+    for (int i = 0; i < NB; ++i) setup(d.B, Bb, TB, TRB, n0, d.N, BN, tid + i * 256, pb[i], wb[i], okb[i]);
 
     typedef f32x4 Slot;
     // fp16 x 2 only: per-operand power-of-two scales (measured maximum or the fixed one), undone in the epilogue
@@ -154,9 +180,12 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
     const float sc_b = NPL == 2 ? (d.amax_b ? pow2_scale(*d.amax_b) : F16_SCALE) : 1.0f;
     // full: the whole k-tile lies inside [kbeg, kend), so the load needs no predicate at all (rows / columns past the
     // matrix edge read row / column 0: their products land in accumulator entries the epilogue never stores).
-    auto fetch = [&](const Operand& op, bool T, const float*& p, int& w, bool ok, int kpos, bool full) -> Slot {
+    auto fetch = [&](const Operand& op, bool T, bool TRX, const float*& p, int& w, bool ok, int kpos, bool full) -> Slot {
         Slot s = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!T) {
+        if (TRX) {
+            if (full || (ok && kpos < kend)) s = *reinterpret_cast<const f32x4*>(p);
+            if (!(d.diag & 4)) p += (long)BK * op.ld;
+        } else if (!T) {
             if (full) s = *reinterpret_cast<const f32x4*>(p);
             else if (ok && kpos < kend) {
                 if (kpos + 3 < kend) s = *reinterpret_cast<const f32x4*>(p);
@@ -189,19 +218,19 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int f = tid + i * 256;
-            ra[i] = fetch(d.A, TA, pa[i], wa[i], oka[i], TA ? k0 + 4 * (f / BM) : k0 + (f % 8) * 4, full);
+            ra[i] = fetch(d.A, TA, TRA, pa[i], wa[i], oka[i], TRA ? k0 + f / 32 : (TA ? k0 + 4 * (f / BM) : k0 + (f % 8) * 4), full);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int f = tid + i * 256;
-            rb[i] = fetch(d.B, TB, pb[i], wb[i], okb[i], TB ? k0 + 4 * (f / BN) : k0 + (f % 8) * 4, full);
+            rb[i] = fetch(d.B, TB, TRB, pb[i], wb[i], okb[i], TRB ? k0 + f / 32 : (TB ? k0 + 4 * (f / BN) : k0 + (f % 8) * 4), full);
         }
     };
     // split the prefetched fp32 values and write the three bf16 planes
-    auto sstore_one = [&](unsigned char* S, int P, bool T, int BX, int f, const Slot& s, float scale) {
+    auto sstore_one = [&](unsigned char* S, int P, bool T, bool TRX, int BX, int f, const Slot& s, float scale) {
         const int row = T ? f % BX : f / 8;
         const int k = T ? (f / BX) * 4 : (f % 8) * 4;
-        const int o = lds_off(row, k);
+        const int o = TRX ? lds_off_t(f / 32, 4 * (f % 32)) : lds_off(row, k);
         if (NPL == 1) {
             *reinterpret_cast<u32x2*>(S + o) = u32x2{round2(s[0], s[1]), round2(s[2], s[3])};
             return;
@@ -223,9 +252,9 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
     };
     auto sstore = [&]() {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) sstore_one(As, PA, TA, BM, tid + i * 256, ra[i], sc_a);
+        for (int i = 0; i < NA; ++i) sstore_one(As, PA, TA, TRA, BM, tid + i * 256, ra[i], sc_a);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) sstore_one(Bs, PB, TB, BN, tid + i * 256, rb[i], sc_b);
+        for (int i = 0; i < NB; ++i) sstore_one(Bs, PB, TB, TRB, BN, tid + i * 256, rb[i], sc_b);
     };
 
     f32x16 acc[MI][NI];
@@ -237,6 +266,11 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     const int l31 = lane & 31, kg = lane >> 5;
+    // transposing reads: lane 4q + pp of a 16-lane group addresses row k + q, tile rows x16 + 4pp .. of its block.  The k-step
+    // (16 rows = 4096 B) and the plane are constant byte offsets; the second 32-row sub-tile flips chunk bit 2 (XOR 64 B).
+    const int tq = (lane & 15) >> 2, tpp = lane & 3;
+    const int ta_lo = lds_off_t(kg * 8 + tq, wm * (BM / 2) + (lane & 16) + 4 * tpp), ta_hi = lds_off_t(kg * 8 + 4 + tq, wm * (BM / 2) + (lane & 16) + 4 * tpp);
+    const int tb_lo = lds_off_t(kg * 8 + tq, wn * (BN / 2) + (lane & 16) + 4 * tpp), tb_hi = lds_off_t(kg * 8 + 4 + tq, wn * (BN / 2) + (lane & 16) + 4 * tpp);
     const int nfull = (kend - kbeg) / BK;           // k-tiles that need no bounds checks
     if (nk > 0) gload(kbeg, false);
     unsigned long long ph[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
@@ -260,14 +294,20 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
                 const int row = wm * (BM / 2) + mi * 32 + l31;
                 const int o = lds_off(row, ks16 * 16 + kg * 8) * fskip;
 #pragma unroll
-                for (int p = 0; p < NPL; ++p) a[p][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + p * PA + o));
+                for (int p = 0; p < NPL; ++p) {
+                    if constexpr (TRA) a[p][mi] = __builtin_bit_cast(bf16x8, tr_frag(As + p * PA + ks16 * 4096, ta_lo ^ (mi * 64), ta_hi ^ (mi * 64)));
+                    else a[p][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + p * PA + o));
+                }
             }
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 const int row = wn * (BN / 2) + ni * 32 + l31;
                 const int o = lds_off(row, ks16 * 16 + kg * 8) * fskip;
 #pragma unroll
-                for (int p = 0; p < NPL; ++p) b[p][ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bs + p * PB + o));
+                for (int p = 0; p < NPL; ++p) {
+                    if constexpr (TRB) b[p][ni] = __builtin_bit_cast(bf16x8, tr_frag(Bs + p * PB + ks16 * 4096, tb_lo ^ (ni * 64), tb_hi ^ (ni * 64)));
+                    else b[p][ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bs + p * PB + o));
+                }
             }
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
@@ -329,6 +369,20 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
 template <int BM, int BN, bool TA, bool TB>
 hipError_t launch_cfg(const GemmDesc& d, hipStream_t s) {
     dim3 grid(cdiv(d.N, BN), cdiv(d.M, BM), d.batch * d.ksplit);
+    // transposing LDS reads for the reduction-major operands of 128-wide tiles: every 4-column quad must be loadable as one
+    // aligned float4 and lie inside one segment
+    auto quad_ok = [&](const Operand& op, bool T, int X) {
+        return !T || (X % 4 == 0 && op.ld % 4 == 0 && op.bstride % 4 == 0 && ((size_t)op.p & 15) == 0 &&
+                      (op.seglen == 0 || (op.seglen % 4 == 0 && op.segstride % 4 == 0)));
+    };
+    constexpr bool CAN_TR = (TA || TB) && (!TA || BM == 128) && (!TB || BN == 128);
+    if constexpr (CAN_TR) {
+        if (g_gemm_tr && (g_gemm_tr == 1 || !(TA && TB)) && !(d.flags & GEMM_BF16) && quad_ok(d.A, TA, d.M) && quad_ok(d.B, TB, d.N)) {
+            if (d.flags & GEMM_F16X2) hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB, 2, false, true>), grid, dim3(256), 0, s, d);
+            else hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB, 3, false, true>), grid, dim3(256), 0, s, d);
+            return hipGetLastError();
+        }
+    }
     if (d.flags & GEMM_BF16) hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB, 1>), grid, dim3(256), 0, s, d);
     else if (d.flags & GEMM_F16X2) hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB, 2>), grid, dim3(256), 0, s, d);
     else if ((d.diag & 16) && BM == 128 && BN == 128 && !TA && !TB)
