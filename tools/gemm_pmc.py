@@ -9,7 +9,7 @@ want = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 _capi.check(lib.ss_tune(b'gemm_want', want))
 if len(sys.argv) > 2:
     _capi.check(lib.ss_tune(b'gemm_diag', int(sys.argv[2])))
-shapes = [(8192, 4096, 1024, False, False, 1), (8192, 512, 2560, False, False, 1), (8448, 1024, 2048, False, True, 1),
+shapes = [(8192, 4096, 1024, False, False, 1), (8192, 512, 2560, False, False, 1), (8192, 1024, 4096, False, True, 1),
           (2048, 1024, 8448, True, True, 4), (2048, 512, 8447, True, True, 8)]
 for M, N, K, ta, tb, ks in shapes:
     A = torch.randn((K, M) if ta else (M, K), device='cuda')

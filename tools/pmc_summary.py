@@ -6,9 +6,9 @@ HBM-side bytes follow MI355X_MICROARCH.md's gfx950 recipe: read = 2 x FETCH_SIZE
 64 B per 128-B request of a 16-B/lane read), write = WRITE_SIZE x 1024."""
 import collections, csv, glob, json, sys
 
-SHAPES = ['proj NT 8192x4096x1024', 'conv NT 8192x512x2560', 'dX NN 8448x1024x2048', 'dW_ih TN 2048x1024x8448 ks4',
+SHAPES = ['proj NT 8192x4096x1024', 'conv NT 8192x512x2560', 'dX NN 8192x1024x4096', 'dW_ih TN 2048x1024x8448 ks4',
           'dW_hh TN 2048x512x8447 ks8']
-FLOPS = [2.0 * 8192 * 4096 * 1024, 2.0 * 8192 * 512 * 2560, 2.0 * 8448 * 1024 * 2048, 2.0 * 2048 * 1024 * 8448, 2.0 * 2048 * 512 * 8447]
+FLOPS = [2.0 * 8192 * 4096 * 1024, 2.0 * 8192 * 512 * 2560, 2.0 * 8192 * 1024 * 4096, 2.0 * 2048 * 1024 * 8448, 2.0 * 2048 * 512 * 8447]
 LAUNCHES = 4
 
 
