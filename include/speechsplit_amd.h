@@ -38,6 +38,9 @@ typedef struct ss_hparams {
 #define SS_STEP_SPLIT_BACKWARD 2 /* ss_g3_train_step: return once the head + decoder gradients (arena offsets >=
                                     ss_grad_split(), 80 % of the bytes, produced first) are complete, so their all-reduce
                                     overlaps the encoder backward that ss_train_finish() then enqueues */
+#define SS_STEP_SPLIT_NO_JOIN 4 /* with SS_STEP_SPLIT_BACKWARD: do not make `stream` wait for the decoder's weight-gradient
+                                    GEMMs (they run on an engine stream beside the encoder backward, as in the one-call
+                                    step); the consumer of the decoder range orders itself with ss_wait_decoder_grads() */
 
 const char* ss_last_error(void);
 int ss_abi_version(void);
@@ -90,6 +93,9 @@ int ss_g6_train_step(ss_engine* e, const float* mel_dev, const float* f0_onehot_
 
 /* second half of a SS_STEP_SPLIT_BACKWARD step: encoder backward (+ Adam unless SS_STEP_NO_ADAM) */
 int ss_train_finish(ss_engine* e, float grad_scale, int flags, void* stream);
+/* After a SS_STEP_SPLIT_BACKWARD | SS_STEP_SPLIT_NO_JOIN step and BEFORE ss_train_finish is enqueued: make `consumer_stream`
+ * (e.g. the stream the all-reduce of the decoder range is launched on) wait until the head + decoder gradients are final. */
+int ss_wait_decoder_grads(ss_engine* e, void* consumer_stream);
 /* first arena offset (floats) of the decoder + head parameters; [0, split) is the encoder */
 long ss_grad_split(const ss_engine* e);
 

@@ -153,6 +153,8 @@ struct ss_engine {
     hipStream_t side3 = nullptr;          // third independent branch of the encoder backward (Encoder_t)
     hipStream_t cap = nullptr;            // graphs are captured and replayed here (a legacy default stream cannot capture)
     hipEvent_t ev_io[2] = {};             // caller stream <-> cap ordering
+    hipEvent_t ev_dec[2] = {};            // split step without join: decoder chain done (caller stream) / its weight gradients done (side)
+    int dec_pending = 0;                  // 0 none, 1 ev_dec[0] only, 2 both
     // captured training steps (hipGraph), keyed by geometry / flags / grad_scale; inputs are staged into engine-owned
     // buffers so a replay does not depend on the caller's tensor addresses
     struct StepGraph {
@@ -1167,6 +1169,8 @@ void ss_destroy(ss_engine* e) {
             (void)hipStreamSynchronize(e->cap);
             for (auto& ev : e->ev_io)
                 if (ev) (void)hipEventDestroy(ev);
+            for (auto& ev : e->ev_dec)
+                if (ev) (void)hipEventDestroy(ev);
             (void)hipStreamDestroy(e->cap);
         }
     }
@@ -1223,6 +1227,7 @@ int ss_bind(ss_engine* e, float* params, float* grads, float* m, float* v, void*
         HIPCHK(hipStreamCreateWithFlags(&e->side3, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&e->cap, hipStreamNonBlocking));
         for (auto& ev : e->ev_io) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        for (auto& ev : e->ev_dec) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
     AdamState st{};
     st.lr = 1e-4;
@@ -1349,7 +1354,16 @@ static int g3_step_body(ss_engine* e, const float* mel, const float* f0, const f
                     C, 1.0f, e->loss_part, loss, s));                                       // solver.py:166
     if (flags & SS_STEP_SPLIT_BACKWARD) {         // data parallel: stop once the decoder + head gradients are complete
         CHK(backward_decoder(e, s));
-        return join_side(e, s);
+        if (!(flags & SS_STEP_SPLIT_NO_JOIN)) return join_side(e, s);
+        // the weight-gradient GEMMs stay on the side stream (joined by backward_encoder, as in the one-call step);
+        // ss_wait_decoder_grads() orders the consumer of the decoder range behind both parts
+        HIPCHK(hipEventRecord(e->ev_dec[0], s));
+        e->dec_pending = 1;
+        if (e->side_used) {
+            HIPCHK(hipEventRecord(e->ev_dec[1], e->side));
+            e->dec_pending = 2;
+        }
+        return 0;
     }
     CHK(backward_core(e, s));                                                               // solver.py:170-171
     if (!(flags & SS_STEP_NO_ADAM)) CHK(ss_adam_step(e, grad_scale, (void*)s));             // solver.py:172
@@ -1409,6 +1423,15 @@ int ss_train_finish(ss_engine* e, float grad_scale, int flags, void* stream) {
     if (!e->have_fwd) return fail("ss_train_finish without a preceding ss_*_train_step(SS_STEP_SPLIT_BACKWARD)");
     CHK(backward_encoder(e, s));
     if (!(flags & SS_STEP_NO_ADAM)) CHK(ss_adam_step(e, grad_scale, stream));
+    return 0;
+}
+
+int ss_wait_decoder_grads(ss_engine* e, void* consumer_stream) {
+    if (!e->dec_pending) return fail("ss_wait_decoder_grads without a preceding SS_STEP_SPLIT_BACKWARD | SS_STEP_SPLIT_NO_JOIN step");
+    hipStream_t c = S(consumer_stream);
+    HIPCHK(hipStreamWaitEvent(c, e->ev_dec[0], 0));
+    if (e->dec_pending == 2) HIPCHK(hipStreamWaitEvent(c, e->ev_dec[1], 0));
+    e->dec_pending = 0;
     return 0;
 }
 

@@ -609,8 +609,9 @@ def test_split_backward_equals_fused(E):
 
 
 def test_dp_step_on_a_one_rank_rccl_group(E):
-    """The data-parallel schedule end to end (split backward, two async RCCL all-reduces, Adam with the mean folded in)
-    on a world of one: must equal the plain fused step."""
+    """The three data-parallel schedules end to end (two async RCCL all-reduces behind the step / overlapped from a
+    communication stream / after a joined split; Adam with the mean folded in) on a world of one: each must equal
+    the plain fused step."""
     import torch.distributed as dist
     if not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -623,17 +624,19 @@ def test_dp_step_on_a_one_rank_rccl_group(E):
         mel, f0, emb, lens = synth_batch(27, B, T, 64)
         d = stack_draws(draws_for(28, B, 4))
         res = []
-        for dp in (False, True):
+        for dp in (None, 'after', 'overlap', 'join'):
             eng = get_engine(E, 'G3', T, 8)
             eng.load_weights(w)
             eng.adam_m.zero_()
             eng.adam_v.zero_()
             eng.set_adam(1e-4, 0.9, 0.999, 1e-8, 0)
-            loss = eng.dp_train_step(mel, f0, emb, lens, d, 1) if dp else eng.g3_train_step(mel, f0, emb, lens, d)
+            for _ in range(2):          # two steps: the second one runs on the first one's update
+                loss = eng.dp_train_step(mel, f0, emb, lens, d, 1, schedule=dp) if dp else eng.g3_train_step(mel, f0, emb, lens, d)
             torch.cuda.synchronize()
             res.append((float(loss), eng.params.clone()))
-        assert res[0][0] == res[1][0]
-        assert rel(res[1][1], res[0][1]) < 1e-6
+        for r in res[1:]:
+            assert r[0] == res[0][0]
+            assert rel(r[1], res[0][1]) < 1e-6
     finally:
         dist.destroy_process_group()
 
