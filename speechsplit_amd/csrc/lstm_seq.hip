@@ -354,9 +354,12 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (st > 0) {                                   // h(-1) = 0: nothing to multiply at the first step
-            if (w == 0) {
+            // two waves watch the flag line half a round trip apart: the arrival is seen a quarter of a round trip earlier on
+            // average (more watchers only delay the members' flag stores: eight per workgroup tripled the step)
+            if (w < 2) {
+                if (w == 1) __builtin_amdgcn_s_sleep(8);
                 const bool ok = (diag & 16) ? true : wait_flags(flags, JT, (unsigned)(st + 1), abortp);
-                if (lane == 0) s_ok = ok ? 1 : 0;
+                if (lane == 0 && (w == 0 || !ok)) s_ok = ok ? 1 : 0;
             }
             __syncthreads();
             if (!s_ok) return;                          // uniform: every thread reads the same LDS word
@@ -570,7 +573,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_seq_bwd_kernel(float* __re
         };
         f32x4 part = {0.f, 0.f, 0.f, 0.f};
         if (st > 0) {
-            if (w == 0) {
+            if (w == 0) {                              // one watcher here: a second one made the backward slower (3.1 -> 3.3 us)
                 const bool ok = (diag & 16) ? true : wait_flags(flags, JT, (unsigned)(st + 1), abortp);
                 if (lane == 0) s_ok = ok ? 1 : 0;
             }
