@@ -1558,7 +1558,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "defer_dw" && (value == 0 || value == 1)) g_defer_dw = value;
     else if (k == "dx_batched" && value >= 0 && value <= 2) g_dx_batched = value;
     else if (k == "conv_want" && value >= 0) g_conv_want = value;
-    else if (k == "small_lds" && (value == 0 || value == 1)) g_small_lds = value;
+    else if (k == "small_lds" && value >= 0 && value <= 2) g_small_lds = value;
     else if (k == "gemm_tr" && value >= 0 && value <= 2) g_gemm_tr = value;
     else if (k == "graph" && (value == 0 || value == 1)) g_graph = value;
     else if (k == "split" && (value == 0 || value == 1)) g_split = value;

@@ -16,7 +16,8 @@
 
 namespace ss {
 
-int g_small_lds = 1;     // 0: always the streaming kernels (A/B experiments)
+int g_small_lds = 1;     // 1: LDS-staged kernels (single-wave variant where it applies), 2: LDS-staged without the single-wave variant,
+                        // 0: always the streaming kernels (A/B experiments)
 
 namespace {
 
@@ -212,6 +213,53 @@ __global__ __launch_bounds__((4 * H > 64 ? 4 * H : 64)) void lstm_small_fwd_lds_
     }
 }
 
+// Single-wave variant for 4H <= 64 (H = 1 .. 16): all gate threads sit in one wave, so a step needs no LDS exchange and no
+// barrier at all -- h(t-1) is read lane by lane with v_readlane (a scalar operand for the H multiply-adds), the four gates of
+// a unit meet in its cell lane through three ds_bpermute, and the next step's pre-activation is already in a register.
+// One dependent LDS-crossbar round trip per step instead of four.  Same arithmetic order as the kernels above.
+template <int H>
+__global__ __launch_bounds__(64) void lstm_small_fwd_wave_kernel(float* __restrict__ gates, const float* __restrict__ whh_f,
+                                                                 const float* __restrict__ whh_b, float* __restrict__ out,
+                                                                 float* __restrict__ csave, int T) {
+    static_assert(4 * H <= 64, "one wave");
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    float* xs = dyn;
+    const int b = blockIdx.x, dir = blockIdx.y, n = threadIdx.x;
+    const int TP = T + 2 * HALO;
+    const float* whh = dir ? whh_b : whh_f;
+    const bool gate_thread = n < 4 * H;
+    float w[H];
+#pragma unroll
+    for (int k = 0; k < H; ++k) w[k] = gate_thread ? whh[n * H + k] : 0.f;
+    float* g0 = gates + (long)b * TP * (8 * H) + dir * 4 * H;
+    auto tau_of = [&](int s) { return HALO + (dir == 0 ? s : T - 1 - s); };
+    stage_rows<64, H, 16>(reinterpret_cast<const float4*>(g0), reinterpret_cast<float4*>(xs), T, n, tau_of);
+    lds_barrier();
+    float* grow = g0 + n;
+    const int nn = gate_thread ? n : 0;                      // idle lanes mirror lane 0 (never stored)
+    float c = 0.f, h = 0.f;
+    float xn = xs[nn];
+    for (int s = 0; s < T; ++s) {
+        const int tau = tau_of(s);
+        float acc = xn;
+        if (s + 1 < T) xn = xs[(s + 1) * 4 * H + nn];         // next step's pre-activation: no dependence on this step
+#pragma unroll
+        for (int k = 0; k < H; ++k) acc += w[k] * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h), k));
+        const float act = (nn / H == 2) ? ss_tanh(acc) : sigmoidf_(acc);
+        if (gate_thread) grow[(long)tau * (8 * H)] = act;
+        // unit u's gates sit in lanes u, u+H, u+2H, u+3H; lanes >= H compute along (their c / h are never used)
+        const int u = n & (H - 1);
+        const float gi = __shfl(act, u), gf = __shfl(act, u + H), gg = __shfl(act, u + 2 * H), go = __shfl(act, u + 3 * H);
+        c = gf * c + gi * gg;
+        h = go * ss_tanh(c);
+        if (n < H) {
+            const long o = ((long)b * TP + tau) * (2 * H) + dir * H + n;
+            out[o] = h;
+            csave[o] = c;
+        }
+    }
+}
+
 // dynamic LDS, all in STEP order of the backward walk: ga[T][4H] activated gates, dd[T][H] d_out, cc[T + 1][H] cell states
 // (cc[s + 1] is step s's previous cell state in forward time; the last one is a halo row = 0)
 template <int H>
@@ -310,6 +358,14 @@ template <int H>
 hipError_t fwd_t(float* gates, const float* wf, const float* wb, float* out, float* csave, int B, int T, hipStream_t s) {
     constexpr int NT = 4 * H > 64 ? 4 * H : 64;
     const long bytes = (long)T * 4 * H * 4;
+    if constexpr (4 * H <= 64) {
+        if (g_small_lds == 1 && bytes <= LDS_BUDGET) {
+            hipError_t e = allow_lds(lstm_small_fwd_wave_kernel<H>, bytes);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((lstm_small_fwd_wave_kernel<H>), dim3(B, 2), dim3(64), bytes, s, gates, wf, wb, out, csave, T);
+            return hipGetLastError();
+        }
+    }
     if (g_small_lds && bytes <= LDS_BUDGET) {
         hipError_t e = allow_lds(lstm_small_fwd_lds_kernel<H>, bytes);
         if (e != hipSuccess) return e;
