@@ -751,9 +751,9 @@ int lstm_input_grad(ss_engine* e, LstmBlk& lb, int l, Slab dxi, long r0, long nr
         g.ksplit = tiles < 256 ? 4 : 2;
         g.flags |= GEMM_ACCUM;
         HIPCHK(hipMemsetAsync(g.C, 0, nr * dxi.ld * 4, st));
-    } else if (g_dx_batched && nr % TPr == 0 && r0 % TPr == 0 && T % 128 == 0) {
+    } else if (g_dx_batched && nr % TPr == 0 && r0 % TPr == 0 && T % 64 == 0) {
         // whole utterances: leave the halo rows out (nobody reads them in a gradient slab) -- one batch entry per
-        // utterance, T rows each, which also makes the 128 x 128 tiling come out at exactly 2 workgroups per CU for B = 64
+        // utterance, T rows each (T a multiple of 64), which at T = 128 also makes the 128 x 128 tiling come out at exactly 2 workgroups per CU for B = 64
         g.A = {lb.gates[l] + (r0 + HALO) * 8L * H, 8L * H, TPr * 8L * H, 0, 0};
         g.C = dxi.p + (r0 + HALO) * dxi.ld;
         g.cstride = TPr * dxi.ld;
