@@ -690,9 +690,31 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_seq_bwd_kernel(float* __re
 
 }  // namespace
 
+// The persistent kernels spin on each other: every workgroup of a launch must be resident at once.  How many the current
+// device holds is asked of the runtime (CU count x resident workgroups per CU for the larger of the two kernels), once per
+// device; a device that cannot hold the grid (a partitioned GPU, a smaller part) takes the one-launch-per-step kernels.
+static long resident_limit(int H) {
+    static long cache[16][2] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+    long& c = cache[dev][H == 512 ? 0 : 1];
+    if (c == 0) {
+        hipDeviceProp_t prop;
+        int per_cu = 0;
+        hipError_t e = hipGetDeviceProperties(&prop, dev);
+        if (e == hipSuccess)
+            e = H == 512 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<512, 8>, 576, 0)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<256, 8>, 576, 0);
+        c = e == hipSuccess ? (long)prop.multiProcessorCount * per_cu : -1;
+        if (c == 0) c = -1;
+    }
+    return c > 0 ? c : 0;
+}
+
 bool lstm_seq_supported(int B, int H) {
     const int nbt = (B + 15) / 16;
-    return (H == 512 || H == 256) && 2 * nbt * (H / 16) <= 256 && 2 * nbt <= 60;     // abort word, masks and 32 flags per group fit LSTM_SEQ_SYNC_WORDS
+    if (!((H == 512 || H == 256) && 2 * nbt * (H / 16) <= 256 && 2 * nbt <= 60)) return false;     // abort word, masks and 32 flags per group fit LSTM_SEQ_SYNC_WORDS
+    return 2L * nbt * (H / 16) <= resident_limit(H);
 }
 
 long lstm_seq_xbytes(int B, int H, bool backward) {
