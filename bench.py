@@ -123,7 +123,7 @@ def main():
         if world == 1:
             eng.g3_train_step(mel, f0, emb, lens, (sc, ls))
         else:
-            # RCCL sum over xGMI in two buckets behind the unchanged one-GPU step (see Engine.dp_train_step for the overlapped variants);
+            # RCCL sum of the gradient arena over xGMI behind the unchanged one-GPU step (see Engine.dp_train_step for the overlapped variants);
             # the mean is taken inside the Adam kernel
             eng.dp_train_step(mel, f0, emb, lens, (sc, ls), world)
 

@@ -147,15 +147,16 @@ class Engine:
         return int(self.lib.ss_grad_split(self.h))
 
     def dp_train_step(self, mel, f0, emb, len_org, draws, world, group=None, schedule='after'):
-        """One data-parallel step on this rank's shard: backward, RCCL sum of the gradient arena in two buckets (decoder +
-        head, 80 % of the bytes, then the encoder), the same Adam update on every rank with the 1/world mean folded in.
+        """One data-parallel step on this rank's shard: backward, RCCL sum of the gradient arena, the same Adam update on
+        every rank with the 1/world mean folded in.
 
-        schedule='after' (default): the one-GPU step unchanged, both all-reduces behind it.  Nothing of the collectives is
-            hidden, nothing of the step is disturbed (world 1: +0.03 ms).
-        schedule='overlap': split backward without joining the engine streams (SS_STEP_SPLIT_NO_JOIN); the first bucket
-            is reduced from a communication stream that waits only for the decoder range, while the encoder backward
-            runs.  The wait is issued before the encoder backward is enqueued (a cross-stream wait on ROCm covers what the
-            other stream holds at that moment), the collective after it.
+        schedule='after' (default): the one-GPU step unchanged, one all-reduce of the whole arena (78 MB) behind it.
+            Nothing of the collective is hidden, nothing of the step is disturbed (world 1: +0.05 ms).
+        schedule='overlap': two buckets (decoder + head = 80 % of the bytes, final first; then the encoder).  Split
+            backward without joining the engine streams (SS_STEP_SPLIT_NO_JOIN); the first bucket is reduced from a
+            communication stream that waits only for the decoder range, while the encoder backward runs.  The wait is
+            issued before the encoder backward is enqueued (a cross-stream wait on ROCm covers what the other stream
+            holds at that moment), the collective after it.
         schedule='join': SS_STEP_SPLIT_BACKWARD joins the engine streams, first bucket reduced right away.
         On one MI355X the last two cost +0.4 / +0.6 ms per step before any byte is sent: HIP streams share 4 hardware
         queues, and a collective waiting for its bucket at the head of a queue holds back the compute stream that shares
@@ -163,9 +164,11 @@ class Engine:
         backward).  They pay off only when the reduction of the first bucket takes longer than that."""
         import torch.distributed as dist
         k = self.grad_split
-        if schedule == 'after':
+        if schedule == 'after':                    # nothing to overlap with: one collective over the whole arena
             self.g3_train_step(mel, f0, emb, len_org, draws, no_adam=True)
-            h1 = dist.all_reduce(self.grads[k:], op=dist.ReduceOp.SUM, group=group, async_op=True)
+            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=group, async_op=True).wait()
+            self.adam_step(1.0 / world)
+            return self.loss
         elif schedule == 'join':
             self.g3_train_step(mel, f0, emb, len_org, draws, no_adam=True, split_backward=True)
             h1 = dist.all_reduce(self.grads[k:], op=dist.ReduceOp.SUM, group=group, async_op=True)
