@@ -123,7 +123,8 @@ def main():
         if world == 1:
             eng.g3_train_step(mel, f0, emb, lens, (sc, ls))
         else:
-            # RCCL sum of the gradient arena over xGMI behind the unchanged one-GPU step (see Engine.dp_train_step for the overlapped variants);
+            # RCCL sum of the gradient arena over xGMI: decoder + head bucket from the engine's side stream beside the encoder backward,
+            # then the encoder bucket (Engine.dp_train_step, schedule 'overlap');
             # the mean is taken inside the Adam kernel
             eng.dp_train_step(mel, f0, emb, lens, (sc, ls), world)
 

@@ -96,6 +96,9 @@ int ss_train_finish(ss_engine* e, float grad_scale, int flags, void* stream);
 /* After a SS_STEP_SPLIT_BACKWARD | SS_STEP_SPLIT_NO_JOIN step and BEFORE ss_train_finish is enqueued: make `consumer_stream`
  * (e.g. the stream the all-reduce of the decoder range is launched on) wait until the head + decoder gradients are final. */
 int ss_wait_decoder_grads(ss_engine* e, void* consumer_stream);
+/* the engine stream that carries the decoder's weight-gradient GEMMs (a hipStream_t; NULL if the engine runs without
+ * branch streams).  A collective launched from it is ordered behind those GEMMs by construction. */
+void* ss_side_stream(ss_engine* e);
 /* first arena offset (floats) of the decoder + head parameters; [0, split) is the encoder */
 long ss_grad_split(const ss_engine* e);
 

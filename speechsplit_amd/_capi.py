@@ -42,6 +42,7 @@ SYMBOLS = {
     'ss_g6_train_step': (_i, [_vp, _fp, _fp, _ip, _fp, _ip, _i, _i, _f, _i, _fp, _vp]),
     'ss_train_finish': (_i, [_vp, _f, _i, _vp]),
     'ss_wait_decoder_grads': (_i, [_vp, _vp]),
+    'ss_side_stream': (_vp, [_vp]),
     'ss_grad_split': (_l, [_vp]),
     'ss_set_adam': (_i, [_vp, _d, _d, _d, _d, _l, _vp]),
     'ss_adam_step': (_i, [_vp, _f, _vp]),

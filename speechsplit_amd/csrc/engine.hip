@@ -1435,6 +1435,8 @@ int ss_wait_decoder_grads(ss_engine* e, void* consumer_stream) {
     return 0;
 }
 
+void* ss_side_stream(ss_engine* e) { return (void*)e->side; }
+
 long ss_grad_split(const ss_engine* e) {
     for (const auto& p : e->params)
         if (p.name.rfind("decoder.", 0) == 0) return p.offset;

@@ -146,25 +146,28 @@ class Engine:
     def grad_split(self):
         return int(self.lib.ss_grad_split(self.h))
 
-    def dp_train_step(self, mel, f0, emb, len_org, draws, world, group=None, schedule='after'):
+    def dp_train_step(self, mel, f0, emb, len_org, draws, world, group=None, schedule='overlap'):
         """One data-parallel step on this rank's shard: backward, RCCL sum of the gradient arena, the same Adam update on
         every rank with the 1/world mean folded in.
 
-        schedule='after' (default): the one-GPU step unchanged, one all-reduce of the whole arena (78 MB) behind it.
-            Nothing of the collective is hidden, nothing of the step is disturbed (world 1: +0.05 ms).
-        schedule='overlap': two buckets (decoder + head = 80 % of the bytes, final first; then the encoder).  Split
-            backward without joining the engine streams (SS_STEP_SPLIT_NO_JOIN); the first bucket is reduced from a
-            communication stream that waits only for the decoder range, while the encoder backward runs.  The wait is
-            issued before the encoder backward is enqueued (a cross-stream wait on ROCm covers what the other stream
-            holds at that moment), the collective after it.
-        schedule='join': SS_STEP_SPLIT_BACKWARD joins the engine streams, first bucket reduced right away.
-        On one MI355X the last two cost +0.4 / +0.6 ms per step before any byte is sent: HIP streams share 4 hardware
-        queues, and a collective waiting for its bucket at the head of a queue holds back the compute stream that shares
-        it ('join' additionally makes the decoder's weight-gradient GEMMs run alone instead of beside the encoder
-        backward).  They pay off only when the reduction of the first bucket takes longer than that."""
+        schedule='overlap' (default): two buckets -- decoder + head (80 % of the bytes, final first), then the encoder.
+            The backward is enqueued exactly as in the one-GPU step (SS_STEP_SPLIT_NO_JOIN: the decoder's weight-gradient
+            GEMMs run on an engine stream beside the encoder backward); the first bucket is reduced FROM THAT ENGINE
+            STREAM, i.e. behind those GEMMs by construction, and runs while the rest of the encoder backward executes.
+            World 1: +0.02 ms over the fused step.
+        schedule='after': the one-GPU step unchanged, one all-reduce of the whole arena (78 MB) behind it; nothing hidden.
+        schedule='join': SS_STEP_SPLIT_BACKWARD joins the engine streams, first bucket reduced right away (+0.6 ms: the
+            decoder's weight-gradient GEMMs then run alone instead of beside the encoder backward).
+        Why the engine's own stream: HIP streams share 4 hardware queues.  A collective launched from a separate
+        communication stream waits for its bucket at the head of whatever queue that stream was mapped to and holds the
+        compute stream sharing it back -- measured +0.4 .. +0.6 ms per step on one MI355X for 3 of 4 queue positions
+        (tools/rccl_queue_effect.py); on the stream it has to follow anyway it costs nothing."""
         import torch.distributed as dist
         k = self.grad_split
-        if schedule == 'after':                    # nothing to overlap with: one collective over the whole arena
+        side = self.lib.ss_side_stream(self.h) if schedule == 'overlap' else None
+        if schedule == 'overlap' and not side:
+            schedule = 'after'                         # engine without branch streams
+        if schedule == 'after':                        # nothing to overlap with: one collective over the whole arena
             self.g3_train_step(mel, f0, emb, len_org, draws, no_adam=True)
             dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=group, async_op=True).wait()
             self.adam_step(1.0 / world)
@@ -180,9 +183,12 @@ class Engine:
             # SS_STEP_NO_ADAM | SS_STEP_SPLIT_BACKWARD | SS_STEP_SPLIT_NO_JOIN
             _capi.check(self.lib.ss_g3_train_step(self.h, _ptr(mel), _ptr(f0), _ptr(emb), _ptr(len_org), _ptr(sc), _ptr(ls),
                                                   B, T, 1.0, 1 | 2 | 4, _ptr(self.loss), _stream()))
-            if getattr(self, '_comm_stream', None) is None:
-                self._comm_stream = torch.cuda.Stream(self.device)
-            cs = self._comm_stream
+            if getattr(self, '_side_stream', None) is None:
+                self._side_stream = torch.cuda.ExternalStream(side, device=self.device)
+            cs = self._side_stream
+            # the engine stream already follows the decoder chain and carries its weight gradients; this also orders it
+            # behind the chain's last kernel explicitly (and must precede the encoder backward: a cross-stream wait on ROCm
+            # covers what the other stream holds when it is issued)
             _capi.check(self.lib.ss_wait_decoder_grads(self.h, C.c_void_p(cs.cuda_stream)))
             self.train_finish(no_adam=True)
             with torch.cuda.stream(cs):

@@ -624,7 +624,7 @@ def test_dp_step_on_a_one_rank_rccl_group(E):
         mel, f0, emb, lens = synth_batch(27, B, T, 64)
         d = stack_draws(draws_for(28, B, 4))
         res = []
-        for dp in (None, 'after', 'overlap', 'join'):
+        for dp in (None, 'overlap', 'after', 'join'):
             eng = get_engine(E, 'G3', T, 8)
             eng.load_weights(w)
             eng.adam_m.zero_()
