@@ -93,11 +93,6 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit('bench.py: for --gpus N > 1 launch with torch.distributed.run --nproc-per-node N')
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(f'cuda:{local}'))
     torch.cuda.set_device(local)
     dev = torch.device(f'cuda:{local}')
 
@@ -110,6 +105,14 @@ def main():
     hp = W.default_hparams(max_len_pad=T)
     eng = Engine('G3', hp, B, T, device=dev)
     eng.load_weights(W.make_weights('G3', hp, 0))
+    # The communicator comes AFTER the engine: HIP spreads a process's streams over 4 hardware queues in creation order, and
+    # the engine's four streams should get one each (with RCCL's streams created first the same step measured 0.3 - 0.7 ms
+    # slower on one GPU: tools/stream_order_effect.py, tools/soak_dp.py).
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     eng.set_adam(1e-4, 0.9, 0.999, 1e-8, 0)
     eng.set_precision(args.precision)
     mel, f0, emb, lens = synth(B, T, 1000 + rank, dev)

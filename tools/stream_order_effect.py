@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""How the fused step's time depends on how many HIP streams the process created BEFORE the engine (HIP maps streams
+round-robin onto 4 hardware queues, so the engine's branch streams end up sharing queues differently)."""
+import os, sys, time, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import weights as W
+from oracle.gen_fixtures import synth_batch
+from speechsplit_amd import engine as E
+B, T = 64, 128
+hp = W.default_hparams(max_len_pad=T)
+mel, f0, emb, lens = [t.cuda() for t in synth_batch(1, B, T, 64)]
+sc, ls = E.draw_interp(B, 4, hp)
+sc, ls = sc.cuda(), ls.cuda()
+w = W.make_weights('G3', hp, 0)
+import ctypes
+hip = ctypes.CDLL('libamdhip64.so')
+keep = []
+for n_before in range(0, 6):
+    if n_before:                                   # one more lone stream in the process before this engine's four
+        st = ctypes.c_void_p()
+        assert hip.hipStreamCreateWithFlags(ctypes.byref(st), 1) == 0
+        keep.append(st)
+    eng = E.Engine('G3', hp, B, T)
+    eng.load_weights(w)
+    for _ in range(5):
+        eng.g3_train_step(mel, f0, emb, lens, (sc, ls))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(30):
+        eng.g3_train_step(mel, f0, emb, lens, (sc, ls))
+    torch.cuda.synchronize()
+    print(f'{n_before} lone stream(s) created before the engine: {(time.perf_counter() - t0) / 30 * 1e3:.3f} ms/step', flush=True)
+    del eng
