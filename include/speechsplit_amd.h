@@ -143,6 +143,18 @@ int ss_op_lstm_fwd(float* gates_dev, const float* whh_f_dev, const float* whh_b_
 /* BPTT of the same: d_out [B,T+4,2H]; gates is replaced by the pre-activation gradients. */
 int ss_op_lstm_bwd(float* gates_dev, const float* whh_f_dev, const float* whh_b_dev, const float* d_out_dev,
                    const float* csave_dev, float* scratch_dev, long scratch_floats, int B, int T, int H, void* stream);
+/* One relu(GroupNorm(ConvNorm(x))) block (model.py:61-67,76-77; 16 channels per group) through the engine's own block
+ * routines, forward and -- when dy is given -- backward.  x [B,T,Ci], w [Co,Ci,5], bias/gamma/beta [Co], y/dy [B,T,Co],
+ * dx [B,T,Ci] (nullable), gw [Co,Ci,5], gb/ggamma/gbeta [Co]; scratch of ss_op_conv_block_scratch() floats. */
+long ss_op_conv_block_scratch(int B, int T, int Ci, int Co);
+int ss_op_conv_block(const float* x_dev, const float* w_dev, const float* bias_dev, const float* gamma_dev, const float* beta_dev,
+                     const float* dy_dev, float* y_dev, float* dx_dev, float* gw_dev, float* gb_dev, float* ggamma_dev,
+                     float* gbeta_dev, float* scratch_dev, long scratch_floats, int B, int T, int Ci, int Co, void* stream);
+/* The ReLU branch the engine took in conv block `block` ("enc1.c1_0" .. "enc1.c2_2", "enc3.c_0" .. "enc3.c_2", "enc2.c") of
+ * the last forward: mask [B,T,Co] dense, 1.0f where the GroupNorm output is > 0.  A GroupNorm output within fp32 rounding
+ * of 0 may fall on either side in two correct implementations; parity tests hand this mask to the oracle so that the
+ * comparison of gradients does not depend on that coin flip. */
+int ss_debug_relu_mask(ss_engine* e, const char* block, float* mask_dev, void* stream);
 /* tuning knobs (process-global): "lstm_nw" 4|8|16, "lstm_g" 0..16, "gemm_bk" 16|32, "gemm_want" >= 1,
  * "overlap" 0|1, "graph" 0|1, "persist" 0|1, "split" 0|1, "gemm_mode" 0 (fp32 MFMA) | 1 (split arithmetic on the 16-bit pipe),
  * "fwd_f16x2" / "bwd_f16x2" 0|1 (fp16 x 2 instead of bf16 x 3 for the forward / the scaled gradient contractions);

@@ -18,6 +18,13 @@ import torch.nn.functional as F
 from . import interp_np
 
 TAP = None      # set to a dict to record intermediates (name -> [B,T,C] tensor) for kernel-level debugging
+# ReLU branch override for gradient parity tests.  A GroupNorm output within fp32 rounding of 0 lands on either side of the
+# kink in two correct fp32 implementations, and the side decides a whole channel's gradient.  MASK = {block: bool [B,T,C]}
+# (the implementation under test reports the branch it took) makes this restatement take the same branch; MASK_STATS then
+# records, per block, how many elements disagreed with this restatement's own sign and the largest |z| among them, so a
+# test can assert that the override only ever acted AT the kink (|z| ~ 1e-6), never on a clearly signed value.
+MASK = None
+MASK_STATS = None
 
 
 def _tap(name, t, nct=False):
@@ -35,6 +42,13 @@ def conv_gn_relu(x_nct, P, prefix, chs_grp=16, tap=None):
     y = F.group_norm(y, w.shape[0] // chs_grp, P[prefix + '.1.weight'], P[prefix + '.1.bias'], eps=1e-5)
     if tap and TAP is not None:
         TAP['zmin:' + tap] = float(y.detach().abs().min())     # distance of the closest pre-activation to the ReLU kink
+    blk = tap[:-5] if tap and tap.endswith('.conv') else tap
+    if MASK is not None and blk in MASK:
+        m = MASK[blk].transpose(1, 2)                          # [B,T,C] -> NCT
+        if MASK_STATS is not None:
+            dis = m != (y.detach() > 0)
+            MASK_STATS[blk] = (int(dis.sum()), float(y.detach().abs()[dis].max()) if bool(dis.any()) else 0.0)
+        return y * m.to(y.dtype)
     return F.relu(y)
 
 
@@ -216,4 +230,12 @@ class TrainState:
         self.opt.zero_grad()                                                 # solver.py:170
         loss.backward()                                                      # :171
         self.opt.step()                                                      # :172
+        return loss.detach(), out.detach()
+
+    def step_g6(self, hp, mel, f0_onehot, target_idx, draws):
+        """The same three statements around g6_loss (this repo's choice of loss, see g6_loss)."""
+        loss, out = g6_loss(self.P, hp, mel, f0_onehot, target_idx, draws)
+        self.opt.zero_grad()
+        loss.backward()
+        self.opt.step()
         return loss.detach(), out.detach()

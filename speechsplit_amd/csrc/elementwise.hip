@@ -176,6 +176,24 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
     }
 }
 
+// Test hook: the ReLU branch the engine took for every element, recomputed from the saved conv output and statistics with the
+// expression gn_relu_bwd_kernel uses (which is also the forward kernel's).  mask [B, T, C] dense, 1.0f where z > 0.
+__global__ __launch_bounds__(256) void gn_relu_mask_kernel(const float* __restrict__ x, long x_ld, long x_bs,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ stats, float* __restrict__ mask, int T, int C) {
+    const int b = blockIdx.y;
+    const long n = (long)T * C;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int t = (int)(i / C), c = (int)(i - (long)t * C);
+        const int g = c >> 4;
+        const float mean = stats[((long)b * (C >> 4) + g) * 2 + 0];
+        const float rstd = stats[((long)b * (C >> 4) + g) * 2 + 1];
+        const float h = (x[b * x_bs + (long)(t + HALO) * x_ld + c] - mean) * rstd;
+        const float z = h * gamma[c] + beta[c];
+        mask[(long)b * n + i] = z > 0.f ? 1.f : 0.f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ column sums
 // grid = (ceil(C/64), chunks); block 256 = 64 columns x 4 row lanes
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, long ld, int R, int C, int rows_per_chunk,
@@ -469,6 +487,14 @@ hipError_t gn_relu_bwd(const float* x, long x_ld, long x_bs, float* dy, long dy_
     if (C % 64 != 0 || T > 16 * GN_MAXIT) return hipErrorInvalidValue;
     hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(C / 64, B), dim3(256), 0, s, x, x_ld, x_bs, dy, dy_ld, dy_bs, gamma, beta,
                        stats, g_gamma, g_beta, g_bias, reinterpret_cast<unsigned*>(amax), B, T, C);
+    return hipGetLastError();
+}
+
+hipError_t gn_relu_mask(const float* x, long x_ld, long x_bs, const float* gamma, const float* beta, const float* stats,
+                        float* mask, int B, int T, int C, hipStream_t s) {
+    int gx = cdiv((long)T * C, 256 * 4);
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(gn_relu_mask_kernel, dim3(gx, B), dim3(256), 0, s, x, x_ld, x_bs, gamma, beta, stats, mask, T, C);
     return hipGetLastError();
 }
 

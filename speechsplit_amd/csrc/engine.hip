@@ -1647,6 +1647,92 @@ int ss_debug_buffer(ss_engine* e, const char* name, float** ptr, long* rows, lon
     return 0;
 }
 
+int ss_debug_relu_mask(ss_engine* e, const char* block, float* mask, void* stream) {
+    if (!e || !block || !mask) return fail("ss_debug_relu_mask: null argument");
+    if (!e->curB) return fail("ss_debug_relu_mask: no forward has run");
+    auto it = e->dbg.find(std::string(block) + ".conv");
+    if (it == e->dbg.end()) return fail(std::string("ss_debug_relu_mask: no such conv block: ") + block);
+    ConvBlk* all[7] = {&e->c1[0], &e->c1[1], &e->c1[2], &e->c2[0], &e->c2[1], &e->c2[2], &e->ct};
+    for (ConvBlk* cb : all)
+        if (cb->Co && cb->cout == it->second.first) {
+            const long TP = e->curT + 2 * HALO;
+            HIPCHK(gn_relu_mask(cb->cout, cb->Co, TP * cb->Co, e->P + cb->ga, e->P + cb->be, cb->stats, mask, e->curB, e->curT,
+                                cb->Co, S(stream)));
+            return 0;
+        }
+    return fail("ss_debug_relu_mask: block has no storage");
+}
+
+long ss_op_conv_block_scratch(int B, int T, int Ci, int Co) {
+    const long Cp = align4(Ci), R = (long)B * (T + 2 * HALO);
+    const long np = align4((long)Co * Ci * 5) + 3L * Co;
+    return 2 * np + 2L * Co * 5 * Cp + (long)Ci * 5 * Co + R * (2 * Cp + 3L * Co) + 2L * B * (Co / 16) + 64;
+}
+
+int ss_op_conv_block(const float* x, const float* w, const float* bias, const float* gamma, const float* beta, const float* dy,
+                     float* y, float* dx, float* gw, float* gb, float* ggamma, float* gbeta, float* scratch, long scratch_floats,
+                     int B, int T, int Ci, int Co, void* stream) {
+    hipStream_t s = S(stream);
+    if (!x || !w || !bias || !gamma || !beta || !y || !scratch) return fail("ss_op_conv_block: null pointer");
+    if (Co % 64 || T < 1 || T > 256 || B < 1) return fail("ss_op_conv_block: needs Co % 64 == 0 and 1 <= T <= 256");
+    if (scratch_floats < ss_op_conv_block_scratch(B, T, Ci, Co)) return fail("ss_op_conv_block: scratch too small");
+    // a stack engine that holds nothing but this block: the product's own conv_block_fwd / conv_block_bwd do the work
+    ss_engine e{};
+    e.kind = SS_GENERATOR_3;
+    e.curB = B;
+    e.curT = T;
+    const long TP = T + 2 * HALO, R = (long)B * TP;
+    ConvBlk cb;
+    cb.Ci = Ci;
+    cb.Co = Co;
+    cb.Cp = (int)align4(Ci);
+    cb.w = 0;
+    cb.b = align4((long)Co * Ci * 5);
+    cb.ga = cb.b + Co;
+    cb.be = cb.ga + Co;
+    cb.need_dx = dx != nullptr;
+    const long np = cb.be + Co;
+    HIPCHK(hipMemsetAsync(scratch, 0, ss_op_conv_block_scratch(B, T, Ci, Co) * 4, s));
+    float* p = scratch;
+    auto take = [&](long n) {
+        float* q = p;
+        p += align4(n);
+        return q;
+    };
+    e.P = take(np);
+    e.G = take(np);
+    cb.wf = take((long)Co * 5 * cb.Cp);
+    cb.wb = take((long)Ci * 5 * Co);
+    cb.gp = take((long)Co * 5 * cb.Cp);
+    float* xs = take(R * cb.Cp);
+    float* dxs = take(R * cb.Cp);
+    cb.cout = take(R * Co);
+    float* ys = take(R * Co);
+    float* dys = take(R * Co);
+    cb.stats = take(2L * B * (Co / 16));
+    e.amax = take(16);
+    cb.amax_i = 0;
+    HIPCHK(hipMemcpyAsync(e.P + cb.w, w, (long)Co * Ci * 5 * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(e.P + cb.b, bias, Co * 4L, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(e.P + cb.ga, gamma, Co * 4L, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(e.P + cb.be, beta, Co * 4L, hipMemcpyDeviceToDevice, s));
+    HIPCHK(copy_rows(x, Ci, (long)T * Ci, xs + HALO * cb.Cp, cb.Cp, TP * cb.Cp, B, T, Ci, s));
+    CHK(conv_pack_all(&e, cb, s));
+    CHK(conv_block_fwd(&e, cb, Slab{xs, cb.Cp}, Slab{ys, Co}, s));
+    HIPCHK(copy_rows(ys + HALO * Co, Co, TP * Co, y, Co, (long)T * Co, B, T, Co, s));
+    if (dy) {
+        if (!gw || !gb || !ggamma || !gbeta) return fail("ss_op_conv_block: backward needs the gradient outputs");
+        HIPCHK(copy_rows(dy, Co, (long)T * Co, dys + HALO * Co, Co, TP * Co, B, T, Co, s));
+        CHK(conv_block_bwd(&e, cb, Slab{dys, Co}, Slab{xs, cb.Cp}, dx ? Slab{dxs, cb.Cp} : Slab{nullptr, 0}, s));
+        HIPCHK(hipMemcpyAsync(gw, e.G + cb.w, (long)Co * Ci * 5 * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(gb, e.G + cb.b, Co * 4L, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(ggamma, e.G + cb.ga, Co * 4L, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(gbeta, e.G + cb.be, Co * 4L, hipMemcpyDeviceToDevice, s));
+        if (dx) HIPCHK(copy_rows(dxs + HALO * cb.Cp, cb.Cp, TP * cb.Cp, dx, Ci, (long)T * Ci, B, T, Ci, s));
+    }
+    return 0;
+}
+
 int ss_debug_names(ss_engine* e, char* buf, int cap) {
     std::string all;
     for (auto& kv : e->dbg) all += kv.first + "\n";

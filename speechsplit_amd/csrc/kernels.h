@@ -42,6 +42,9 @@ hipError_t gn_relu_fwd(const float* x, long x_ld, long x_bs, float* y, long y_ld
 hipError_t gn_relu_bwd(const float* x, long x_ld, long x_bs, float* dy, long dy_ld, long dy_bs, const float* gamma,
                        const float* beta, const float* stats, float* g_gamma, float* g_beta, float* g_bias, float* amax, int B,
                        int T, int C, hipStream_t s);
+// test hook: mask [B, T, C] dense = 1.0f where the block's GroupNorm output is > 0 (the ReLU branch the kernels above take)
+hipError_t gn_relu_mask(const float* x, long x_ld, long x_bs, const float* gamma, const float* beta, const float* stats,
+                        float* mask, int B, int T, int C, hipStream_t s);
 // out[c] += sum_r in[r*ld + c]   (atomic accumulate)
 hipError_t colsum_acc(const float* in, long ld, int R, int C, float* out, hipStream_t s);
 hipError_t copy_rows(const float* src, long s_ld, long s_bs, float* dst, long d_ld, long d_bs, int B, int T, int C,

@@ -259,6 +259,20 @@ class Engine:
         self.lib.ss_debug_names(self.h, buf, len(buf))
         return [s for s in buf.value.decode().split('\n') if s]
 
+    def relu_masks(self, B, T):
+        """Test hook (ss_debug_relu_mask): {conv block name: bool [B,T,Co]} -- the ReLU branch taken in the last forward."""
+        out = {}
+        for name in self.debug_names():
+            if not name.endswith('.conv'):
+                continue
+            blk = name[:-5]
+            p, rows, cols = C.c_void_p(), C.c_long(), C.c_long()
+            _capi.check(self.lib.ss_debug_buffer(self.h, name.encode(), C.byref(p), C.byref(rows), C.byref(cols)))
+            m = torch.empty(B, T, cols.value, device=self.device)
+            _capi.check(self.lib.ss_debug_relu_mask(self.h, blk.encode(), _ptr(m), _stream()))
+            out[blk] = m > 0
+        return out
+
     def set_precision(self, precision):
         """'f32' (default, the 1e-4 parity mode) or 'bf16' (bf16-rounded GEMM operands, fp32 accumulate / state)."""
         code = {'f32': 0, 'fp32': 0, 'bf16': 1}[precision]
@@ -280,6 +294,88 @@ class Engine:
         n = rows.value * cols.value
         flat = self.ws[off:off + 4 * n].view(torch.float32)
         return flat.view(B, T + 4, cols.value)[:, 2:2 + T].clone()
+
+
+def conv_block(x, w, bias, gamma, beta, dy=None, need_dx=True):
+    """Test hook (ss_op_conv_block): relu(GroupNorm(conv5(x))) of one block through the engine's block routines.
+    x [B,T,Ci] -> y [B,T,Co]; with dy also (dx, gw, gb, ggamma, gbeta)."""
+    lib = _capi.lib()
+    B, T, Ci = x.shape
+    Co = w.shape[0]
+    dev = x.device
+    f = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
+    x, w, bias, gamma, beta = f(x), f(w), f(bias), f(gamma), f(beta)
+    n = lib.ss_op_conv_block_scratch(B, T, Ci, Co)
+    scratch = torch.empty(n, device=dev)
+    y = torch.empty(B, T, Co, device=dev)
+    if dy is None:
+        _capi.check(lib.ss_op_conv_block(_ptr(x), _ptr(w), _ptr(bias), _ptr(gamma), _ptr(beta), None, _ptr(y), None, None, None,
+                                         None, None, _ptr(scratch), n, B, T, Ci, Co, _stream()))
+        return y
+    dy = f(dy)
+    dx = torch.empty(B, T, Ci, device=dev) if need_dx else None
+    gw, gb, gg, gbe = torch.empty_like(w), torch.empty_like(bias), torch.empty_like(gamma), torch.empty_like(beta)
+    _capi.check(lib.ss_op_conv_block(_ptr(x), _ptr(w), _ptr(bias), _ptr(gamma), _ptr(beta), _ptr(dy), _ptr(y), _ptr(dx), _ptr(gw),
+                                     _ptr(gb), _ptr(gg), _ptr(gbe), _ptr(scratch), n, B, T, Ci, Co, _stream()))
+    return y, dx, gw, gb, gg, gbe
+
+
+def _slab(x):
+    """[B,T,C] -> haloed slab [B,T+4,C] (kernels.h: frame t at row t+2, zero halo rows)."""
+    B, T, Cc = x.shape
+    s = torch.zeros(B, T + 4, Cc, device=x.device)
+    s[:, 2:2 + T] = x
+    return s
+
+
+def blstm_layer(x, w_ih, w_hh, b_ih, b_hh, d_out=None):
+    """Test hook: one bidirectional LSTM layer through ss_op_lstm_fwd / ss_op_lstm_bwd (the engine's recurrence kernels) with
+    the input projection and the weight / input gradients on the engine's GEMM (ss_op_gemm).  w_ih etc. are (forward, reverse)
+    pairs with PyTorch's shapes.  Returns out [B,T,2H]; with d_out also (dx, [(gw_ih, gw_hh, gb) per direction])."""
+    lib = _capi.lib()
+    B, T, In = x.shape
+    H = w_hh[0].shape[1]
+    dev = x.device
+    wcat = torch.cat([w_ih[0], w_ih[1]], 0).contiguous()                    # [8H, In]
+    bsum = torch.cat([b_ih[0] + b_hh[0], b_ih[1] + b_hh[1]]).contiguous()
+    xs = _slab(x)
+    R = B * (T + 4)
+    gates = torch.zeros(R, 8 * H, device=dev)
+    g_real = gemm(xs.view(R, In), wcat, bsum)                               # all rows, halo rows are then re-zeroed
+    gates.copy_(g_real)
+    gates.view(B, T + 4, 8 * H)[:, :2] = 0
+    gates.view(B, T + 4, 8 * H)[:, T + 2:] = 0
+    out = torch.zeros(B, T + 4, 2 * H, device=dev)
+    csave = torch.zeros(B, T + 4, 2 * H, device=dev)
+    B16 = (B + 15) // 16 * 16
+    nscr = 8 * H * H + 16 * B16 * H + 2 * B * H + (4 * ((B + 15) // 16) * (H // 16) ** 2 * 1024 + 8192) // 4 + 4096
+    scratch = torch.zeros(max(nscr, 1), device=dev)
+    whf, whb = w_hh[0].contiguous(), w_hh[1].contiguous()
+    _capi.check(lib.ss_op_lstm_fwd(_ptr(gates), _ptr(whf), _ptr(whb), _ptr(out), _ptr(csave), _ptr(scratch), scratch.numel(),
+                                   B, T, H, _stream()))
+    y = out[:, 2:2 + T].clone()
+    if d_out is None:
+        return y
+    ds = _slab(d_out.to(dev))
+    scratch.zero_()
+    _capi.check(lib.ss_op_lstm_bwd(_ptr(gates), _ptr(whf), _ptr(whb), _ptr(ds), _ptr(csave), _ptr(scratch), scratch.numel(),
+                                   B, T, H, _stream()))
+    dG = gates.view(R, 8 * H)                                               # pre-activation gradients, halo rows zero
+    dx = gemm(dG, wcat, tb=True).view(B, T + 4, In)[:, 2:2 + T].clone()     # dX = dG . W_ih (both directions)
+    grads = []
+    flat_x = xs.view(R, In)
+    flat_o = out.view(R, 2 * H)
+    for d in range(2):
+        dGd = dG[:, d * 4 * H:(d + 1) * 4 * H].contiguous()
+        gw_ih = gemm(dGd, flat_x, ta=True, tb=True)                         # [4H, In] = dG^T . X
+        hprev = torch.zeros(R, H, device=dev)
+        if d == 0:
+            hprev[1:] = flat_o[:-1, :H]                                     # forward: h(t-1) is one slab row earlier
+        else:
+            hprev[:-1] = flat_o[1:, H:]
+        gw_hh = gemm(dGd, hprev, ta=True, tb=True)
+        grads.append((gw_ih, gw_hh, dGd.sum(0)))
+    return y, dx, grads
 
 
 def tune(key, value):

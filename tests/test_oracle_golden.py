@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from oracle import interp_np, ref_model, weights as W
+from oracle.gen_fixtures import draws_for, synth_batch
 
 torch.set_num_threads(4)
 
@@ -215,3 +216,45 @@ def test_g6_train_forward_and_ce(gold_dir):
     for n, s in rec['grads'].items():
         gl = float(P[n].grad.double().norm())
         assert abs(gl - s['l2']) <= 1e-4 * s['l2'] + 1e-12, n
+
+
+def test_relu_mask_override_is_neutral_with_own_branches():
+    """ref_model.MASK (the hook the GPU parity tests use to hand the oracle the engine's ReLU branches): fed the oracle's OWN
+    branches it must change nothing -- same loss, same gradients, zero disagreements -- and a flipped element must be reported."""
+    hp = W.default_hparams(max_len_pad=64)
+    w = W.make_weights('G3', hp, 3)
+    mel, f0, emb, lens = synth_batch(5, 2, 64, 64)
+    draws = draws_for(6, 2, 4)
+    P = ref_model.as_params(w)
+    ref_model.TAP = {}
+    l0, _ = ref_model.g3_loss(P, hp, mel, f0, emb, lens.numpy(), draws)
+    tap, ref_model.TAP = ref_model.TAP, None
+    l0.backward()
+    g0 = {n: p.grad.clone() for n, p in P.items()}
+    # the oracle's own branches: GroupNorm of the tapped conv outputs
+    masks = {}
+    for k, v in tap.items():
+        if k.endswith('.conv') and not k.startswith('zmin:'):
+            pre = {'enc2.c': 'encoder_2.convolutions.0'}.get(k[:-5]) or \
+                f"encoder_1.convolutions_{k[6]}.{k[8]}"          # 'enc1.c<stream>_<layer>.conv'
+            z = torch.nn.functional.group_norm(v.transpose(1, 2), v.shape[-1] // 16, P[pre + '.1.weight'].detach(),
+                                               P[pre + '.1.bias'].detach(), eps=1e-5)
+            masks[k[:-5]] = (z > 0).transpose(1, 2)
+    assert len(masks) == 7
+    P2 = ref_model.as_params(w)
+    ref_model.MASK, ref_model.MASK_STATS = masks, {}
+    try:
+        l1, _ = ref_model.g3_loss(P2, hp, mel, f0, emb, lens.numpy(), draws)
+        stats = dict(ref_model.MASK_STATS)
+        l1.backward()
+        assert float(l1) == float(l0) and all(v == (0, 0.0) for v in stats.values()), stats
+        for n, p in P2.items():
+            assert torch.equal(p.grad, g0[n]), n
+        flipped = {k: v.clone() for k, v in masks.items()}
+        flipped['enc2.c'][0, 0, 0] = ~flipped['enc2.c'][0, 0, 0]
+        ref_model.MASK, ref_model.MASK_STATS = flipped, {}
+        with torch.no_grad():
+            ref_model.g3_loss(P2, hp, mel, f0, emb, lens.numpy(), draws)
+        assert ref_model.MASK_STATS['enc2.c'][0] == 1 and ref_model.MASK_STATS['enc2.c'][1] > 0
+    finally:
+        ref_model.MASK, ref_model.MASK_STATS = None, None
