@@ -1,17 +1,28 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Generator_3 training step (solver.py:157-172) throughput in utterances/s.
+"""Headline benchmark: Generator_3 training step (reference solver.py:157-172) throughput in utterances/s.
 
   python bench.py --gpus N --steps K --warmup W
 
 N=1: one process.  N>1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`,
-one rank per GPU; each rank processes its own 64-utterance shard (weak scaling), gradients are averaged with one
-RCCL all-reduce over the flat gradient arena, then every rank applies the same Adam update.
+one rank per GPU; each rank processes its own 64-utterance shard (weak scaling), gradients are summed with RCCL
+all-reduces over the flat gradient arena (decoder bucket beside the encoder backward, then the encoder bucket), then every
+rank applies the same Adam update with the 1/N mean folded in.
 
-Workload (BASELINE.json metric / SURVEY.md section 8(d)): batch 64 per GPU, 128 frames, 80-bin mel + F0, fp32,
-max_len_pad=128, synthetic inputs resident in HBM before the timed region, weights from a fixed seed.
-A step = resample -> quantise -> forward -> MSE -> backward -> [all-reduce] -> Adam, nothing skipped.
+Workload (BASELINE.json metric / SURVEY.md section 8(d)): batch 64 per GPU, 128 frames, 80-bin mel + F0, max_len_pad=128,
+synthetic batch resident in HBM before the timed region, weights from a fixed seed.  A step = resample -> quantise ->
+forward -> MSE -> backward -> [all-reduce] -> Adam, nothing skipped; every timed step draws FRESH resampling randomness on
+the host with the reference's generator calls (model.py:392-393, 399-402) and uploads it from pinned memory, non-blocking.
 
-Rank 0 prints ONE JSON line (contract in the task statement) including `roofline` and `cpu_baseline`.
+Rank 0 prints ONE JSON line (contract in the task statement).  Besides the contract's fields:
+  config.products   the product format of the contractions (the default mode is fp32 storage / accumulation with every
+                    product formed from an fp16 x 2 split on the 16-bit matrix pipe: 22 significand bits, see the header)
+  roofline          the kernel class with the most GPU time in the timed region (hipEvent brackets on the launch streams,
+                    ss_profile), algorithmic FLOPs / its summed duration, against the pipe it runs on
+  kernel_classes    time / launches / rate of every kernel class per step, from an all-class survey pass before the timed region
+  recurrence        the six persistent decoder-recurrence launches: us per time step forward / backward, share of the step
+  alt_precisions    the same step with exact bf16 x 3 split products and with true fp32 MFMA products (ms per step)
+  solver_loop       Solver.train() iterations/s through the device-side batch producer (loader-to-loss, N=1 only)
+  cpu_baseline      the oracle on the host cores: batch 64 on the box's CPU share, plus the 1-thread figure
 """
 import argparse
 import json
@@ -19,7 +30,6 @@ import os
 import sys
 import time
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -27,8 +37,11 @@ sys.path.insert(0, ROOT)
 
 # algorithmic work, SURVEY.md section 8(d): 19 405 064 MAC / frame / utterance, fwd+bwd = 3 x 2 x MAC
 MAC_PER_FRAME_G3 = 19405064
-PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_16BIT_MFMA_TFLOPS = 2500.0    # dense bf16 / fp16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+PRODUCTS = {'f32': 'fp32 operands/accumulate/storage; products on the 16-bit matrix pipe from an fp16 x 2 split (3 MFMAs, '
+                   '22 significand bits rel. to the operand maximum); head + encoder BLSTMs bf16 x 3 (6 MFMAs, exact to 2^-24)',
+            'bf16': 'operands rounded to bf16 inside the GEMM (1 MFMA), fp32 accumulate/storage/recurrent state'}
 
 
 def synth(B, T, seed, device):
@@ -44,33 +57,126 @@ def synth(B, T, seed, device):
     return [t.to(device) for t in (mel, f0, emb, lens.to(torch.int32))]
 
 
-def cpu_baseline(T, seconds_budget=20.0):
-    """The oracle (PyTorch-CPU restatement of the reference step, same ATen/oneDNN kernels) timed on the host cores,
-    on a bounded sample of the same workload: batch 16 instead of 64 (utt/s is flat in B on CPU)."""
+def cpu_baseline(T, budget=12.0):
+    """The oracle (PyTorch-CPU restatement of the reference step, same ATen / oneDNN kernels as the reference) timed on the
+    host: the SAME shape as the GPU line (batch 64) on the CPU share of one GPU slot, and one thread at batch 16."""
     from oracle import ref_model, weights as W
     from oracle.gen_fixtures import synth_batch, draws_for
-    # the GPU box shares its host: use the CPU share of one GPU slot (16), not every core the kernel lists
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = int(os.environ.get('SS_CPU_THREADS', min(avail, 16)))
-    torch.set_num_threads(cores)
-    print(f'[bench] cpu_baseline: {cores} threads (of {avail} visible)', file=sys.stderr, flush=True)
-    B = 16
+    cores = int(os.environ.get('SS_CPU_THREADS', min(avail, 16)))   # a one-GPU box owns 16 host cores of the 256 the kernel lists
     hp = W.default_hparams(max_len_pad=T)
-    st = ref_model.TrainState(W.make_weights('G3', hp, 0))
-    mel, f0, emb, lens = synth_batch(1, B, T, 64)
-    draws = draws_for(2, B, 4)
-    st.step_g3(hp, mel, f0, emb, lens.numpy(), draws)          # warm-up
-    n, t0 = 0, time.time()
-    while n < 3 or (time.time() - t0 < seconds_budget and n < 20):
-        st.step_g3(hp, mel, f0, emb, lens.numpy(), draws)
-        n += 1
-        print(f'[bench] cpu_baseline step {n}: {(time.time() - t0) / n:.2f} s/step', file=sys.stderr, flush=True)
-    dt = (time.time() - t0) / n
-    return dict(value=round(B / dt, 2), unit='utterances/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'{n} full training steps of Generator_3 at batch {B} x {T} frames (PyTorch-CPU oracle, fp32)')
+
+    def run(B, threads, budget, min_steps):
+        torch.set_num_threads(threads)
+        st = ref_model.TrainState(W.make_weights('G3', hp, 0))
+        mel, f0, emb, lens = synth_batch(1, B, T, 64)
+        draws = draws_for(2, B, 4)
+        st.step_g3(hp, mel, f0, emb, lens.numpy(), draws)          # warm-up
+        n, t0 = 0, time.time()
+        while n < min_steps or (time.time() - t0 < budget and n < 20):
+            st.step_g3(hp, mel, f0, emb, lens.numpy(), draws)
+            n += 1
+            print(f'[bench] cpu_baseline B={B} threads={threads} step {n}: {(time.time() - t0) / n:.2f} s/step', file=sys.stderr, flush=True)
+        return B / ((time.time() - t0) / n), n
+
+    v64, n64 = run(64, cores, budget, 3)
+    v1, n1 = run(16, 1, 6.0, 1)
+    torch.set_num_threads(cores)
+    return dict(value=round(v64, 2), unit='utterances/s', cores=cores, kind='port',
+                sample=f'{n64} full training steps of Generator_3 at batch 64 x {T} frames on {cores} threads (of {avail} visible; '
+                       f'PyTorch-CPU oracle, fp32)',
+                one_thread=dict(value=round(v1, 2), cores=1, sample=f'{n1} step(s) at batch 16 x {T} frames'))
+
+
+def class_table(rec, steps, mfmas):
+    return {k: dict(launches_per_step=round(n / steps, 2), us_per_step=round(us / steps, 1),
+                    tflops=round(fl / us / 1e6, 2) if us else None, mfma_per_product=mfmas[k]) for k, (n, us, fl) in rec.items()}
+
+
+def mfma_per_product(rec, precision):
+    """the pipe each class runs on, as MFMA instructions per algorithmic fp32 product"""
+    if precision == 'bf16':
+        return {k: 1 for k in rec}
+    m = {k: 3 for k in rec}                              # fp16 x 2
+    for k in ('head', 'enc_lstm'):
+        m[k] = 6                                         # bf16 x 3
+    return m
+
+
+def dominant_class(rec):
+    gemm = {k: v for k, v in rec.items() if not k.startswith('rec_')}
+    return max(gemm, key=lambda k: gemm[k][1])
+
+
+def kernel_report(eng, steps, ms_step, precision, top, survey):
+    """roofline / recurrence from the hipEvent brackets recorded DURING the timed region (dominant class + recurrences);
+    kernel_classes from the all-class survey pass that ran before it (same process, same inputs)."""
+    rec = eng.profile_read()
+    if not rec or top not in rec:
+        return None, None, None
+    mfmas = mfma_per_product({**survey[0], **rec}, precision)
+    classes = class_table(survey[0], survey[1], mfmas)
+    n, us, fl = rec[top]
+    ach = fl / us / 1e6
+    peak = PEAK_16BIT_MFMA_TFLOPS / mfmas[top]
+    names = {'dec_dw': 'gemm_bf16x3_kernel<128,128,TN> split-K: decoder weight gradients dW_ih / dW_hh (12 launches per step, beside the encoder backward)',
+             'dec_proj': 'gemm_bf16x3_kernel<128,128,NT>: decoder input projection, layers 1-2',
+             'dec_dx': 'gemm_bf16x3_kernel<128,128,NN>: decoder input gradients',
+             'conv_fwd': 'gemm_bf16x3_kernel<.,.,NT> segmented-K: conv trunk forward',
+             'conv_dw': 'gemm_bf16x3_kernel<.,.,TN> split-K: conv weight gradients',
+             'conv_dx': 'gemm_bf16x3_kernel<.,.,NT> segmented-K: conv input gradients'}
+    traffic = None
+    try:      # HBM bytes per launch from the separate rocprofv3 --pmc passes kept under profiles/ (tools/pmc_summary.py)
+        for r in json.load(open(os.path.join(ROOT, 'profiles', 'r02', 'gemm_pmc.json'))):
+            if r.get('class') == top:
+                traffic = r['hbm_read_bytes'] + r['hbm_write_bytes']
+    except Exception:
+        pass
+    roof = {'bound': 'mfma', 'kernel': names.get(top, top), 'class': top, 'achieved': round(ach, 2), 'peak': round(peak, 1),
+            'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+            'peak_basis': f'dense 16-bit MFMA {PEAK_16BIT_MFMA_TFLOPS:.0f} TFLOP/s / {mfmas[top]} MFMA products per fp32 multiply-add',
+            'mfma_tflops_executed': round(mfmas[top] * ach, 1), 'fp32_mfma_peak': PEAK_F32_MFMA_TFLOPS,
+            'vs_fp32_mfma_peak': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'launches_timed': n,
+            'flops_per_launch': round(fl / n), 'us_per_launch': round(us / n, 2),
+            'share_of_bracketed_gpu_time': round(survey[0][top][1] / sum(v[1] for v in survey[0].values()), 3), 'traffic': traffic}
+    recur = None
+    if 'rec_fwd' in rec and 'rec_bwd' in rec:
+        T = eng.hp.max_len_pad
+        nf, uf, _ = rec['rec_fwd']
+        nb, ub, _ = rec['rec_bwd']
+        recur = {'launches_per_step': round((nf + nb) / steps, 2), 'fwd_us_per_time_step': round(uf / nf / T, 3),
+                 'bwd_us_per_time_step': round(ub / nb / T, 3), 'ms_per_step': round((uf + ub) / steps / 1e3, 3),
+                 'share_of_step_wall_time': round((uf + ub) / steps / 1e3 / ms_step, 3)}
+    return roof, classes, recur
+
+
+def solver_loop(B, T, iters=40, warm=8):
+    """Loader-to-loss: Solver.train() as main.py runs it, batches cropped / clipped / padded on the GPU from an HBM-resident
+    synthetic corpus (data_loader.get_device_loader), host draws per step, H2D staging, log line every 10 iterations."""
+    import contextlib
+    import io
+    import tempfile
+    from types import SimpleNamespace
+    from speechsplit_amd import data_loader, hparams as HP, solver
+    hp = HP.default_hparams(batch_size=B, max_len_pad=T)
+    loader = data_loader.get_device_loader(hp, dataset=data_loader.SyntheticUtterances(4 * B, seed=5))
+    with tempfile.TemporaryDirectory() as tmp, contextlib.redirect_stdout(io.StringIO()):
+        cfg = SimpleNamespace(num_iters=warm, g_lr=1e-4, beta1=0.9, beta2=0.999, resume_iters=None, use_tensorboard=False, device_id=torch.cuda.current_device(),
+                              log_dir=tmp, sample_dir=tmp, model_save_dir=tmp, log_step=10, sample_step=10 ** 9, model_save_step=10 ** 9)
+        s = solver.Solver(loader, cfg, hp)
+        s.validation_pt = []
+        s.train()
+        torch.cuda.synchronize()
+        s.num_iters = iters
+        t0 = time.perf_counter()
+        s.train()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return {'iterations_per_s': round(iters / dt, 2), 'utterances_per_s': round(B * iters / dt, 1), 'ms_per_iteration': round(dt / iters * 1e3, 3),
+            'what': f'speechsplit_amd.solver.Solver.train(), {iters} iterations, batch {B} x {T}, DeviceBatcher + DevicePrefetcher, loss read every 10 iterations'}
 
 
 def main():
@@ -81,55 +187,54 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='utterances per GPU')
     ap.add_argument('--frames', type=int, default=128)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip alt_precisions and solver_loop')
     ap.add_argument('--precision', choices=['f32', 'bf16'], default='f32',
-                    help="f32 (default): the 1e-4 parity mode the headline is quoted on; bf16: BASELINE configs 2-4's arithmetic")
-    ap.add_argument('--stream', choices=['default', 'own'], default='default', help='launch the steps on the default stream or on a stream of their own')
+                    help="f32 (default): the 1e-4 parity mode the headline is quoted on; bf16: BASELINE configs 3-5's arithmetic")
+    ap.add_argument('--force-dp', action='store_true', help='run the data-parallel step (bucketed all-reduce, sliced draws) even at world size 1')
+    ap.add_argument('--no-profile', action='store_true', help='no hipEvent brackets in the timed region (to measure their cost)')
     ap.add_argument('--tune', action='append', default=[], metavar='KEY=VALUE', help='experiment knob of the HIP library (ss_tune)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py: for --gpus N > 1 launch with torch.distributed.run --nproc-per-node N')
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        sys.exit('bench.py: for --gpus N > 1 launch with torch.distributed.run --nproc-per-node N')
     torch.cuda.set_device(local)
     dev = torch.device(f'cuda:{local}')
 
-    from oracle import weights as W            # weight generator only (frozen-stream seeds); not on the timed path
+    from speechsplit_amd import hparams as HP, model as M
     from speechsplit_amd.engine import Engine, draw_interp, tune
     for kv in args.tune:
         k, v = kv.split('=')
         tune(k, int(v))
     B, T = args.batch, args.frames
-    hp = W.default_hparams(max_len_pad=T)
+    hp = HP.default_hparams(max_len_pad=T, batch_size=B * world)
     eng = Engine('G3', hp, B, T, device=dev)
-    eng.load_weights(W.make_weights('G3', hp, 0))
-    # The communicator comes AFTER the engine: HIP spreads a process's streams over 4 hardware queues in creation order, and
-    # the engine's four streams should get one each (with RCCL's streams created first the same step measured 0.3 - 0.7 ms
-    # slower on one GPU: tools/stream_order_effect.py, tools/soak_dp.py).
+    eng.load_weights(M.init_weights('G3', hp, 0))          # the reference's initialisers, fixed seed
+    dp = world > 1 or args.force_dp
     dist = None
-    if world > 1:
+    if dp:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     eng.set_adam(1e-4, 0.9, 0.999, 1e-8, 0)
     eng.set_precision(args.precision)
     mel, f0, emb, lens = synth(B, T, 1000 + rank, dev)
     torch.manual_seed(1234)
-    sc_all, ls_all = draw_interp(B * world, 4, hp)          # one global draw stream, each rank takes its utterances' slice
-    S = sc_all.shape[1] // (B * world)
-    sc = sc_all.view(4, world, B * S)[:, rank].contiguous().to(dev)
-    ls = ls_all.view(4, world, B * S)[:, rank].contiguous().to(dev)
+    S = hp.max_len_seq // hp.min_len_seg + 1
 
     def step():
-        if world == 1:
-            eng.g3_train_step(mel, f0, emb, lens, (sc, ls))
-        else:
-            # RCCL sum of the gradient arena over xGMI: decoder + head bucket from the engine's side stream beside the encoder backward,
-            # then the encoder bucket (Engine.dp_train_step, schedule 'overlap');
-            # the mean is taken inside the Adam kernel
+        # fresh randomness every step: one global draw stream (the reference's generator calls), each rank takes its utterances' slice
+        sc, ls = draw_interp(B * world, 4, hp)
+        if world > 1:
+            sc = sc.view(4, world, B * S)[:, rank]
+            ls = ls.view(4, world, B * S)[:, rank]
+        if dp:
             eng.dp_train_step(mel, f0, emb, lens, (sc, ls), world)
+        else:
+            eng.g3_train_step(mel, f0, emb, lens, (sc, ls))
 
     def barrier():
         torch.cuda.synchronize()
@@ -137,88 +242,71 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.stream == 'own':
-        own = torch.cuda.Stream(dev)
-        own.wait_stream(torch.cuda.current_stream())
-        torch.cuda.set_stream(own)
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    eng.profile(True)            # hipEvent pairs around the dominant kernel's launches, on their launch stream (ss_profile)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt)
+    def timed(steps, warmup, profile):
+        for _ in range(warmup):
+            step()
+        barrier()
+        if profile:
+            eng.profile(profile)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if profile:
+            eng.profile(False)
+        if dist is not None:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt)
+        return dt
+
+    # survey pass (untimed): every kernel class bracketed, to find the class with the most GPU time; the timed region then
+    # carries brackets on that class and on the recurrences only (all 71 brackets per step cost 4.5 %, these < 1 %)
+    top, survey = None, None
+    if not args.no_profile:
+        timed(6, 2, True)
+        survey = (eng.profile_read(), 6)
+        top = dominant_class(survey[0])
+    dt = timed(args.steps, args.warmup, None if args.no_profile else [top, 'rec_fwd', 'rec_bwd'])
     eng.check()                  # outside the timed region: no persistent kernel reported a bounded-wait expiry
     ms = dt / args.steps * 1e3
     value = B * world / (dt / args.steps)
 
     if rank == 0:
-        # roofline of the dominant kernel family: the fp32 MFMA GEMM.  Timed live with HIP events on the launch stream
-        # at the shape that carries the most FLOPs in the step (decoder input projection, layer 1/2).
         print(f'[bench] gpu: {ms:.3f} ms/step, {value:.1f} utt/s on {world} GPU(s)', file=sys.stderr, flush=True)
-        roof = gemm_roofline(eng, B, T, args.precision)
+        roof, classes, recur = kernel_report(eng, args.steps, ms, args.precision, top, survey) if top else (None, None, None)
         print(f'[bench] roofline: {roof}', file=sys.stderr, flush=True)
+    alt = None
+    if not args.no_extras and args.precision == 'f32':
+        # the same step with the other product formats of the fp32 mode (every rank runs them: the collectives must match)
+        alt = {}
+        for name, knobs in (('bf16x3_exact_split_ms', {'fwd_f16x2': 0, 'bwd_f16x2': 0}), ('fp32_mfma_ms', {'gemm_mode': 0})):
+            for k, v in knobs.items():
+                tune(k, v)
+            alt[name] = round(timed(8, 2, False) / 8 * 1e3, 3)
+            for k in knobs:
+                tune(k, 1)
+        eng.check()
+    if rank == 0:
         out = {
             'metric': 'utterances/sec (fwd+bwd, 128-frame 80-mel, batch 64) at 1/2/4/8 MI355X',
             'value': round(value, 1), 'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.precision, 'data': 'synthetic',
-            'config': {'workload': f'Generator_3 full training step (resample+quantise+fwd+MSE+bwd+Adam), '
+            'config': {'workload': f'Generator_3 full training step (host draws+resample+quantise+fwd+MSE+bwd+Adam), '
                                    f'{B} utterances/GPU x {T} frames x 80 mel + F0, max_len_pad={T}',
-                       'global_batch': B * world, 'seq_len': T, 'parallelism': f'dp{world}'},
+                       'global_batch': B * world, 'seq_len': T, 'parallelism': f'dp{world}' + (' (forced DP path)' if args.force_dp and world == 1 else ''),
+                       'products': PRODUCTS[args.precision]},
             'step_tflops': round(3 * 2 * MAC_PER_FRAME_G3 * T * B * world / (dt / args.steps) / 1e12, 2),
-            'roofline': roof,
+            'roofline': roof, 'kernel_classes': classes, 'recurrence': recur, 'alt_precisions': alt,
+            'solver_loop': None if (args.no_extras or world > 1) else solver_loop(B, T),
             'cpu_baseline': None if args.no_cpu_baseline else cpu_baseline(T),
         }
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def gemm_roofline(eng, B, T, precision='f32'):
-    """Roofline of the dominant kernel, measured INSIDE the timed region: the engine brackets every launch of the decoder
-    input-projection GEMM of layers 1-2 (gemm_bf16x3_kernel<128,128,NT>; per launch M = B*T rows, N = 4096 = both directions,
-    K = 1024, fp32 in / fp32 out / fp32 accumulate) with hipEvents on its launch stream (ss_profile in
-    include/speechsplit_amd.h).  achieved = algorithmic FLOPs of one launch (2*M*N*K) / mean launch duration.
-
-    The kernel forms every fp32 product on the 16-bit matrix pipe (dense peak 2.5 PFLOP/s for fp16 and bf16 alike) from a
-    split of both operands: forward contractions, whose operands are bounded by construction, use fp16 x 2 = 3
-    v_mfma_f32_32x32x16_f16 per multiply-add (22 significand bits relative to the operand's maximum); the general path is
-    bf16 x 3 = 6 MFMAs.  The ceiling in algorithmic fp32 FLOP/s is therefore 2500 / 3 = 833 TFLOP/s for this kernel; the
-    fp32 MFMA peak (157.3 TFLOP/s) is reported beside it."""
-    n, us, flops = eng.profile(False)
-    if n == 0:
-        return None
-    sec = us / n / 1e6
-    ach = flops / sec / 1e12
-    # HBM bytes per launch of this shape from the PMC passes kept under profiles/ (separate rocprofv3 --pmc runs, gfx950
-    # corrections applied by tools/pmc_summary.py); counters cannot be collected from inside the benchmark process
-    traffic = None
-    try:
-        rec = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'gemm_pmc.json')))[0]
-        if rec['shape'].startswith('proj NT 8192x4096x1024') and B * T == 8192 and 'bf16x3' in rec.get('kernel', ''):
-            traffic = rec['hbm_read_bytes'] + rec['hbm_write_bytes']
-    except Exception:
-        pass
-    if precision == 'bf16':      # one bf16 MFMA per product: the pipe's own peak
-        return {'bound': 'mfma', 'kernel': 'gemm_bf16x3_kernel<128,128,NT,1 plane> (decoder input projection, layers 1-2; bf16 operands, fp32 accumulate)',
-                'achieved': round(ach, 2), 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
-                'launches_timed': n, 'flops_per_launch': flops, 'us_per_launch': round(sec * 1e6, 2), 'traffic': None}
-    products = 3
-    peak = PEAK_BF16_MFMA_TFLOPS / products
-    return {'bound': 'mfma', 'kernel': 'gemm_bf16x3_kernel<128,128,NT,fp16x2> (decoder input projection, layers 1-2; fp32 via 3 fp16 MFMAs per product)',
-            'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-            'peak_basis': 'dense 16-bit MFMA 2500 TFLOP/s / 3 MFMA products per fp32 multiply-add',
-            'mfma_tflops_executed': round(products * ach, 1), 'fp32_mfma_peak': PEAK_F32_MFMA_TFLOPS,
-            'vs_fp32_mfma_peak': round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-            'launches_timed': n, 'flops_per_launch': flops, 'us_per_launch': round(sec * 1e6, 2), 'traffic': traffic}
 
 
 if __name__ == '__main__':

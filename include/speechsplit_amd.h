@@ -125,8 +125,23 @@ int ss_collate(const float* mel_cat_dev, const float* f0_cat_dev, const float* e
                const int* len_dev, const int* item_dev, int B, int T, int n_mel, int emb_dim, float* mel_dev, float* f0_dev,
                float* emb_dev, void* stream);
 
-/* Synchronise `stream` and report asynchronous failures (a persistent recurrence kernel whose bounded wait expired). */
+/* Asynchronous failures.  The engine keeps a STATUS WORD that kernels set and no step clears:
+ *   SS_STATUS_ABORT   a persistent recurrence kernel's bounded wait expired on this device (e.g. the GPU is shared and the
+ *                     256-workgroup grid was not co-resident): that step's gradients are garbage;
+ *   SS_STATUS_REMOTE  another data-parallel rank reported the same through the gradient arena's status slot (the last four
+ *                     floats of the arena; the all-reduce sums it);
+ *   SS_STATUS_RANGE   a parameter is not finite or reached |p| >= 64, outside what the fixed-scale fp16 x 2 forward
+ *                     products are valid for.
+ * While it is non-zero the Adam kernel SKIPS the update on the device (parameters, moments and step counter untouched --
+ * no host round trip is involved), every later ss_*_forward / ss_*_train_step / ss_adam_step returns an error without
+ * enqueueing anything, and ss_check() keeps failing until ss_clear_abort().  ss_check synchronises `stream`;
+ * ss_status() reads the word without synchronising. */
+#define SS_STATUS_ABORT 1u
+#define SS_STATUS_REMOTE 2u
+#define SS_STATUS_RANGE 4u
 int ss_check(ss_engine* e, void* stream);
+unsigned ss_status(const ss_engine* e);
+int ss_clear_abort(ss_engine* e, void* stream);
 
 /* ---- test / profiling hooks ---- */
 /* C[M,N] = A . B^T style fp32 MFMA GEMM used by every contraction on the path (flags: 1 = A stored [K,M], 2 = B stored [K,N], 8 = bf16-rounded operands) */
@@ -155,25 +170,51 @@ int ss_op_conv_block(const float* x_dev, const float* w_dev, const float* bias_d
  * of 0 may fall on either side in two correct implementations; parity tests hand this mask to the oracle so that the
  * comparison of gradients does not depend on that coin flip. */
 int ss_debug_relu_mask(ss_engine* e, const char* block, float* mask_dev, void* stream);
-/* tuning knobs (process-global): "lstm_nw" 4|8|16, "lstm_g" 0..16, "gemm_bk" 16|32, "gemm_want" >= 1,
- * "overlap" 0|1, "graph" 0|1, "persist" 0|1, "split" 0|1, "gemm_mode" 0 (fp32 MFMA) | 1 (split arithmetic on the 16-bit pipe),
- * "fwd_f16x2" / "bwd_f16x2" 0|1 (fp16 x 2 instead of bf16 x 3 for the forward / the scaled gradient contractions);
- * "lstm_mode" / "gemm_diag" / "seq_prio" > 1 are timing experiments that produce wrong results */
+/* tuning knobs (process-global; every value leaves the results correct): "lstm_nw" 4|8|16, "lstm_g" 0..16, "gemm_bk" 16|32,
+ * "gemm_want" >= 1, "overlap" 0|1, "graph" 0|1, "persist" 0|1, "split" 0|1, "gemm_mode" 0 (fp32 MFMA) | 1 (split arithmetic on
+ * the 16-bit pipe), "fwd_f16x2" / "bwd_f16x2" 0|1 (fp16 x 2 instead of bf16 x 3 for the forward / the scaled gradient
+ * contractions), "seq_spin_log2" 0..24 (log2 of the persistent kernels' bounded wait; 0 makes it expire at once -- how the
+ * tests exercise the abort path), "deterministic" 0|1.  The timing experiments that produce WRONG results ("lstm_mode",
+ * "gemm_diag", "seq_prio" > 1) are compiled out of this library; `make -C speechsplit_amd/csrc diag` builds
+ * libspeechsplit_hip_diag.so with them for tools/ (never loaded by the package unless SS_DIAG_LIB=1 is set). */
 int ss_tune(const char* key, int value);
 /* Arithmetic of the contractions (convolutions, LSTM input projections, all weight / input gradients, head).
- * SS_PRECISION_F32 (default): fp32-grade products (exact 3-way bf16 split, 6 MFMAs) -- the 1e-4 parity mode.
+ * SS_PRECISION_F32 (default) -- the 1e-4 parity mode.  Operands, accumulation and storage are fp32; every PRODUCT is formed
+ *   on the 16-bit matrix pipe from a split of both fp32 operands:
+ *     fp16 x 2 (default wherever an operand's magnitude is known): y = s*x = h + l, h = fp16(y), l = fp16(y - h), s a power of
+ *       two; 3 v_mfma_f32_32x32x16_f16 per k-step (h.l, l.h, h.h): 22 significand bits relative to the operand's scaled
+ *       maximum (elements more than 2^22 below it lose relative precision; the residual goes subnormal 2^-3 below the
+ *       maximum's binade and flushes at 2^-33 of it).  Forward operands use the fixed scale s = 16 (|x| < 4094 survives);
+ *       ss_bind / every parameter load checks max|w| against that range and the engine falls back to bf16 x 3 when it
+ *       does not hold.  Gradient operands are scaled by the power of two their producer kernel measured.
+ *     bf16 x 3 (head, encoder BLSTMs, unaligned shapes; everything with ss_tune("fwd_f16x2" / "bwd_f16x2", 0)): exact
+ *       3-way truncation split x = h + m + l, 6 v_mfma_f32_32x32x16_bf16 per k-step, dropped terms <= 2^-24 relative.
+ *     ss_tune("gemm_mode", 0): true fp32 MFMA (v_mfma_f32_32x32x2_f32), the A/B reference.
+ *   Against fp64 the three measure 1.3-2.2e-6, 1.2e-6 and 1.3e-6 of max|C| (profiles/r02/f16x2_error.txt).
  * SS_PRECISION_BF16: operands rounded to bf16 (nearest-even) inside the GEMM, one MFMA, fp32 accumulation; storage, the
- * recurrences (W_hh.h, cell state), GroupNorm, losses, resampling indices and Adam stay fp32 (BASELINE configs 2-4). */
+ *   recurrences (W_hh.h, cell state), GroupNorm, losses, resampling indices and Adam stay fp32 (BASELINE configs 3-5). */
 #define SS_PRECISION_F32 0
 #define SS_PRECISION_BF16 1
 int ss_set_precision(ss_engine* e, int precision);
-/* Live timing of the dominant kernel inside a caller's own timed region: while enabled, the engine brackets every launch
- * of the decoder input-projection GEMM of layers >= 1 (one launch per layer, both directions: M = B*T rows, N = 8H, K = 2H,
- * H = decoder hidden size) with
- * hipEvents on the stream it is launched on.  A call returns the launches recorded since the previous call, their summed
- * duration and the algorithmic FLOPs of one launch (2*B*T*8H*2H), resets the record and sets the enable state.
- * Synchronises on the recorded events.  At most 256 launches are kept between two calls.  Any out pointer may be null. */
-int ss_profile(ss_engine* e, int enable, int* launches, double* total_us, double* flops_per_launch);
+/* Live timing of the step's kernels inside a caller's own timed region.  ss_profile(e, mask) makes the engine bracket every
+ * launch of the classes whose bit (1u << class) is set with hipEvents on the stream the launch goes to (a non-zero mask clears
+ * the record, 0 stops recording; at most 8192 launches are kept).  A bracket costs ~4 us of stream time: all 71 per step are
+ * +4.5 % on the step, the dominant class + the recurrences (18 per step) are below 1 %.  ss_profile_read synchronises on the recorded events of one class and returns their count, their summed duration
+ * and their summed algorithmic FLOPs (2*M*N*K per GEMM; 2 * 2 directions * B * T * 4H * H per recurrence launch). */
+#define SS_PROF_DEC_PROJ 0  /* decoder input projection, layers >= 1 (NT, M = B*T, N = 8H, K = 2H) */
+#define SS_PROF_DEC_PROJ0 1 /* decoder input projection, layer 0 (K = 164 / 66) */
+#define SS_PROF_DEC_DW 2    /* decoder weight gradients dW_ih, dW_hh (TN, split-K) */
+#define SS_PROF_DEC_DX 3    /* decoder input gradients (NN) */
+#define SS_PROF_CONV_FWD 4  /* conv trunk forward (segmented-K NT) */
+#define SS_PROF_CONV_DW 5   /* conv weight gradients (TN) */
+#define SS_PROF_CONV_DX 6   /* conv input gradients */
+#define SS_PROF_REC_FWD 7   /* persistent decoder recurrence, forward (one launch per layer) */
+#define SS_PROF_REC_BWD 8   /* persistent decoder recurrence, backward */
+#define SS_PROF_ENC_LSTM 9  /* encoder BLSTM projections / gradients (small GEMMs) */
+#define SS_PROF_HEAD 10     /* LinearNorm head forward / gradients */
+#define SS_PROF_CLASSES 11
+int ss_profile(ss_engine* e, unsigned class_mask);
+int ss_profile_read(ss_engine* e, int klass, int* launches, double* total_us, double* total_flops);
 /* timing experiment: with ss_tune("gemm_diag", 16) the 128x128 NT bf16x3 GEMM accumulates, for its first 64 workgroups, the
  * s_memtime ticks every wave spends per k-loop phase; out24 = [4 waves][split+store, barrier, load issue, fragments+MFMA,
  * barrier, k-tiles (wave 0 only)].  Synchronises the device. */

@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libspeechsplit_hip.so')
+# SS_DIAG_LIB=1 (tools/ only): the -DSS_DIAG build with the wrong-result timing experiments compiled in
+LIB_PATH = os.path.join(_HERE, 'lib', 'libspeechsplit_hip_diag.so' if os.environ.get('SS_DIAG_LIB') == '1' else 'libspeechsplit_hip.so')
 
 HP_FIELDS = ('freq', 'dim_neck', 'freq_2', 'dim_neck_2', 'freq_3', 'dim_neck_3', 'dim_enc', 'dim_enc_2', 'dim_enc_3',
              'dim_freq', 'dim_spk_emb', 'dim_f0', 'chs_grp', 'min_len_seg', 'max_len_seg', 'max_len_seq', 'max_len_pad')
@@ -50,6 +51,8 @@ SYMBOLS = {
     'ss_interp_forward': (_i, [_vp, _fp, _ip, _fp, _ip, _i, _i, _i, _fp, _ip, _fp, _ip, _vp]),
     'ss_interp_backward': (_i, [_vp, _fp, _i, _i, _i, _fp, _vp]),
     'ss_check': (_i, [_vp, _vp]),
+    'ss_status': (C.c_uint, [_vp]),
+    'ss_clear_abort': (_i, [_vp, _vp]),
     'ss_op_gemm': (_i, [_fp, _l, _fp, _l, _fp, _l, _fp, _i, _i, _i, _i, _i, _vp]),
     'ss_op_lstm_fwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _l, _i, _i, _i, _vp]),
     'ss_op_lstm_bwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _l, _i, _i, _i, _vp]),
@@ -58,7 +61,8 @@ SYMBOLS = {
     'ss_debug_relu_mask': (_i, [_vp, C.c_char_p, _fp, _vp]),
     'ss_collate': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'ss_set_precision': (_i, [_vp, _i]),
-    'ss_profile': (_i, [_vp, _i, C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    'ss_profile': (_i, [_vp, C.c_uint]),
+    'ss_profile_read': (_i, [_vp, _i, C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     'ss_debug_gemm_phases': (_i, [C.POINTER(C.c_ulonglong), _i]),
     'ss_tune': (_i, [C.c_char_p, _i]),
     'ss_debug_buffer': (_i, [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(_l), C.POINTER(_l)]),

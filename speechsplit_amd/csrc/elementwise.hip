@@ -5,6 +5,8 @@
 
 namespace ss {
 
+extern int g_deterministic;
+
 namespace {
 
 constexpr int GN_MAXIT = 16;     // T <= 256
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ stats, float* __restrict__ g_gamma,
                                                           float* __restrict__ g_beta, float* __restrict__ g_bias,
-                                                          unsigned* __restrict__ amax, int B, int T, int C) {
+                                                          unsigned* __restrict__ amax, float* __restrict__ part, int B, int T, int C) {
     __shared__ float red[256];
     __shared__ float g4[4];
     __shared__ float colred[3][16][64];
@@ -172,8 +174,21 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
         float s = 0.f;
         for (int r = 0; r < 16; ++r) s += colred[which][r][cc];
         float* dst = which == 0 ? g_gamma : which == 1 ? g_beta : g_bias;     // sums over the utterances meet in the arena
-        atomicAdd(dst + blockIdx.x * 64 + cc, s);
+        if (part) part[((long)b * 3 + which) * C + blockIdx.x * 64 + cc] = s;  // deterministic mode: summed in utterance order below
+        else atomicAdd(dst + blockIdx.x * 64 + cc, s);
     }
+}
+
+// deterministic mode: dst[which][c] += sum over b (in order) of part[b][which][c]
+__global__ __launch_bounds__(256) void gn_part_reduce_kernel(const float* __restrict__ part, int B, int C, float* __restrict__ g_gamma,
+                                                             float* __restrict__ g_beta, float* __restrict__ g_bias) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 3 * C) return;
+    const int which = i / C, c = i - which * C;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += part[((long)b * 3 + which) * C + c];
+    float* dst = which == 0 ? g_gamma : which == 1 ? g_beta : g_bias;
+    dst[c] += s;
 }
 
 // Test hook: the ReLU branch the engine took for every element, recomputed from the saved conv output and statistics with the
@@ -434,7 +449,15 @@ __global__ __launch_bounds__(64) void ce_kernel(const float* __restrict__ logits
 // ------------------------------------------------------------------------------------------------ Adam
 // torch.optim.Adam defaults as solver.py:62 constructs it (no amsgrad, no weight decay), single-tensor formulas:
 //   m = lerp(m, g, 1-b1); v = v*b2 + (1-b2) g*g; p -= step_size * m / (sqrt(v)/sqrt(bc2) + eps)
-__global__ void adam_prepare_kernel(AdamState* st) {
+__global__ void adam_prepare_kernel(AdamState* st, unsigned* sticky, const float* status) {
+    const unsigned mine = sticky ? __hip_atomic_load(sticky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+    const bool remote = status && *status != 0.f;
+    if (mine || remote) {          // this step's gradients are garbage somewhere: leave parameters, moments and step alone
+        st->skip = 1u;
+        if (remote && sticky && !(mine & SS_STICKY_ABORT)) __hip_atomic_fetch_or(sticky, SS_STICKY_REMOTE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    st->skip = 0u;
     st->step += 1;
     const double t = (double)st->step;
     const double bc1 = 1.0 - pow(st->beta1, t);
@@ -449,6 +472,7 @@ __global__ void adam_prepare_kernel(AdamState* st) {
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n4,
                                                    const AdamState* __restrict__ st, float gscale) {
+    if (st->skip) return;
     const float step_size = st->step_size, bc2s = st->bc2_sqrt, b1 = st->f_beta1, b2 = st->f_beta2, eps = st->f_eps;
     const float w1 = (float)(1.0 - st->beta1), w2 = (float)(1.0 - st->beta2);
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -482,11 +506,13 @@ hipError_t gn_relu_fwd(const float* x, long x_ld, long x_bs, float* y, long y_ld
 }
 
 hipError_t gn_relu_bwd(const float* x, long x_ld, long x_bs, float* dy, long dy_ld, long dy_bs, const float* gamma,
-                       const float* beta, const float* stats, float* g_gamma, float* g_beta, float* g_bias, float* amax, int B,
-                       int T, int C, hipStream_t s) {
+                       const float* beta, const float* stats, float* g_gamma, float* g_beta, float* g_bias, float* amax, float* part,
+                       int B, int T, int C, hipStream_t s) {
     if (C % 64 != 0 || T > 16 * GN_MAXIT) return hipErrorInvalidValue;
+    if (!g_deterministic) part = nullptr;
     hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(C / 64, B), dim3(256), 0, s, x, x_ld, x_bs, dy, dy_ld, dy_bs, gamma, beta,
-                       stats, g_gamma, g_beta, g_bias, reinterpret_cast<unsigned*>(amax), B, T, C);
+                       stats, g_gamma, g_beta, g_bias, reinterpret_cast<unsigned*>(amax), part, B, T, C);
+    if (part) hipLaunchKernelGGL(gn_part_reduce_kernel, dim3(cdiv(3 * C, 256)), dim3(256), 0, s, part, B, C, g_gamma, g_beta, g_bias);
     return hipGetLastError();
 }
 
@@ -500,7 +526,7 @@ hipError_t gn_relu_mask(const float* x, long x_ld, long x_bs, const float* gamma
 
 hipError_t colsum_acc(const float* in, long ld, int R, int C, float* out, hipStream_t s) {
     const int cblocks = cdiv(C, 64);
-    int chunks = cdiv(1024, cblocks);
+    int chunks = g_deterministic ? 1 : cdiv(1024, cblocks);      // several chunks per column meet through atomics
     if (chunks > cdiv(R, 16)) chunks = cdiv(R, 16);
     if (chunks < 1) chunks = 1;
     const int rpc = cdiv(R, chunks);
@@ -593,9 +619,39 @@ hipError_t ce_loss(const float* logits, long o_ld, long o_bs, const int* tgt, fl
     return hipGetLastError();
 }
 
-hipError_t adam_step(float* p, const float* g, float* m, float* v, long n, AdamState* st, float grad_scale, hipStream_t s) {
+namespace {
+
+__global__ void status_publish_kernel(const unsigned* sticky, float* status) {
+    *status = __hip_atomic_load(sticky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) ? 1.f : 0.f;
+}
+
+__global__ __launch_bounds__(256) void param_guard_kernel(const float* __restrict__ p, long n4, float limit, unsigned* sticky) {
+    bool bad = false;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(p)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bad |= !(fabsf(v[j]) < limit);       // also true for NaN
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) __hip_atomic_fetch_or(sticky, SS_STICKY_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+}  // namespace
+
+hipError_t status_publish(const unsigned* sticky, float* status, hipStream_t s) {
+    hipLaunchKernelGGL(status_publish_kernel, dim3(1), dim3(1), 0, s, sticky, status);
+    return hipGetLastError();
+}
+
+hipError_t param_guard(const float* p, long n, float limit, unsigned* sticky, hipStream_t s) {
     if (n % 4 != 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, s, st);
+    hipLaunchKernelGGL(param_guard_kernel, dim3(512), dim3(256), 0, s, p, n / 4, limit, sticky);
+    return hipGetLastError();
+}
+
+hipError_t adam_step(float* p, const float* g, float* m, float* v, long n, AdamState* st, float grad_scale, unsigned* sticky,
+                     const float* status, hipStream_t s) {
+    if (n % 4 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, s, st, sticky, status);
     long blocks = (n / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, s, p, g, m, v, n / 4, st, grad_scale);

@@ -18,8 +18,8 @@
 using namespace ss;
 
 namespace ss {
-extern int g_small_lds, g_gemm_tr;
-extern int g_lstm_nw, g_lstm_g, g_lstm_mode, g_gemm_bk, g_gemm_want, g_gemm_diag, g_seq_prio, g_gemm_mode;
+extern int g_small_lds, g_gemm_tr, g_deterministic;
+extern int g_lstm_nw, g_lstm_g, g_lstm_mode, g_gemm_bk, g_gemm_want, g_gemm_diag, g_seq_prio, g_gemm_mode, g_seq_spin_log2;
 int g_fwd_f16x2 = 1;   // 1: forward contractions (operands bounded by construction: mel, one-hot, GroupNorm/ReLU outputs, |h| < 1, weights)
                        //    use the fp16 x 2 split (3 MFMAs) instead of bf16 x 3 (6 MFMAs); gradients keep bf16 x 3 (their range is not bounded)
 int g_bwd_f16x2 = 1;   // 1: the decoder's and the conv trunk's gradient GEMMs also use fp16 x 2: the gradient operand is scaled by the power
@@ -35,6 +35,12 @@ int g_split = 0;       // 1: decoder recurrences run as two batch-half chains on
                        //    machine while the other half sits in its latency-bound time loop)
 int g_graph = 0;       // 1: the fused training step is captured into a hipGraph and replayed (measured: no gain while the
                        // step is GPU-bound at batch 64; useful when the host is the bottleneck)
+int g_own_streams = 0; // 1: every C-ABI call runs on the ENGINE's own main stream (created back to back with its three branch streams at
+                       //    ss_bind), ordered behind the caller's stream on entry and in front of it on exit.  Built to make the step time
+                       //    independent of how many streams the process created earlier -- it does not: HIP hands a new stream the
+                       //    least-loaded of its 4 hardware queues, and which engine stream ends up sharing a queue with the caller's still
+                       //    moves the step by 5 % either way (profiles/r02/stream_order_effect.txt: 6.70 - 7.13 ms owned, 6.69 - 7.38 not).
+                       //    Off by default until the engine can measure and pick its queue placement.
 int g_tune_epoch = 0;  // bumped by ss_tune: captured graphs bake the knobs in, so they are dropped when it changes
 }
 
@@ -67,7 +73,7 @@ struct ParamInfo {
 struct ConvBlk {
     int Ci = 0, Co = 0, Cp = 0;
     long w = 0, b = 0, ga = 0, be = 0;     // arena offsets
-    float *wf = nullptr, *wb = nullptr, *gp = nullptr, *cout = nullptr, *stats = nullptr;
+    float *wf = nullptr, *wb = nullptr, *gp = nullptr, *cout = nullptr, *stats = nullptr, *part = nullptr;
     int amax_i = -1;                       // slot in ss_engine::amax
     bool need_dx = false;
 };
@@ -114,7 +120,11 @@ struct ss_engine {
     int maxB, maxT;
     int precision = SS_PRECISION_F32;
     std::vector<ParamInfo> params;
-    long arena = 0;
+    long arena = 0;                        // floats per arena, INCLUDING the 4-float status slot at the end
+    long status_off = 0;                   // gradient arena: G[status_off] = 1 when this rank's step is invalid; the data-parallel
+                                           // all-reduce sums it, so every rank's Adam kernel sees a non-zero value and skips
+    unsigned* sticky = nullptr;            // engine status word in host-coherent pinned memory (kernels.h SS_STICKY_*): written by
+                                           // kernels, read by the host without synchronising; cleared only by ss_clear_abort
 
     float *P = nullptr, *G = nullptr, *Mm = nullptr, *Vv = nullptr;
     char* ws = nullptr;
@@ -148,6 +158,7 @@ struct ss_engine {
     std::map<std::string, std::pair<float*, long>> dbg;   // name -> (ptr, cols)
     // weight-gradient GEMMs of a BLSTM layer run on this side stream while the next layer's recurrence (latency-bound,
     // one launch per time step) proceeds on the caller's stream
+    hipStream_t main_s = nullptr;         // the stream the step's dependency chain runs on (see g_own_streams)
     hipStream_t side = nullptr;
     hipStream_t side2 = nullptr;          // independent branches (per-step weight re-layouts, Encoder_t, second encoder BLSTM); second batch-half chain
     hipStream_t side3 = nullptr;          // third independent branch of the encoder backward (Encoder_t)
@@ -172,10 +183,15 @@ struct ss_engine {
     bool side_used = false;
     // ss_profile: hipEvent pairs around the launches of the dominant kernel (decoder input-projection GEMM, layers >= 1)
     // on the stream they are launched on, so a benchmark can report that kernel's duration inside its own timed region
-    static constexpr int PROF_CAP = 256;
-    std::vector<hipEvent_t> prof_ev;
+    static constexpr int PROF_CAP = 8192;
+    struct ProfRec {
+        int klass;
+        double flops;
+    };
+    std::vector<hipEvent_t> prof_ev;      // 2 per record, created on demand
+    std::vector<ProfRec> prof_rec;
     int prof_n = 0;
-    bool prof_on = false;
+    unsigned prof_mask = 0;               // bit k set: launches of class k are bracketed
 
     long carve(int B, int T, bool assign);
 };
@@ -265,7 +281,8 @@ void build_table(ss_engine* e) {
         e->CE = h.dim_enc_3;
     }
     e->ld.amax0 = 0;                      // decoder layers: slots 0..2 of ss_engine::amax (the convs follow from 3)
-    e->arena = align4(tb.off);
+    e->status_off = align4(tb.off);
+    e->arena = e->status_off + 4;
     e->f0p = (int)align4(h.dim_f0);
     for (int i = 0; i < 3; ++i) {
         e->c1[i].need_dx = i > 0;
@@ -298,6 +315,7 @@ long ss_engine::carve(int B, int T, bool assign) {
         cb.wb = cb.need_dx ? (float*)take((long)cb.Ci * 5 * cb.Co * 4) : nullptr;
         cb.cout = slab((name + ".conv").c_str(), cb.Co);
         cb.stats = (float*)take((long)B * (cb.Co / 16) * 2 * 4);
+        cb.part = (float*)take((long)B * 3 * cb.Co * 4);          // deterministic mode: per-utterance affine / bias gradient sums
     };
     auto lstm_ws = [&](LstmBlk& lb, const std::string& name) {
         if (lb.L == 0) return;
@@ -485,6 +503,72 @@ int fork_join(ss_engine* e, hipStream_t from, hipStream_t to) {
     return 0;
 }
 
+// Host-side view of the engine status word: no synchronisation, so it reports what earlier steps left behind.
+int sticky_check(ss_engine* e) {
+    if (!e->sticky) return 0;
+    const unsigned v = *(volatile unsigned*)e->sticky;
+    if (!v) return 0;
+    if (v & SS_STICKY_RANGE)
+        return fail("a parameter is not finite or left the range (|p| < 64) the fixed-scale fp16 x 2 forward products are valid for: the step was "
+                    "not applied.  Use ss_tune(\"fwd_f16x2\", 0) and ss_tune(\"bwd_f16x2\", 0) (bf16 x 3 products, no range limit), then ss_clear_abort()");
+    return fail(v & SS_STICKY_ABORT ? "a persistent LSTM kernel gave up waiting for its group (bounded spin expired) in an earlier step: that step's "
+                                      "results were discarded and the parameters left untouched; ss_clear_abort() to continue"
+                                    : "another data-parallel rank reported an aborted step: the update was skipped on every rank; ss_clear_abort() to continue");
+}
+
+// Scope of one C-ABI call: work goes to the engine's main stream, which first waits for everything the caller's stream holds;
+// on exit the caller's stream waits for the call's work, so the stream-ordered contract of the ABI is unchanged.
+struct Own {
+    ss_engine* e;
+    hipStream_t caller, s;
+    bool on = false;
+    Own(ss_engine* e_, void* stream) : e(e_), caller((hipStream_t)stream), s((hipStream_t)stream) {
+        if (e && e->main_s && g_own_streams && caller != e->main_s &&
+            hipEventRecord(e->ev_io[0], caller) == hipSuccess && hipStreamWaitEvent(e->main_s, e->ev_io[0], 0) == hipSuccess) {
+            s = e->main_s;
+            on = true;
+        }
+    }
+    ~Own() {
+        if (on && hipEventRecord(e->ev_io[1], s) == hipSuccess) (void)hipStreamWaitEvent(caller, e->ev_io[1], 0);
+    }
+    Own(const Own&) = delete;
+    Own& operator=(const Own&) = delete;
+};
+
+// ss_profile: bracket one launch with hipEvents on the stream it is launched on
+int prof_begin(ss_engine* e, int klass, hipStream_t st, double flops) {
+    if (!((e->prof_mask >> klass) & 1u) || g_graph || e->prof_n >= ss_engine::PROF_CAP) return -1;
+    const int i = e->prof_n;
+    while ((int)e->prof_ev.size() < 2 * (i + 1)) {
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) return -1;
+        e->prof_ev.push_back(ev);
+    }
+    if ((int)e->prof_rec.size() <= i) e->prof_rec.resize(i + 1);
+    e->prof_rec[i] = {klass, flops};
+    if (hipEventRecord(e->prof_ev[2 * i], st) != hipSuccess) return -1;
+    e->prof_n = i + 1;
+    return i;
+}
+void prof_end(ss_engine* e, int i, hipStream_t st) {
+    if (i >= 0) (void)hipEventRecord(e->prof_ev[2 * i + 1], st);
+}
+double gemm_flops(const GemmDesc& d) { return 2.0 * d.M * d.N * (double)d.K * (d.batch > 0 ? d.batch : 1); }
+// GEMM launch bracketed as profile class `k`
+#define PGEMM_ON(k, d, st)                                   \
+    do {                                                     \
+        const int _pi = prof_begin(e, k, st, gemm_flops(d)); \
+        GEMM_ON(d, st);                                      \
+        prof_end(e, _pi, st);                                \
+    } while (0)
+#define PGEMM_FWD_ON(k, d, st)                               \
+    do {                                                     \
+        const int _pi = prof_begin(e, k, st, gemm_flops(d)); \
+        GEMM_FWD_ON(d, st);                                  \
+        prof_end(e, _pi, st);                                \
+    } while (0)
+
 // ---- convolution block -------------------------------------------------------------------------------------
 int conv_pack_all(ss_engine* e, ConvBlk& cb, hipStream_t s) {
     HIPCHK(conv_pack(e->P + cb.w, cb.Co, cb.Ci, cb.Cp, cb.wf, cb.wb, s));
@@ -513,7 +597,7 @@ int conv_block_fwd(ss_engine* e, ConvBlk& cb, Slab x, Slab y, hipStream_t s) {
     d.batch = B;
     d.ksplit = 1;
     d.want = g_conv_want;
-    GEMM_FWD_ON(d, s);
+    PGEMM_FWD_ON(SS_PROF_CONV_FWD, d, s);
     HIPCHK(gn_relu_fwd(cb.cout, cb.Co, TP * cb.Co, y.p, y.ld, TP * y.ld, e->P + cb.ga, e->P + cb.be, cb.stats, B, T, cb.Co, s));
     return 0;
 }
@@ -525,7 +609,7 @@ int conv_block_bwd(ss_engine* e, ConvBlk& cb, Slab dy, Slab x, Slab dx, hipStrea
     const long TP = T + 2 * HALO, R = (long)B * TP;
     float* am = (g_bwd_f16x2 && cb.amax_i >= 0) ? e->amax + cb.amax_i : nullptr;
     HIPCHK(gn_relu_bwd(cb.cout, cb.Co, TP * cb.Co, dy.p, dy.ld, TP * dy.ld, e->P + cb.ga, e->P + cb.be, cb.stats,
-                       e->G + cb.ga, e->G + cb.be, e->G + cb.b, am, B, T, cb.Co, s));
+                       e->G + cb.ga, e->G + cb.be, e->G + cb.b, am, cb.part, B, T, cb.Co, s));
     // weight gradient: one reduction over every slab row (halo rows of dy are zero); cb.gp was zeroed by zero_conv_grads
     GemmDesc d{};
     d.A = {dy.p + 2 * dy.ld, dy.ld, 0, 0, 0};
@@ -539,7 +623,7 @@ int conv_block_bwd(ss_engine* e, ConvBlk& cb, Slab dy, Slab x, Slab dx, hipStrea
     d.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM | (am ? GEMM_F16X2 : 0);
     d.amax_a = am;                                  // gradient operand: measured scale; the block input is O(1)
     d.ksplit = pick_ksplit(d.M, d.N, d.K);
-    GEMM(d);
+    PGEMM_ON(SS_PROF_CONV_DW, d, s);
     HIPCHK(conv_unpack_grad(cb.gp, cb.Co, cb.Ci, cb.Cp, e->G + cb.w, s));
     if (dx.p) {
         GemmDesc g{};
@@ -556,7 +640,7 @@ int conv_block_bwd(ss_engine* e, ConvBlk& cb, Slab dy, Slab x, Slab dx, hipStrea
         g.flags = am ? GEMM_F16X2 : 0;
         g.amax_a = am;
         g.want = g_conv_want;
-        GEMM(g);
+        PGEMM_ON(SS_PROF_CONV_DX, g, s);
     }
     return 0;
 }
@@ -626,10 +710,7 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
                 d.K = In;
                 d.batch = ch[c].nb;
                 d.ksplit = 1;
-                const bool timed = e->prof_on && !g_graph && l > 0 && nch == 1 && e->prof_n < ss_engine::PROF_CAP;
-                if (timed) HIPCHK(hipEventRecord(e->prof_ev[2 * e->prof_n], ch[c].st));
-                GEMM_FWD_ON(d, ch[c].st);
-                if (timed) HIPCHK(hipEventRecord(e->prof_ev[2 * e->prof_n++ + 1], ch[c].st));
+                PGEMM_FWD_ON(l > 0 ? SS_PROF_DEC_PROJ : SS_PROF_DEC_PROJ0, d, ch[c].st);
             }
             if (!persist) {
                 const long half = 2L * (((ch[c].nb + 15) / 16) * 16) * H;
@@ -637,8 +718,10 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
             }
         }
         if (persist) {   // start state zeroed by lstm_prep
+            const int pi = prof_begin(e, SS_PROF_REC_FWD, s, 2.0 * 2 * B * T * 4.0 * H * H);
             HIPCHK(lstm_seq_fwd(lb.gates[l], e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.hf_l(l), lb.out[l], lb.csave[l],
-                                lb.sync_f(l), B, T, H, false, s));
+                                lb.sync_f(l), e->sticky, B, T, H, false, s));
+            prof_end(e, pi, s);
             continue;
         }
         for (int st = 0; st < T; ++st)
@@ -674,7 +757,7 @@ int lstm_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
             d.K = In;
             d.batch = B;
             d.ksplit = 1;
-            GEMM_FWD_ON(d, s);
+            PGEMM_FWD_ON(SS_PROF_ENC_LSTM, d, s);
         }
         HIPCHK(lstm_small_fwd(lb.gates[l], e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.out[l], lb.csave[l], B, T, H,
                               s));
@@ -705,7 +788,7 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
         a.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM | (am ? GEMM_F16X2 : 0);
         a.amax_a = am;                              // gradient slab: measured scale; the layer input is O(1)
         a.ksplit = pick_ksplit(a.M, a.N, a.K);
-        GEMM_ON(a, ws);
+        PGEMM_ON(lb.big() ? SS_PROF_DEC_DW : SS_PROF_ENC_LSTM, a, ws);
         // dW_hh[n][k] = sum_r dG[r][n] * h_prev[r][k];  h_prev = out one row earlier (fwd) / later (reverse)
         GemmDesc h{};
         h.A = {dir == 0 ? dGd + 8L * H : dGd, 8L * H, 0, 0, 0};
@@ -719,7 +802,7 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
         h.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM | (am ? GEMM_F16X2 : 0);
         h.amax_a = am;
         h.ksplit = pick_ksplit(h.M, h.N, h.K);
-        GEMM_ON(h, ws);
+        PGEMM_ON(lb.big() ? SS_PROF_DEC_DW : SS_PROF_ENC_LSTM, h, ws);
         if (!bias_done) {     // the persistent backward kernel accumulates both bias gradients itself
             HIPCHK(colsum_acc(dGd, 8L * H, (int)R, 4 * H, e->G + pd.bih, ws));
             HIPCHK(hipMemcpyAsync(e->G + pd.bhh, e->G + pd.bih, 4L * H * 4, hipMemcpyDeviceToDevice, ws));
@@ -761,7 +844,7 @@ int lstm_input_grad(ss_engine* e, LstmBlk& lb, int l, Slab dxi, long r0, long nr
         g.batch = (int)(nr / TPr);
         g.want = g_dx_batched == 2 ? 512 : 0;
     }
-    GEMM_ON(g, st);
+    PGEMM_ON(lb.big() ? SS_PROF_DEC_DX : SS_PROF_ENC_LSTM, g, st);
     return 0;
 }
 
@@ -783,7 +866,7 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
         // fp16 x 2 gradient GEMMs need the slab's maximum, which only the persistent kernel measures
         float* am = (persist && g_bwd_f16x2 && lb.amax0 >= 0) ? e->amax + lb.amax0 + l : nullptr;
         // b_ih and b_hh gradients sit back to back in the arena (registration order): the persistent kernel fills both
-        const bool bias_in_kernel = persist && lb.pd[l * 2].bhh == lb.pd[l * 2].bih + 4L * H &&
+        const bool bias_in_kernel = persist && !g_deterministic && lb.pd[l * 2].bhh == lb.pd[l * 2].bih + 4L * H &&
                                     lb.pd[l * 2 + 1].bhh == lb.pd[l * 2 + 1].bih + 4L * H;
         if (lb.big()) {
             for (int c = 0; c < nch && !persist; ++c) {
@@ -791,10 +874,13 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
                 HIPCHK(hipMemsetAsync(lb.gf[c], 0, 2 * half * 4, ch[c].st));
             }
             // persistent: start state zeroed by backward_decoder
-            if (persist)
+            if (persist) {
+                const int pi = prof_begin(e, SS_PROF_REC_BWD, s, 2.0 * 2 * B * T * 4.0 * H * H);
                 HIPCHK(lstm_seq_bwd(dG, e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.px, dcur, lb.csave[l], lb.sync_b(l),
-                                    am, bias_in_kernel ? e->G + lb.pd[l * 2].bih : nullptr,
+                                    e->sticky, am, bias_in_kernel ? e->G + lb.pd[l * 2].bih : nullptr,
                                     bias_in_kernel ? e->G + lb.pd[l * 2 + 1].bih : nullptr, B, T, H, false, s));
+                prof_end(e, pi, s);
+            }
             for (int st = 0; st < T && !persist; ++st)
                 for (int c = 0; c < nch; ++c) {
                     const long r0 = (long)ch[c].b0 * TP;
@@ -841,7 +927,7 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
         for (int l = lb.L - 1; l >= 0; --l) {
             Slab xi = l == 0 ? x : Slab{lb.out[l - 1], 2L * H};
             float* am = (g_bwd_f16x2 && lb.amax0 >= 0) ? e->amax + lb.amax0 + l : nullptr;
-            const bool bias_in_kernel = lb.pd[l * 2].bhh == lb.pd[l * 2].bih + 4L * H && lb.pd[l * 2 + 1].bhh == lb.pd[l * 2 + 1].bih + 4L * H;
+            const bool bias_in_kernel = !g_deterministic && lb.pd[l * 2].bhh == lb.pd[l * 2].bih + 4L * H && lb.pd[l * 2 + 1].bhh == lb.pd[l * 2 + 1].bih + 4L * H;
             CHK(lstm_weight_grads(e, lb, l, xi, am, bias_in_kernel, e->side));
         }
     }
@@ -898,6 +984,10 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
             CHK(lstm_prep(e, e->lt, tb, b2));
             CHK(lstm_prep(e, e->ld, tb, b2));
             HIPCHK(prep_run(tb, b2));
+            // fp16 x 2 products scale weights and activations by a FIXED 16 (forward and gradient contractions alike), valid while every parameter (weights, GroupNorm affine) stays
+            // below 64 in magnitude: weights < 4094 / 16, and |GroupNorm output| <= 64 * sqrt(16 T) + 64 < 4094.  Outside that
+            // range (or for a non-finite parameter) the step is marked invalid instead of silently overflowing to inf.
+            if ((g_fwd_f16x2 || g_bwd_f16x2) && e->precision == SS_PRECISION_F32 && e->sticky) HIPCHK(param_guard(e->P, e->arena, 64.0f, e->sticky, b2));
             // Encoder_t (model.py:74-89)
             CHK(conv_block_fwd(e, e->ct, Slab{e->org, e->hp.dim_freq}, Slab{e->act_t, e->hp.dim_enc_2}, b2));
             CHK(lstm_fwd(e, e->lt, Slab{e->act_t, e->hp.dim_enc_2}, b2));
@@ -953,7 +1043,7 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
     d.K = (int)HD;
     d.batch = B;
     d.ksplit = 1;
-    GEMM_FWD_ON(d, s);
+    PGEMM_FWD_ON(SS_PROF_HEAD, d, s);
     e->fwd_training = training;
     e->enc_plan0 = draw0;
     e->have_fwd = true;
@@ -994,7 +1084,7 @@ int backward_decoder(ss_engine* e, hipStream_t s) {
         a.batch = 1;
         a.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM;
         a.ksplit = pick_ksplit(a.M, a.N, a.K);
-        GEMM(a);
+        PGEMM_ON(SS_PROF_HEAD, a, s);
         HIPCHK(colsum_acc(e->d_out_slab, e->head_out, (int)R, e->head_out, e->G + e->head_b, s));
         GemmDesc g{};
         g.A = {e->d_out_slab, e->head_out, 0, 0, 0};
@@ -1007,10 +1097,13 @@ int backward_decoder(ss_engine* e, hipStream_t s) {
         g.batch = 1;
         g.flags = GEMM_TB;
         g.ksplit = 1;
-        GEMM(g);
+        PGEMM_ON(SS_PROF_HEAD, g, s);
     }
     if (par) CHK(fork_join(e, b2, s));
     CHK(lstm_bwd(e, e->ld, e->d_top, Slab{e->dec_in, e->dec_in_dim}, Slab{e->d_dec_in, e->dec_in_dim}, s));
+    // every persistent recurrence of the step is behind this point: publish this rank's status into the gradient arena's
+    // status slot (part of the decoder bucket, so a data-parallel all-reduce carries it to every rank's Adam kernel)
+    if (e->sticky) HIPCHK(status_publish(e->sticky, e->G + e->status_off, s));
     return 0;
 }
 
@@ -1153,6 +1246,10 @@ ss_engine* ss_create(int kind, const ss_hparams* hp, int max_batch, int max_fram
 void ss_destroy(ss_engine* e) {
     if (!e) return;
     drop_graphs(e);
+    if (e->sticky) {
+        (void)hipDeviceSynchronize();
+        (void)hipHostFree(e->sticky);
+    }
     for (auto& ev : e->prof_ev)
         if (ev) (void)hipEventDestroy(ev);
     if (e->side) {
@@ -1165,6 +1262,10 @@ void ss_destroy(ss_engine* e) {
                 (void)hipStreamSynchronize(st);
                 (void)hipStreamDestroy(st);
             }
+        if (e->main_s) {
+            (void)hipStreamSynchronize(e->main_s);
+            (void)hipStreamDestroy(e->main_s);
+        }
         if (e->cap) {
             (void)hipStreamSynchronize(e->cap);
             for (auto& ev : e->ev_io)
@@ -1216,8 +1317,17 @@ int ss_bind(ss_engine* e, float* params, float* grads, float* m, float* v, void*
     e->have_fwd = false;
     HIPCHK(hipMemsetAsync(e->ws, 0, ws_bytes, S(stream)));
     e->carve(e->maxB, e->maxT, true);
+    if (!e->sticky) {       // host-coherent pinned word: kernels OR into it (system scope), the host reads it without a sync
+        void* p = nullptr;
+        HIPCHK(hipHostMalloc(&p, 64, hipHostMallocDefault));
+        std::memset(p, 0, 64);
+        e->sticky = (unsigned*)p;
+    }
     if (!e->side && e->kind != SS_INTERP_ONLY) {
-        {   // filler work (weight-gradient GEMMs) yields to the latency-critical recurrence on the caller's stream
+        // main + three branch streams, created back to back: HIP deals a process's streams onto its hardware queues in creation
+        // order, so these four get one queue each no matter how many streams (PyTorch's, RCCL's) existed before
+        HIPCHK(hipStreamCreateWithFlags(&e->main_s, hipStreamNonBlocking));
+        {
             int least = 0, greatest = 0;
             HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
             HIPCHK(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, g_side_prio ? least : 0));
@@ -1253,22 +1363,33 @@ int ss_set_adam(ss_engine* e, double lr, double b1, double b2, double eps, long 
     return 0;
 }
 
-int ss_adam_step(ss_engine* e, float grad_scale, void* stream) {
+// enqueue only: the host-side status check belongs to the ABI entry points, never to the middle of a step being enqueued
+// (the device-side guard in adam_prepare_kernel is what protects the parameters)
+static int adam_enqueue(ss_engine* e, float grad_scale, hipStream_t s) {
     if (!e->ws || !e->Mm || !e->Vv) return fail("ss_adam_step: Adam arenas are not bound");
-    HIPCHK(adam_step(e->P, e->G, e->Mm, e->Vv, e->arena, e->adam, grad_scale, S(stream)));
+    HIPCHK(adam_step(e->P, e->G, e->Mm, e->Vv, e->arena, e->adam, grad_scale, e->sticky, e->G + e->status_off, s));
     return 0;
+}
+
+int ss_adam_step(ss_engine* e, float grad_scale, void* stream) {
+    CHK(sticky_check(e));
+    Own own(e, stream);
+    return adam_enqueue(e, grad_scale, own.s);
 }
 
 int ss_zero_grads(ss_engine* e, void* stream) {
     if (!e->G) return fail("engine is not bound");
-    HIPCHK(hipMemsetAsync(e->G, 0, e->arena * 4, S(stream)));
+    Own own(e, stream);
+    HIPCHK(hipMemsetAsync(e->G, 0, e->arena * 4, own.s));
     return 0;
 }
 
 int ss_g3_forward(ss_engine* e, const float* x_f0, const float* x_org, const float* c_trg, const float* scales,
                   const int* len_seg, int B, int T, int training, float* out, void* stream) {
     if (e->kind != SS_GENERATOR_3) return fail("ss_g3_forward on a Generator_6 engine");
-    hipStream_t s = S(stream);
+    CHK(sticky_check(e));
+    Own own(e, stream);
+    hipStream_t s = own.s;
     if (training && T != e->hp.max_len_pad)
         return fail("train-mode forward needs T == max_len_pad (InterpLnr pads to max_len_pad, model.py:370)");
     if (training && (!scales || !len_seg)) return fail("train-mode forward needs the InterpLnr draws");
@@ -1281,7 +1402,8 @@ int ss_g3_forward(ss_engine* e, const float* x_f0, const float* x_org, const flo
 
 int ss_g3_backward(ss_engine* e, const float* d_out, void* stream) {
     if (e->kind != SS_GENERATOR_3) return fail("ss_g3_backward on a Generator_6 engine");
-    hipStream_t s = S(stream);
+    Own own(e, stream);
+    hipStream_t s = own.s;
     if (!e->have_fwd) return fail("backward without a preceding forward");
     CHK(import_dout(e, d_out, e->curB, e->curT, s));
     return backward_core(e, s);
@@ -1289,7 +1411,8 @@ int ss_g3_backward(ss_engine* e, const float* d_out, void* stream) {
 
 int ss_g3_rhythm(ss_engine* e, const float* x_org, int B, int T, float* codes, void* stream) {
     if (e->kind != SS_GENERATOR_3) return fail("ss_g3_rhythm on a Generator_6 engine");
-    hipStream_t s = S(stream);
+    Own own(e, stream);
+    hipStream_t s = own.s;
     CHK(geometry(e, B, T, s));
     const ss_hparams& h = e->hp;
     const long TP = T + 2 * HALO;
@@ -1314,7 +1437,9 @@ int ss_g3_rhythm(ss_engine* e, const float* x_org, int B, int T, float* codes, v
 int ss_g6_forward(ss_engine* e, const float* x_org, const float* f0_trg, const float* scales, const int* len_seg, int B,
                   int T, int training, float* out, void* stream) {
     if (e->kind != SS_GENERATOR_6) return fail("ss_g6_forward on a Generator_3 engine");
-    hipStream_t s = S(stream);
+    CHK(sticky_check(e));
+    Own own(e, stream);
+    hipStream_t s = own.s;
     if (training && T != e->hp.max_len_pad) return fail("train-mode forward needs T == max_len_pad (model.py:370)");
     if (training && (!scales || !len_seg)) return fail("train-mode forward needs the InterpLnr draws");
     CHK(geometry(e, B, T, s));
@@ -1330,7 +1455,8 @@ int ss_g6_forward(ss_engine* e, const float* x_org, const float* f0_trg, const f
 
 int ss_g6_backward(ss_engine* e, const float* d_out, void* stream) {
     if (e->kind != SS_GENERATOR_6) return fail("ss_g6_backward on a Generator_3 engine");
-    hipStream_t s = S(stream);
+    Own own(e, stream);
+    hipStream_t s = own.s;
     if (!e->have_fwd) return fail("backward without a preceding forward");
     CHK(import_dout(e, d_out, e->curB, e->curT, s));
     return backward_core(e, s);
@@ -1366,7 +1492,7 @@ static int g3_step_body(ss_engine* e, const float* mel, const float* f0, const f
         return 0;
     }
     CHK(backward_core(e, s));                                                               // solver.py:170-171
-    if (!(flags & SS_STEP_NO_ADAM)) CHK(ss_adam_step(e, grad_scale, (void*)s));             // solver.py:172
+    if (!(flags & SS_STEP_NO_ADAM)) CHK(adam_enqueue(e, grad_scale, s));                    // solver.py:172
     return 0;
 }
 
@@ -1374,7 +1500,9 @@ int ss_g3_train_step(ss_engine* e, const float* mel, const float* f0, const floa
                      const float* scales, const int* len_seg, int B, int T, float grad_scale, int flags, float* loss,
                      void* stream) {
     if (e->kind != SS_GENERATOR_3) return fail("ss_g3_train_step on a Generator_6 engine");
-    hipStream_t s = S(stream);
+    CHK(sticky_check(e));
+    Own own(e, stream);
+    hipStream_t s = own.s;
     const ss_hparams& h = e->hp;
     if (T != h.max_len_pad) return fail("training needs T == max_len_pad (model.py:105,157,370)");
     CHK(geometry(e, B, T, s));
@@ -1386,9 +1514,11 @@ int ss_g3_train_step(ss_engine* e, const float* mel, const float* f0, const floa
 
     // stage the caller's inputs, then replay (or first capture) the step on engine-owned addresses.  All of it runs on
     // the engine's capture stream, ordered after the caller's stream and before whatever the caller enqueues next.
-    hipStream_t c = e->cap;
-    HIPCHK(hipEventRecord(e->ev_io[0], s));
-    HIPCHK(hipStreamWaitEvent(c, e->ev_io[0], 0));
+    hipStream_t c = own.on ? s : e->cap;                  // a created stream (a legacy default stream cannot capture)
+    if (!own.on) {
+        HIPCHK(hipEventRecord(e->ev_io[0], s));
+        HIPCHK(hipStreamWaitEvent(c, e->ev_io[0], 0));
+    }
     const long S7 = e->plan[0].S;
     HIPCHK(hipMemcpyAsync(e->stg_mel, mel, (long)B * T * h.dim_freq * 4, hipMemcpyDeviceToDevice, c));
     HIPCHK(hipMemcpyAsync(e->stg_f0, f0, (long)B * T * 4, hipMemcpyDeviceToDevice, c));
@@ -1413,16 +1543,19 @@ int ss_g3_train_step(ss_engine* e, const float* mel, const float* f0, const floa
     }
     HIPCHK(hipGraphLaunch(sg->x, c));
     if (loss) HIPCHK(hipMemcpyAsync(loss, e->stg_loss, 4, hipMemcpyDeviceToDevice, c));
-    HIPCHK(hipEventRecord(e->ev_io[1], c));
-    HIPCHK(hipStreamWaitEvent(s, e->ev_io[1], 0));
+    if (!own.on) {
+        HIPCHK(hipEventRecord(e->ev_io[1], c));
+        HIPCHK(hipStreamWaitEvent(s, e->ev_io[1], 0));
+    }
     return 0;
 }
 
 int ss_train_finish(ss_engine* e, float grad_scale, int flags, void* stream) {
-    hipStream_t s = S(stream);
+    Own own(e, stream);
+    hipStream_t s = own.s;
     if (!e->have_fwd) return fail("ss_train_finish without a preceding ss_*_train_step(SS_STEP_SPLIT_BACKWARD)");
     CHK(backward_encoder(e, s));
-    if (!(flags & SS_STEP_NO_ADAM)) CHK(ss_adam_step(e, grad_scale, stream));
+    if (!(flags & SS_STEP_NO_ADAM)) CHK(adam_enqueue(e, grad_scale, s));
     return 0;
 }
 
@@ -1446,14 +1579,15 @@ long ss_grad_split(const ss_engine* e) {
 int ss_g6_train_step(ss_engine* e, const float* mel, const float* f0_onehot, const int* target_idx, const float* scales,
                      const int* len_seg, int B, int T, float grad_scale, int flags, float* loss, void* stream) {
     if (e->kind != SS_GENERATOR_6) return fail("ss_g6_train_step on a Generator_3 engine");
-    hipStream_t s = S(stream);
-    CHK(ss_g6_forward(e, mel, f0_onehot, scales, len_seg, B, T, 1, nullptr, stream));
+    Own own(e, stream);
+    hipStream_t s = own.s;
+    CHK(ss_g6_forward(e, mel, f0_onehot, scales, len_seg, B, T, 1, nullptr, (void*)s));
     const long TP = T + 2 * HALO;
     const int C = e->head_out;
     HIPCHK(ce_loss(e->out_slab + HALO * C, C, TP * C, target_idx, e->d_out_slab + HALO * C, C, TP * C, B, T, C, 1.0f,
                    e->loss_part, loss, s));
     CHK(backward_core(e, s));
-    if (!(flags & SS_STEP_NO_ADAM)) CHK(ss_adam_step(e, grad_scale, stream));
+    if (!(flags & SS_STEP_NO_ADAM)) CHK(adam_enqueue(e, grad_scale, s));
     return 0;
 }
 
@@ -1467,7 +1601,8 @@ int ss_collate(const float* mel_cat, const float* f0_cat, const float* emb_tab, 
 
 int ss_interp_forward(ss_engine* e, const float* x, const int* len_seq, const float* scales, const int* len_seg, int B, int T,
                       int C, float* y, int* i0, float* lam, int* counts, void* stream) {
-    hipStream_t s = S(stream);
+    Own own(e, stream);
+    hipStream_t s = own.s;
     if (!e->ws) return fail("engine is not bound");
     if (B > e->maxB || T > e->maxT) return fail("ss_interp_forward: batch / frames exceed the engine limits");
     if (!e->curB) CHK(geometry(e, e->maxB, e->maxT, s));
@@ -1484,7 +1619,8 @@ int ss_interp_forward(ss_engine* e, const float* x, const int* len_seq, const fl
 }
 
 int ss_interp_backward(ss_engine* e, const float* dy, int B, int T, int C, float* dx, void* stream) {
-    hipStream_t s = S(stream);
+    Own own(e, stream);
+    hipStream_t s = own.s;
     if (!e->ws || !e->curB) return fail("ss_interp_backward without ss_interp_forward");
     InterpPlan pl = e->plan[3];
     pl.T = T;
@@ -1519,28 +1655,30 @@ int ss_set_precision(ss_engine* e, int precision) {
     return 0;
 }
 
-int ss_profile(ss_engine* e, int enable, int* launches, double* total_us, double* flops_per_launch) {
+int ss_profile(ss_engine* e, unsigned class_mask) {
     if (!e) return fail("ss_profile: null engine");
-    if (launches || total_us) {
-        double us = 0;
-        for (int i = 0; i < e->prof_n; ++i) {
-            if (hipEventSynchronize(e->prof_ev[2 * i + 1]) != hipSuccess) return fail("ss_profile: event sync failed");
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, e->prof_ev[2 * i], e->prof_ev[2 * i + 1]) != hipSuccess)
-                return fail("ss_profile: elapsed time failed");
-            us += ms * 1e3;
-        }
-        if (launches) *launches = e->prof_n;
-        if (total_us) *total_us = us;
+    if (class_mask) e->prof_n = 0;
+    e->prof_mask = class_mask;
+    return 0;
+}
+
+int ss_profile_read(ss_engine* e, int klass, int* launches, double* total_us, double* total_flops) {
+    if (!e) return fail("ss_profile_read: null engine");
+    int n = 0;
+    double us = 0, fl = 0;
+    for (int i = 0; i < e->prof_n; ++i) {
+        if (e->prof_rec[i].klass != klass) continue;
+        if (hipEventSynchronize(e->prof_ev[2 * i + 1]) != hipSuccess) return fail("ss_profile_read: event sync failed");
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e->prof_ev[2 * i], e->prof_ev[2 * i + 1]) != hipSuccess)
+            return fail("ss_profile_read: elapsed time failed");
+        us += ms * 1e3;
+        fl += e->prof_rec[i].flops;
+        ++n;
     }
-    if (flops_per_launch) *flops_per_launch = 2.0 * e->curB * e->curT * (8.0 * e->ld.H) * (2.0 * e->ld.H);
-    e->prof_n = 0;
-    if (enable && e->prof_ev.empty()) {
-        e->prof_ev.resize(2 * ss_engine::PROF_CAP);
-        for (auto& ev : e->prof_ev)
-            if (hipEventCreate(&ev) != hipSuccess) return fail("ss_profile: hipEventCreate failed");
-    }
-    e->prof_on = enable != 0;
+    if (launches) *launches = n;
+    if (total_us) *total_us = us;
+    if (total_flops) *total_flops = fl;
     return 0;
 }
 
@@ -1555,7 +1693,14 @@ int ss_tune(const char* key, int value) {
     const std::string k = key ? key : "";
     if (k == "lstm_nw" && (value == 4 || value == 8 || value == 16)) g_lstm_nw = value;
     else if (k == "lstm_g" && value >= 0 && value <= 16) g_lstm_g = value;
+#ifdef SS_DIAG
     else if (k == "lstm_mode" && value >= 0 && value <= 4) g_lstm_mode = value;
+    else if (k == "gemm_diag" && value >= 0 && value < 512) g_gemm_diag = value;
+    else if (k == "seq_prio" && value >= 0 && value < 1024) g_seq_prio = value;
+#else
+    else if (k == "seq_prio" && (value == 0 || value == 1)) g_seq_prio = value;
+#endif
+    else if (k == "seq_spin_log2" && value >= 0 && value <= 24) g_seq_spin_log2 = value;
     else if (k == "overlap" && (value == 0 || value == 1)) g_overlap = value;
     else if (k == "defer_dw" && (value == 0 || value == 1)) g_defer_dw = value;
     else if (k == "dx_batched" && value >= 0 && value <= 2) g_dx_batched = value;
@@ -1563,17 +1708,21 @@ int ss_tune(const char* key, int value) {
     else if (k == "small_lds" && value >= 0 && value <= 2) g_small_lds = value;
     else if (k == "gemm_tr" && value >= 0 && value <= 2) g_gemm_tr = value;
     else if (k == "graph" && (value == 0 || value == 1)) g_graph = value;
+    else if (k == "own_streams" && (value == 0 || value == 1)) g_own_streams = value;
+    else if (k == "deterministic" && (value == 0 || value == 1)) g_deterministic = value;
     else if (k == "split" && (value == 0 || value == 1)) g_split = value;
     else if (k == "persist" && (value == 0 || value == 1)) g_persist = value;
-    else if (k == "seq_prio" && value >= 0 && value < 1024) g_seq_prio = value;
     else if (k == "side_prio" && (value == 0 || value == 1)) g_side_prio = value;
     else if (k == "gemm_bk" && (value == 16 || value == 32)) g_gemm_bk = value;
     else if (k == "gemm_want" && value >= 1) g_gemm_want = value;
     else if (k == "gemm_mode" && (value == 0 || value == 1)) g_gemm_mode = value;
     else if (k == "fwd_f16x2" && (value == 0 || value == 1)) g_fwd_f16x2 = value;
     else if (k == "bwd_f16x2" && (value == 0 || value == 1)) g_bwd_f16x2 = value;
-    else if (k == "gemm_diag" && value >= 0 && value < 512) g_gemm_diag = value;
-    else return fail("ss_tune: unknown key or bad value: " + k);
+    else return fail("ss_tune: unknown key or bad value: " + k
+#ifndef SS_DIAG
+                     + " (the wrong-result timing modes lstm_mode / gemm_diag / seq_prio > 1 exist only in the -DSS_DIAG build: make diag)"
+#endif
+    );
     ++g_tune_epoch;
     return 0;
 }
@@ -1587,7 +1736,7 @@ int ss_op_lstm_fwd(float* gates, const float* whh_f, const float* whh_b, float* 
         float* hf = scratch + wn;
         if (g_persist && lstm_seq_supported(B, H) && wn * 4 >= lstm_seq_xbytes(B, H, false)) {
             // exchange buffer in the (unused) packed-weight area, counters behind it
-            HIPCHK(lstm_seq_fwd(gates, whh_f, whh_b, scratch, out, csave, (unsigned*)hf, B, T, H, true, s));
+            HIPCHK(lstm_seq_fwd(gates, whh_f, whh_b, scratch, out, csave, (unsigned*)hf, nullptr, B, T, H, true, s));
             return 0;
         }
         HIPCHK(lstm_pack_w(whh_f, whh_b, scratch, H, 0, s));
@@ -1610,8 +1759,8 @@ int ss_op_lstm_bwd(float* gates, const float* whh_f, const float* whh_b, const f
         float* dc = gf + 2 * half;
         const long xbytes = lstm_seq_xbytes(B, H, true);
         if (g_persist && lstm_seq_supported(B, H) && scratch_floats * 4 >= xbytes + 4L * LSTM_SEQ_SYNC_WORDS) {     // [exchange tiles][flags]
-            HIPCHK(lstm_seq_bwd(gates, whh_f, whh_b, scratch, d_out, csave, (unsigned*)((char*)scratch + xbytes), nullptr, nullptr, nullptr, B, T, H,
-                                true, s));
+            HIPCHK(lstm_seq_bwd(gates, whh_f, whh_b, scratch, d_out, csave, (unsigned*)((char*)scratch + xbytes), nullptr, nullptr, nullptr, nullptr, B, T,
+                                H, true, s));
             return 0;
         }
         HIPCHK(lstm_pack_w(whh_f, whh_b, scratch, H, 1, s));
@@ -1635,8 +1784,17 @@ int ss_check(ss_engine* e, void* stream) {
             if (flag) return fail("persistent LSTM kernel gave up waiting for its group (bounded spin expired): results are invalid");
         }
     }
+    return sticky_check(e);       // an abort in ANY earlier step (the per-launch words above are re-zeroed every step)
+}
+
+int ss_clear_abort(ss_engine* e, void* stream) {
+    if (!e) return fail("ss_clear_abort: null engine");
+    HIPCHK(hipStreamSynchronize(S(stream)));
+    if (e->sticky) *(volatile unsigned*)e->sticky = 0u;
     return 0;
 }
+
+unsigned ss_status(const ss_engine* e) { return e && e->sticky ? *(volatile unsigned*)e->sticky : 0u; }
 
 int ss_debug_buffer(ss_engine* e, const char* name, float** ptr, long* rows, long* cols) {
     auto it = e->dbg.find(name);

@@ -27,6 +27,14 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int BK = 32;
 
+// timing experiments that produce wrong results (tools/kbench.py gdiag): present only in the -DSS_DIAG build, so the product
+// library's k-loop carries none of their branches
+#ifdef SS_DIAG
+#define GDIAG(d, bits) ((d).diag & (bits))
+#else
+#define GDIAG(d, bits) 0
+#endif
+
 // split two fp32 values into packed bf16 pairs: (h0,h1), (m0,m1), (l0,l1); element 0 in the low half
 __device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
     const unsigned b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
             // resident on the XCD then share 8 column panels AND 8 row panels in its 4 MB L2, instead of streaming every
             // column panel once per pair of rows (3.4x -> 1.6x the operand bytes from HBM on the projection shape).
             constexpr int GW = 8;
-            if (!(d.diag & 8) && chunk % gx == 0 && gx % GW == 0 && chunk / gx >= 2) {
+            if (!GDIAG(d, 8) && chunk % gx == 0 && gx % GW == 0 && chunk / gx >= 2) {
                 const int rows = chunk / gx, local = rem % chunk;
                 const int c = (local / (GW * rows)) * GW + local % GW;
                 const int r = (local / GW) % rows;
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
         Slot s = f32x4{0.f, 0.f, 0.f, 0.f};
         if (TRX) {
             if (full || (ok && kpos < kend)) s = *reinterpret_cast<const f32x4*>(p);
-            if (!(d.diag & 4)) p += (long)BK * op.ld;
+            if (!GDIAG(d, 4)) p += (long)BK * op.ld;
         } else if (!T) {
             if (full) s = *reinterpret_cast<const f32x4*>(p);
             else if (ok && kpos < kend) {
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
                     for (int j = 0; j < 4; ++j)
                         if (kpos + j < kend) s[j] = p[j];
             }
-            if (!(d.diag & 4)) p += BK;             // diag 4 (timing only): every k-tile re-reads tile 0 -> no memory latency
+            if (!GDIAG(d, 4)) p += BK;             // diag 4 (timing only): every k-tile re-reads tile 0 -> no memory latency
             if (op.seglen) {                          // seglen >= BK (checked by the launcher): at most one wrap per tile
                 w += BK;
                 const bool wrap = w >= op.seglen;
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
                 for (int j = 0; j < 4; ++j)
                     if (kpos + j < kend) s[j] = p[(long)j * op.ld];
             }
-            if (!(d.diag & 4)) p += (long)BK * op.ld;
+            if (!GDIAG(d, 4)) p += (long)BK * op.ld;
         }
         return s;
     };
@@ -276,19 +284,19 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
     unsigned long long ph[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
     for (int kt = 0; kt < nk; ++kt) {
         if (PROBE) t0 = __builtin_readcyclecounter();
-        if (!(d.diag & 64)) sstore();               // tile kt: registers -> bf16 planes   (diag 64 / 128 / 256: timing ablations)
+        if (!GDIAG(d, 64)) sstore();               // tile kt: registers -> bf16 planes   (diag 64 / 128 / 256: timing ablations)
         if (PROBE) { t1 = __builtin_readcyclecounter(); ph[0] += t1 - t0; t0 = t1; }
-        if (!(d.diag & 32)) __syncthreads();        // diag 32 (timing only, wrong results): no barriers in the k-loop
+        if (!GDIAG(d, 32)) __syncthreads();        // diag 32 (timing only, wrong results): no barriers in the k-loop
         if (PROBE) { t1 = __builtin_readcyclecounter(); ph[1] += t1 - t0; t0 = t1; }
         // tile kt+1 in flight during the MFMAs
-        if (d.diag & 128) {
+        if (GDIAG(d, 128)) {
         } else if (kt + 1 < nfull) gload(kbeg + (kt + 1) * BK, true);
         else if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK, false);
         if (PROBE) { t1 = __builtin_readcyclecounter(); ph[2] += t1 - t0; t0 = t1; }
 #pragma unroll
         for (int ks16 = 0; ks16 < BK / 16; ++ks16) {
             bf16x8 a[NPL][MI], b[NPL][NI];
-            const int fskip = (d.diag & 256) ? 0 : 1;    // 256: every fragment read hits the same LDS word (no bandwidth, same instruction count)
+            const int fskip = GDIAG(d, 256) ? 0 : 1;    // 256: every fragment read hits the same LDS word (no bandwidth, same instruction count)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 const int row = wm * (BM / 2) + mi * 32 + l31;
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
                 }
         }
         if (PROBE) { t1 = __builtin_readcyclecounter(); ph[3] += t1 - t0; t0 = t1; }
-        if (!(d.diag & 32)) __syncthreads();        // all fragment reads done before the planes are overwritten
+        if (!GDIAG(d, 32)) __syncthreads();        // all fragment reads done before the planes are overwritten
         if (PROBE) { t1 = __builtin_readcyclecounter(); ph[4] += t1 - t0; }
     }
     if (PROBE && lane == 0 && blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z) < 64) {
@@ -385,7 +393,7 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t s) {
     }
     if (d.flags & GEMM_BF16) hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB, 1>), grid, dim3(256), 0, s, d);
     else if (d.flags & GEMM_F16X2) hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB, 2>), grid, dim3(256), 0, s, d);
-    else if ((d.diag & 16) && BM == 128 && BN == 128 && !TA && !TB)
+    else if (GDIAG(d, 16) && BM == 128 && BN == 128 && !TA && !TB)
         hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB, 3, (BM == 128 && BN == 128 && !TA && !TB)>), grid, dim3(256), 0, s, d);
     else hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB, 3>), grid, dim3(256), 0, s, d);
     return hipGetLastError();

@@ -17,6 +17,9 @@ namespace ss {
 
 int g_gemm_bk = 16;        // (unused: BK = 32 measured slower; kept so ss_tune("gemm_bk") stays valid)
 int g_gemm_want = 1024;
+int g_deterministic = 0;   // ss_tune("deterministic", 1): run-to-run bit-identical results -- no split-K (its fp32 atomics commit in arrival
+                           // order), ordered bias / affine gradient sums (elementwise.hip), bias gradients of the persistent recurrence
+                           // through the ordered column sum.  Costs the weight-gradient GEMMs their split-K parallelism.
 int g_gemm_diag = 0;       // A/B experiments: bit 0 = XCD-aware tile order off, bit 1 = two-tile register prefetch
                           // (measured slower: 146 VGPRs cost a resident workgroup per CU)     // minimum number of tiles before the largest tile is chosen, ss_tune("gemm_want")
 
@@ -63,7 +66,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmDesc d) {
     {
         const int gx = gridDim.x, gy = gridDim.y;
         const int total = gx * gy * gridDim.z;
+#ifdef SS_DIAG
         if (!(d.diag & 1) && (total & 7) == 0) {
+#else
+        if ((total & 7) == 0) {
+#endif
             const int lin = bx + gx * (by + gy * bz);
             const int rem = (lin & 7) * (total >> 3) + (lin >> 3);
             bx = rem % gx;
@@ -325,7 +332,7 @@ hipError_t launch_gemm(const GemmDesc& din, hipStream_t s) {
     GemmDesc d = din;
     d.diag = g_gemm_diag;
     if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return hipSuccess;
-    if (d.ksplit < 1) d.ksplit = 1;
+    if (d.ksplit < 1 || g_deterministic) d.ksplit = 1;
     if (d.ksplit > 1 && !(d.flags & GEMM_ACCUM)) return hipErrorInvalidValue;   // split-K needs a zeroed / live C
     const bool vec = vec_ok(d.A) && vec_ok(d.B);
     const bool seg_ok = (d.A.seglen == 0 || d.A.seglen >= 32) && (d.B.seglen == 0 || d.B.seglen >= 32);   // one wrap per k-tile

@@ -39,9 +39,10 @@ hipError_t gn_relu_fwd(const float* x, long x_ld, long x_bs, float* y, long y_ld
 // dy (grad of the ReLU output) is replaced in place by the grad of the GroupNorm input (= conv output).
 // g_gamma / g_beta / g_bias [C]: every utterance's d_gamma, d_beta, d_convbias are ACCUMULATED here (f32 atomics).
 // amax (nullable): receives max |conv-output gradient| written, as for lstm_seq_bwd.
+// part (nullable): [B][3][C] scratch; in deterministic mode the per-utterance sums go there and are added in utterance order.
 hipError_t gn_relu_bwd(const float* x, long x_ld, long x_bs, float* dy, long dy_ld, long dy_bs, const float* gamma,
-                       const float* beta, const float* stats, float* g_gamma, float* g_beta, float* g_bias, float* amax, int B,
-                       int T, int C, hipStream_t s);
+                       const float* beta, const float* stats, float* g_gamma, float* g_beta, float* g_bias, float* amax, float* part,
+                       int B, int T, int C, hipStream_t s);
 // test hook: mask [B, T, C] dense = 1.0f where the block's GroupNorm output is > 0 (the ReLU branch the kernels above take)
 hipError_t gn_relu_mask(const float* x, long x_ld, long x_bs, const float* gamma, const float* beta, const float* stats,
                         float* mask, int B, int T, int C, hipStream_t s);
@@ -93,9 +94,21 @@ hipError_t ce_loss(const float* logits, long o_ld, long o_bs, const int* tgt, fl
 struct AdamState {        // device-resident so a captured graph can replay the step
     double lr, beta1, beta2, eps;
     long step;
-    float step_size, bc2_sqrt, f_beta1, f_beta2, f_eps, pad;
+    float step_size, bc2_sqrt, f_beta1, f_beta2, f_eps;
+    unsigned skip;        // set by adam_prepare when this step's gradients must not be applied (see adam_step)
 };
-hipError_t adam_step(float* p, const float* g, float* m, float* v, long n, AdamState* st, float grad_scale, hipStream_t s);
+// Engine status word ("sticky": host-visible, survives steps, cleared only by ss_clear_abort): bit 0 a persistent recurrence kernel's
+// bounded wait expired on this rank, bit 1 another rank reported it (data parallel), bit 2 a parameter left the range the
+// fixed-scale fp16 x 2 forward products are valid for (or is not finite).
+constexpr unsigned SS_STICKY_ABORT = 1u, SS_STICKY_REMOTE = 2u, SS_STICKY_RANGE = 4u;
+// sticky (nullable) / status (nullable: the gradient arena's status slot, summed over the ranks by the all-reduce): when
+// either is non-zero the update is SKIPPED -- parameters, moments and the step counter stay as they are.
+hipError_t adam_step(float* p, const float* g, float* m, float* v, long n, AdamState* st, float grad_scale, unsigned* sticky,
+                     const float* status, hipStream_t s);
+// *status = (*sticky != 0)   (one thread; enqueued behind the decoder's recurrences, in front of the all-reduce that sums it)
+hipError_t status_publish(const unsigned* sticky, float* status, hipStream_t s);
+// sticky |= SS_STICKY_RANGE if any of the n parameters is not finite or |p| >= limit
+hipError_t param_guard(const float* p, long n, float limit, unsigned* sticky, hipStream_t s);
 
 // ---------------------------------------------------------------- lstm_small.hip  (hidden <= 32: whole recurrence in one launch)
 // gates: [B, TP, 8H] holds x.W_ih^T + b_ih + b_hh on entry (column = dir*4H + gate*H + j, gate order i,f,g,o) and the
@@ -127,14 +140,15 @@ hipError_t lstm_step_bwd(float* gates, const float* wfragT, const float* gf_cur,
 constexpr int LSTM_SEQ_SYNC_WORDS = 2048;   // [0] abort, [1..) XCD masks per group, [64 + 32*group + member] completion flags
 bool lstm_seq_supported(int B, int H);
 long lstm_seq_xbytes(int B, int H, bool backward);
+// sticky (nullable): engine-wide word, host-visible, that a launch ORs 1 into when its bounded wait expires (never cleared by a step)
 hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, float* out, float* csave,
-                        unsigned* sync, int B, int T, int H, bool zero_state, hipStream_t s);
+                        unsigned* sync, unsigned* sticky, int B, int T, int H, bool zero_state, hipStream_t s);
 // amax (nullable): device word that receives max |pre-activation gradient| written (atomic max of the float's bit pattern;
 // zero it first) -- the scale the fp16 x 2 GEMMs that consume the gradient slab need
 // gbias_f / gbias_b (nullable): [2][4H] gradient accumulators of (b_ih, b_hh) of the forward / reverse direction; the kernel
 // adds the sum over utterances and time of the pre-activation gradients to both halves (f32 atomics)
 hipError_t lstm_seq_bwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, const float* d_out,
-                        const float* csave, unsigned* sync, float* amax, float* gbias_f, float* gbias_b, int B, int T, int H,
-                        bool zero_state, hipStream_t s);
+                        const float* csave, unsigned* sync, unsigned* sticky, float* amax, float* gbias_f, float* gbias_b, int B, int T,
+                        int H, bool zero_state, hipStream_t s);
 
 }  // namespace ss

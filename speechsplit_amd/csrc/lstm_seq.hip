@@ -40,27 +40,40 @@
 namespace ss {
 
 int g_seq_prio = 1;    // 1: persistent recurrence waves run at s_setprio 3
+int g_seq_spin_log2 = 18;   // bounded wait of the group hand-off: 2^18 polls ~ tens of ms.  ss_tune("seq_spin_log2", 4) makes the
+                            // first wait of a launch expire, which is how the tests exercise the abort path on hardware
 
 namespace {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return ss_sigmoid(x); }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-constexpr unsigned SPIN_LIMIT = 1u << 18;     // ~ tens of ms of polling before giving up
+// `prio` kernel argument: bit 0 s_setprio, bits 1..15 timing experiments (SS_DIAG builds only), bits 16..20 log2 of the spin limit
+__device__ __forceinline__ unsigned spin_limit_of(int prio) { return 1u << ((prio >> 16) & 31); }
 
 // Group hand-off without read-modify-write traffic: every member owns one word of its group's flag line (32 words = one
 // 128-byte line) and publishes "my step s is complete" by storing s there; a consumer wave reads the whole line with ONE load
 // (lane i = member i) and is done when every member's value has reached `want`.  (A shared arrival counter costs one
 // same-address atomic per member and step, and those serialise in the L2: measured, it was most of the step's latency.)
-// Called by all 64 lanes of one wave; returns false on abort / timeout.
-__device__ __forceinline__ bool wait_flags(const unsigned* flags, int members, unsigned want, unsigned* abortp) {
+// Called by all 64 lanes of one wave; returns false on abort / timeout.  On expiry the launch's abort word makes every other
+// workgroup drain, and the engine's STICKY word (host-visible, never cleared by a step) records that this step's results are
+// garbage: the Adam kernel refuses to apply them and the next C-ABI call reports it.
+struct SeqAbort {
+    unsigned* launch;      // abort word of this launch (sync[0], zeroed per step)
+    unsigned* sticky;      // engine-wide, nullable
+    unsigned limit;
+};
+__device__ __forceinline__ bool wait_flags(const unsigned* flags, int members, unsigned want, const SeqAbort& ab) {
     const int lane = threadIdx.x & 63;
     for (unsigned spins = 0;; ++spins) {
         const unsigned v = lane < members ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
         if (__all((int)(v - want) >= 0)) return true;
-        if ((spins & 63) == 63 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-        if (spins > SPIN_LIMIT) {
-            if (lane == 0) __hip_atomic_store(abortp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((spins & 63) == 63 && __hip_atomic_load(ab.launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+        if (spins > ab.limit) {
+            if (lane == 0) {
+                __hip_atomic_store(ab.launch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ab.sticky) __hip_atomic_fetch_or(ab.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             return false;
         }
         __builtin_amdgcn_s_sleep(1);
@@ -226,7 +239,7 @@ __device__ __forceinline__ unsigned xcc_id() {
 // Round 0 of the group protocol (wave 0 of the workgroup): put my XCD into the group's mask word, publish flag 1, wait for
 // all members, read the mask back.  Returns 1 if the group is XCD-local, 0 if it spans XCDs, -1 on abort.  Completion of
 // step s is then published as s + 2, and step st waits for st + 1.
-__device__ __forceinline__ int group_locality(unsigned* flags, int me, int members, unsigned* mask, unsigned* abortp) {
+__device__ __forceinline__ int group_locality(unsigned* flags, int me, int members, unsigned* mask, const SeqAbort& abortp) {
     const int lane = threadIdx.x & 63;
     if (lane == 0) {
         const unsigned old = __hip_atomic_fetch_or(mask, 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -268,7 +281,8 @@ template <int H, int NW>
 __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict__ gates, const float* __restrict__ whh_f,
                                                                const float* __restrict__ whh_b, unsigned char* __restrict__ xb,
                                                                float* __restrict__ out, float* __restrict__ csave,
-                                                               unsigned* __restrict__ sync, int B, int T, int nbt, int prio) {
+                                                               unsigned* __restrict__ sync, unsigned* __restrict__ sticky, int B, int T,
+                                                               int nbt, int prio) {
     constexpr int JT = H / 16, KC = H / 32, KS = H / NW / 32;       // KS k-steps of 32 per wave
     static_assert(KS == 2, "the persistent forward kernel is written for 64 reduction elements per wave");
     // per-wave partial sums, [unit column][utterance row], rows padded to 20 floats: a lane writes its four accumulator rows
@@ -283,10 +297,14 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
     const int TP = T + 2 * HALO;
     const int li = lane & 15, lq = lane >> 4;
     unsigned* flags = sync + 64 + 32 * grp;
-    unsigned* abortp = sync;
+    const SeqAbort abortp{sync, sticky, spin_limit_of(prio)};
     // timing experiments (wrong results): 1 no exchange loads, 2 no payload stores, 4 no input prefetch, 8 no slab stores,
     // 16 no waiting, 32 ordinary stores regardless
-    const int diag = prio >> 1;
+#ifdef SS_DIAG
+    const int diag = (prio >> 1) & 0x7FFF;
+#else
+    constexpr int diag = 0;
+#endif
     if (w == 0) {
         const int r = group_locality(flags, jt, JT, sync + 1 + grp, abortp);
         if (lane == 0) s_ok = r;
@@ -445,9 +463,9 @@ template <int H, int NW>
 __global__ __launch_bounds__(64 * (NW + 1)) void lstm_seq_bwd_kernel(float* __restrict__ gates, const float* __restrict__ whh_f,
                                                                const float* __restrict__ whh_b, unsigned char* __restrict__ xb,
                                                                const float* __restrict__ d_out, const float* __restrict__ csave,
-                                                               unsigned* __restrict__ sync, unsigned* __restrict__ amax,
-                                                               float* __restrict__ gbias_f, float* __restrict__ gbias_b, int B, int T,
-                                                               int nbt, int prio) {
+                                                               unsigned* __restrict__ sync, unsigned* __restrict__ sticky,
+                                                               unsigned* __restrict__ amax, float* __restrict__ gbias_f,
+                                                               float* __restrict__ gbias_b, int B, int T, int nbt, int prio) {
     constexpr int JT = H / 16, CT = JT / NW, PW = JT / NW;      // column tiles (= consumers) / producers handled per wave
     static_assert(CT == 4 || CT == 2, "the persistent backward kernel is written for 2 or 4 column tiles per wave");
     __shared__ __attribute__((aligned(16))) float red[NW][16][20];      // [unit column][utterance row, padded], see the forward kernel
@@ -458,7 +476,11 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_seq_bwd_kernel(float* __re
     // timing experiments (wrong results unless noted): 1 no exchange loads, 2 no products, 4 no operand fetch, 8 no slab stores,
     // 16 no waits, 32 ordinary tile stores even if the group spans XCDs, 64 operands from two hot rows, 128 idle helper wave
     // (results stay right)
-    const int diag = prio >> 1;
+#ifdef SS_DIAG
+    const int diag = (prio >> 1) & 0x7FFF;
+#else
+    constexpr int diag = 0;
+#endif
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // Wave NW is a helper: it owns no tile and no cell, it only touches the operand rows the cell threads will fetch a few
     // steps later, so that those fetches come out of the L2 (and a warm TLB) instead of HBM.  The memory counter is per
@@ -471,7 +493,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_seq_bwd_kernel(float* __re
     const int TP = T + 2 * HALO;
     const int li = lane & 15, lq = lane >> 4;
     unsigned* flags = sync + 64 + 32 * grp;
-    unsigned* abortp = sync;
+    const SeqAbort abortp{sync, sticky, spin_limit_of(prio)};
     if (w == 0) {
         const int r = (diag & 16) ? 1 : group_locality(flags, jt, JT, sync + 1 + grp, abortp);
         if (lane == 0) s_ok = r;
@@ -722,8 +744,10 @@ long lstm_seq_xbytes(int B, int H, bool backward) {
     return backward ? 2 * (2 * nbt * JT * JT * 1024) : 2 * (2 * nbt * 2 * (H / 32) * 1024);
 }
 
+static int seq_prio_arg() { return (g_seq_prio & 0xFFFF) | ((g_seq_spin_log2 & 31) << 16); }
+
 hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, float* out, float* csave,
-                        unsigned* sync, int B, int T, int H, bool zero_state, hipStream_t s) {
+                        unsigned* sync, unsigned* sticky, int B, int T, int H, bool zero_state, hipStream_t s) {
     const int nbt = (B + 15) / 16;
     if (!lstm_seq_supported(B, H)) return hipErrorInvalidValue;
     if (zero_state) {
@@ -732,14 +756,14 @@ hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, vo
         if (e != hipSuccess) return e;
     }
     unsigned char* xb = static_cast<unsigned char*>(xbuf);
-    if (H == 512) hipLaunchKernelGGL((lstm_seq_fwd_kernel<512, 8>), dim3(2 * nbt * 32), dim3(512), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, B, T, nbt, g_seq_prio);
-    else          hipLaunchKernelGGL((lstm_seq_fwd_kernel<256, 4>), dim3(2 * nbt * 16), dim3(256), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, B, T, nbt, g_seq_prio);
+    if (H == 512) hipLaunchKernelGGL((lstm_seq_fwd_kernel<512, 8>), dim3(2 * nbt * 32), dim3(512), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, B, T, nbt, seq_prio_arg());
+    else          hipLaunchKernelGGL((lstm_seq_fwd_kernel<256, 4>), dim3(2 * nbt * 16), dim3(256), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, B, T, nbt, seq_prio_arg());
     return hipGetLastError();
 }
 
 hipError_t lstm_seq_bwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, const float* d_out,
-                        const float* csave, unsigned* sync, float* amax, float* gbias_f, float* gbias_b, int B, int T, int H,
-                        bool zero_state, hipStream_t s) {
+                        const float* csave, unsigned* sync, unsigned* sticky, float* amax, float* gbias_f, float* gbias_b, int B, int T,
+                        int H, bool zero_state, hipStream_t s) {
     const int nbt = (B + 15) / 16;
     if (!lstm_seq_supported(B, H)) return hipErrorInvalidValue;
     if (zero_state) {
@@ -747,8 +771,8 @@ hipError_t lstm_seq_bwd(float* gates, const float* whh_f, const float* whh_b, vo
         if (e != hipSuccess) return e;
     }
     unsigned char* xb = static_cast<unsigned char*>(xbuf);
-    if (H == 512) hipLaunchKernelGGL((lstm_seq_bwd_kernel<512, 8>), dim3(2 * nbt * 32), dim3(576), 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, reinterpret_cast<unsigned*>(amax), gbias_f, gbias_b, B, T, nbt, g_seq_prio);
-    else          hipLaunchKernelGGL((lstm_seq_bwd_kernel<256, 8>), dim3(2 * nbt * 16), dim3(576), 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, reinterpret_cast<unsigned*>(amax), gbias_f, gbias_b, B, T, nbt, g_seq_prio);
+    if (H == 512) hipLaunchKernelGGL((lstm_seq_bwd_kernel<512, 8>), dim3(2 * nbt * 32), dim3(576), 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, reinterpret_cast<unsigned*>(amax), gbias_f, gbias_b, B, T, nbt, seq_prio_arg());
+    else          hipLaunchKernelGGL((lstm_seq_bwd_kernel<256, 8>), dim3(2 * nbt * 16), dim3(576), 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, reinterpret_cast<unsigned*>(amax), gbias_f, gbias_b, B, T, nbt, seq_prio_arg());
     return hipGetLastError();
 }
 

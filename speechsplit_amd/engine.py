@@ -40,6 +40,7 @@ class Engine:
         self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
         self.max_batch = int(max_batch)
         self.max_frames = int(max_frames or hp.max_len_pad)
+        self._stagers = {}
         self._hps = _capi.hparams_struct(hp)
         self.h = self.lib.ss_create(KIND[kind], C.byref(self._hps), self.max_batch, self.max_frames)
         if not self.h:
@@ -99,10 +100,21 @@ class Engine:
         return t.to(device=self.device, dtype=torch.int32).contiguous()
 
     def _draws(self, draws):
+        """Device tensors pass through untouched; host draws go through a pinned ring with one non-blocking copy on the
+        compute stream (staging.DrawStager) -- never a pageable, blocking `.to(device)`."""
         if draws is None:
             return None, None
         sc, ls = draws
-        return self._f(torch.as_tensor(sc)), self._i(torch.as_tensor(ls))
+        sc, ls = torch.as_tensor(sc), torch.as_tensor(ls)
+        if sc.is_cuda and ls.is_cuda:
+            return self._f(sc), self._i(ls)
+        sc, ls = sc.reshape(sc.shape[0], -1), ls.reshape(ls.shape[0], -1)
+        key = tuple(sc.shape)
+        st = self._stagers.get(key)
+        if st is None:
+            from .staging import DrawStager
+            st = self._stagers[key] = DrawStager(self.device, key[0], key[1])
+        return st.stage(sc, ls)
 
     # ------------------------------------------------------------------ Generator_3
     def g3_forward(self, x_f0, x_org, c_trg, draws=None, training=False):
@@ -231,6 +243,13 @@ class Engine:
         """Synchronise and raise if a kernel reported an asynchronous failure."""
         _capi.check(self.lib.ss_check(self.h, _stream()))
 
+    def status(self):
+        """Engine status word without synchronising (ss_status): 0 ok, bit 0 aborted recurrence, 1 remote abort, 2 parameter range."""
+        return int(self.lib.ss_status(self.h))
+
+    def clear_abort(self):
+        _capi.check(self.lib.ss_clear_abort(self.h, _stream()))
+
     def zero_grads(self):
         _capi.check(self.lib.ss_zero_grads(self.h, _stream()))
 
@@ -279,12 +298,29 @@ class Engine:
         _capi.check(self.lib.ss_set_precision(self.h, code))
         self.precision = 'bf16' if code else 'f32'
 
-    def profile(self, enable):
-        """ss_profile: (launches, total_us, flops_per_launch) of the decoder input-projection GEMM (layers >= 1) recorded
-        with hipEvents on the launch stream since the previous call; sets the enable state for what follows."""
-        n, us, fl = C.c_int(), C.c_double(), C.c_double()
-        _capi.check(self.lib.ss_profile(self.h, int(bool(enable)), C.byref(n), C.byref(us), C.byref(fl)))
-        return n.value, us.value, fl.value
+    PROF_CLASSES = ('dec_proj', 'dec_proj0', 'dec_dw', 'dec_dx', 'conv_fwd', 'conv_dw', 'conv_dx', 'rec_fwd', 'rec_bwd',
+                    'enc_lstm', 'head')
+
+    def profile(self, classes):
+        """ss_profile: bracket the launches of the named classes (True: all; False / empty: stop) with hipEvents; starting
+        clears the record."""
+        if classes is True:
+            mask = (1 << len(self.PROF_CLASSES)) - 1
+        elif not classes:
+            mask = 0
+        else:
+            mask = sum(1 << self.PROF_CLASSES.index(c) for c in classes)
+        _capi.check(self.lib.ss_profile(self.h, mask))
+
+    def profile_read(self):
+        """{class: (launches, total_us, total_flops)} of the launches recorded since profile(True) (ss_profile_read)."""
+        out = {}
+        for k, name in enumerate(self.PROF_CLASSES):
+            n, us, fl = C.c_int(), C.c_double(), C.c_double()
+            _capi.check(self.lib.ss_profile_read(self.h, k, C.byref(n), C.byref(us), C.byref(fl)))
+            if n.value:
+                out[name] = (n.value, us.value, fl.value)
+        return out
 
     def debug_buffer(self, name, B, T):
         """Real frames of an internal haloed slab as a [B, T, C] tensor (copy)."""

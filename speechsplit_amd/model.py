@@ -100,6 +100,14 @@ def _init_tensor(shape, init):
     return t
 
 
+def init_weights(kind, hp, seed=0):
+    """{state_dict name: fp32 tensor} drawn with the reference's initialisers (``_spec`` / ``_init_tensor``) from a generator
+    seeded with `seed`; the global RNG state is left alone."""
+    with torch.random.fork_rng(devices=[]):
+        torch.manual_seed(seed)
+        return {name: _init_tensor(shape, init) for name, shape, init in _spec(kind, hp)}
+
+
 class _G3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mod, x_f0, x_org, c_trg, draws, *params):

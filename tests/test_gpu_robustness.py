@@ -1,0 +1,150 @@
+"""Failure behaviour of the engine on the GPU (pytest -m gpu): an expired bounded wait in a persistent recurrence kernel, a
+parameter outside the fp16 x 2 range, and run-to-run determinism.  None of this exists in the reference (single device, ATen
+kernels, no spinning kernels); the bar is the reference's observable behaviour: a training run either applies correct
+updates or stops with an error -- it never silently trains on garbage."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import weights as W
+from oracle.gen_fixtures import draws_for, synth_batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def E():
+    from speechsplit_amd import engine
+    return engine
+
+
+def stack_draws(draws):
+    return np.stack([d[0] for d in draws]), np.stack([d[1] for d in draws])
+
+
+def fresh(E, B, T, wseed=1):
+    hp = W.default_hparams(max_len_pad=T)
+    eng = E.Engine('G3', hp, B, T)
+    eng.load_weights(W.make_weights('G3', hp, wseed))
+    eng.set_adam(1e-4, 0.9, 0.999, 1e-8, 0)
+    return eng
+
+
+def test_expired_wait_skips_adam_and_stays_reported(E):
+    """ss_tune("seq_spin_log2", 0) makes the first unsatisfied poll of a persistent recurrence kernel expire: the kernels raise
+    their abort word and drain, the rest of that step runs on garbage -- and must not reach the parameters.  Afterwards: the
+    engine status is sticky over further step calls (each returns an error and enqueues nothing), ss_check keeps failing,
+    parameters / Adam moments / step counter are exactly what they were, and after ss_clear_abort training continues as if the
+    aborted step had never been issued (compared with an engine that never saw it)."""
+    B, T = 16, 128
+    mel, f0, emb, lens = synth_batch(77, B, T, 64)
+    d = [stack_draws(draws_for(78 + i, B, 4)) for i in range(3)]
+    ref = fresh(E, B, T)
+    l_ref = [float(ref.g3_train_step(mel, f0, emb, lens, d[0])), float(ref.g3_train_step(mel, f0, emb, lens, d[2]))]
+    ref.check()
+
+    eng = fresh(E, B, T)
+    l0 = float(eng.g3_train_step(mel, f0, emb, lens, d[0]))
+    eng.check()
+    assert abs(l0 - l_ref[0]) <= 1e-6 * l0
+    p1, m1, v1 = eng.params.clone(), eng.adam_m.clone(), eng.adam_v.clone()
+    E.tune('seq_spin_log2', 0)
+    try:
+        eng.g3_train_step(mel, f0, emb, lens, d[1])            # aborts on the device; the call itself cannot know yet
+        torch.cuda.synchronize()
+    finally:
+        E.tune('seq_spin_log2', 18)
+    assert eng.status() & 1
+    assert torch.equal(eng.params, p1) and torch.equal(eng.adam_m, m1) and torch.equal(eng.adam_v, v1)
+    for _ in range(3):                                          # further steps: refused, nothing enqueued
+        with pytest.raises(RuntimeError, match='gave up waiting'):
+            eng.g3_train_step(mel, f0, emb, lens, d[2])
+    with pytest.raises(RuntimeError, match='gave up waiting'):
+        eng.check()
+    with pytest.raises(RuntimeError, match='gave up waiting'):
+        eng.adam_step()
+    assert torch.equal(eng.params, p1)
+    eng.clear_abort()
+    assert eng.status() == 0
+    l2 = float(eng.g3_train_step(mel, f0, emb, lens, d[2]))
+    eng.check()
+    assert abs(l2 - l_ref[1]) <= 1e-6 * l2                      # same loss: same parameters went in
+    assert float((eng.params - ref.params).abs().max()) <= 2e-6        # and the same Adam step number / moments came out (a repeated step 1 would move every weight by lr = 1e-4)
+
+
+def test_remote_abort_reaches_every_rank_through_the_status_slot(E):
+    """Data parallel: the aborting rank publishes 1.0 in the gradient arena's status slot (last 4 floats), the all-reduce sums
+    it, every rank's Adam kernel skips.  Emulated on one GPU by writing the slot the way the sum of another rank's would."""
+    B, T = 4, 128
+    eng = fresh(E, B, T)
+    mel, f0, emb, lens = synth_batch(5, B, T, 64)
+    d = stack_draws(draws_for(6, B, 4))
+    eng.g3_train_step(mel, f0, emb, lens, d, no_adam=True)
+    torch.cuda.synchronize()
+    assert float(eng.grads[-4]) == 0.0 and eng.grad_split < eng.grads.numel() - 4          # the slot rides in the decoder bucket
+    p0 = eng.params.clone()
+    eng.grads[-4] = 1.0                                         # "some other rank aborted"
+    eng.adam_step(0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.params, p0) and eng.status() & 2
+    with pytest.raises(RuntimeError, match='another data-parallel rank'):
+        eng.check()
+    eng.clear_abort()
+    eng.g3_train_step(mel, f0, emb, lens, d)
+    eng.check()
+    assert not torch.equal(eng.params, p0)
+
+
+def test_parameter_outside_fp16x2_range_is_refused(E):
+    """The forward contractions scale their operands by a FIXED 16 before the fp16 x 2 split: a weight >= 4094 would become inf.
+    The engine refuses long before (|p| >= 64, which also bounds the GroupNorm outputs): status RANGE, no update; with
+    ss_tune("fwd_f16x2", 0) + ("bwd_f16x2", 0) (bf16 x 3 products, fp32 exponent range) the same weights train."""
+    B, T = 4, 128
+    eng = fresh(E, B, T)
+    mel, f0, emb, lens = synth_batch(5, B, T, 64)
+    d = stack_draws(draws_for(6, B, 4))
+    pv = eng.param_views()
+    pv['encoder_1.convolutions_1.1.1.weight'][3] = 100.0       # a GroupNorm gamma nobody would call unreasonable
+    p0 = eng.params.clone()
+    eng.g3_train_step(mel, f0, emb, lens, d)
+    torch.cuda.synchronize()
+    assert eng.status() & 4 and torch.equal(eng.params, p0)
+    with pytest.raises(RuntimeError, match='range'):
+        eng.g3_train_step(mel, f0, emb, lens, d)
+    E.tune('fwd_f16x2', 0)
+    E.tune('bwd_f16x2', 0)
+    try:
+        eng.clear_abort()
+        loss = float(eng.g3_train_step(mel, f0, emb, lens, d))
+        eng.check()
+        assert np.isfinite(loss) and not torch.equal(eng.params, p0)
+    finally:
+        E.tune('fwd_f16x2', 1)
+        E.tune('bwd_f16x2', 1)
+
+
+def test_deterministic_mode_is_bit_reproducible(E):
+    """ss_tune("deterministic", 1): two identical 50-step training runs end with bit-identical parameters and losses (the
+    reference's CPU path is run-to-run deterministic; the default mode's split-K / bias atomics are not).  The default mode's
+    spread over the same 50 steps is printed beside it."""
+    B, T, steps = 16, 128, 50
+    mel, f0, emb, lens = synth_batch(91, B, T, 64)
+    d = [stack_draws(draws_for(92 + i, B, 4)) for i in range(5)]
+
+    def run():
+        eng = fresh(E, B, T, wseed=2)
+        for i in range(steps):
+            loss = eng.g3_train_step(mel, f0, emb, lens, d[i % 5])
+        eng.check()
+        return eng.params.clone(), float(loss)
+
+    E.tune('deterministic', 1)
+    try:
+        a, b = run(), run()
+    finally:
+        E.tune('deterministic', 0)
+    assert a[1] == b[1] and torch.equal(a[0], b[0])
+    c, e = run(), run()
+    print(f'[determinism] default mode, {steps} steps: max |param diff| between two runs {float((c[0] - e[0]).abs().max()):.3e}; '
+          f'deterministic mode: 0 (bit-identical), loss {a[1]:.8f}')
+    assert abs(c[1] - a[1]) <= 1e-3 * a[1]          # same training either way

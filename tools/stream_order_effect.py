@@ -8,6 +8,9 @@ from oracle import weights as W
 from oracle.gen_fixtures import synth_batch
 from speechsplit_amd import engine as E
 B, T = 64, 128
+own = int(sys.argv[1]) if len(sys.argv) > 1 else 1      # 0: round 1's behaviour (the step runs on the caller's stream)
+E.tune('own_streams', own)
+print(f'own_streams = {own}', flush=True)
 hp = W.default_hparams(max_len_pad=T)
 mel, f0, emb, lens = [t.cuda() for t in synth_batch(1, B, T, 64)]
 sc, ls = E.draw_interp(B, 4, hp)
