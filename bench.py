@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 
 # algorithmic work, SURVEY.md section 8(d): 19 405 064 MAC / frame / utterance, fwd+bwd = 3 x 2 x MAC
 MAC_PER_FRAME_G3 = 19405064
+MAC_PER_FRAME_G6 = 3474184
 PEAK_16BIT_MFMA_TFLOPS = 2500.0    # dense bf16 / fp16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 PRODUCTS = {'f32': 'fp32 operands/accumulate/storage; products on the 16-bit matrix pipe from an fp16 x 2 split (3 MFMAs, '
@@ -111,7 +112,7 @@ def dominant_class(rec):
     return max(gemm, key=lambda k: gemm[k][1])
 
 
-def kernel_report(eng, steps, ms_step, precision, top, survey):
+def kernel_report(eng, steps, ms_step, precision, top, survey, T):
     """roofline / recurrence from the hipEvent brackets recorded DURING the timed region (dominant class + recurrences);
     kernel_classes from the all-class survey pass that ran before it (same process, same inputs)."""
     rec = eng.profile_read()
@@ -144,7 +145,6 @@ def kernel_report(eng, steps, ms_step, precision, top, survey):
             'share_of_bracketed_gpu_time': round(survey[0][top][1] / sum(v[1] for v in survey[0].values()), 3), 'traffic': traffic}
     recur = None
     if 'rec_fwd' in rec and 'rec_bwd' in rec:
-        T = eng.hp.max_len_pad
         nf, uf, _ = rec['rec_fwd']
         nb, ub, _ = rec['rec_bwd']
         recur = {'launches_per_step': round((nf + nb) / steps, 2), 'fwd_us_per_time_step': round(uf / nf / T, 3),
@@ -190,6 +190,10 @@ def main():
     ap.add_argument('--no-extras', action='store_true', help='skip alt_precisions and solver_loop')
     ap.add_argument('--precision', choices=['f32', 'bf16'], default='f32',
                     help="f32 (default): the 1e-4 parity mode the headline is quoted on; bf16: BASELINE configs 3-5's arithmetic")
+    ap.add_argument('--model', choices=['G3', 'G6'], default='G3', help='G6: Generator_6 (pitch converter, CE loss; BASELINE config 4 is --model G6 --batch 32 --frames 192 --precision bf16)')
+    ap.add_argument('--workload', choices=['fixed', 'config5'], default='fixed',
+                    help='config5: BASELINE config 5 -- crops of 96..192 frames, every batch from one length bucket (speechsplit_amd/buckets.py), '
+                         'assembled on the GPU and staged by DevicePrefetcher inside the timed region; use with --frames 192')
     ap.add_argument('--force-dp', action='store_true', help='run the data-parallel step (bucketed all-reduce, sliced draws) even at world size 1')
     ap.add_argument('--no-profile', action='store_true', help='no hipEvent brackets in the timed region (to measure their cost)')
     ap.add_argument('--tune', action='append', default=[], metavar='KEY=VALUE', help='experiment knob of the HIP library (ss_tune)')
@@ -209,9 +213,10 @@ def main():
         k, v = kv.split('=')
         tune(k, int(v))
     B, T = args.batch, args.frames
+    kind = args.model
     hp = HP.default_hparams(max_len_pad=T, batch_size=B * world)
-    eng = Engine('G3', hp, B, T, device=dev)
-    eng.load_weights(M.init_weights('G3', hp, 0))          # the reference's initialisers, fixed seed
+    eng = Engine(kind, hp, B, T, device=dev)
+    eng.load_weights(M.init_weights(kind, hp, 0))          # the reference's initialisers, fixed seed
     dp = world > 1 or args.force_dp
     dist = None
     if dp:
@@ -224,14 +229,38 @@ def main():
     mel, f0, emb, lens = synth(B, T, 1000 + rank, dev)
     torch.manual_seed(1234)
     S = hp.max_len_seq // hp.min_len_seg + 1
+    ncalls = 4 if kind == 'G3' else 3
+    if kind == 'G6':        # quantised F0 of the batch: input one-hot and cross-entropy target
+        from speechsplit_amd.utils import quantize_f0_torch
+        onehot, qidx = quantize_f0_torch(f0[:, :, 0].clone())
+        onehot, qidx = onehot.contiguous(), qidx.to(torch.int32).contiguous()
+    stream = None
+    frames_done = [0]
+    if args.workload == 'config5':
+        from speechsplit_amd import buckets, data_loader, staging
+        corpus = data_loader.DeviceCorpus(data_loader.SyntheticUtterances(4 * B, seed=7 + rank), dev)
+        loader = buckets.BucketedDeviceBatcher(hp, corpus, 96, 192, rank=rank, world=world, seed=11, steps_per_epoch=10 ** 9)
+        stream = staging.DevicePrefetcher(loader, dev)
 
     def step():
         # fresh randomness every step: one global draw stream (the reference's generator calls), each rank takes its utterances' slice
-        sc, ls = draw_interp(B * world, 4, hp)
+        sc, ls = draw_interp(B * world, ncalls, hp)
         if world > 1:
-            sc = sc.view(4, world, B * S)[:, rank]
-            ls = ls.view(4, world, B * S)[:, rank]
-        if dp:
+            sc = sc.view(ncalls, world, B * S)[:, rank]
+            ls = ls.view(ncalls, world, B * S)[:, rank]
+        if stream is not None:                       # config 5: the next length-bucketed batch, already staged on the device
+            bm, be, bf, bl = next(stream)
+            frames_done[0] += bm.shape[1]
+            if dp:
+                eng.dp_train_step(bm, bf, be, bl, (sc, ls), world, bucket=True)
+            else:
+                eng.g3_train_step(bm, bf, be, bl, (sc, ls), bucket=True)
+        elif kind == 'G6':
+            if dp:
+                eng.dp_g6_train_step(mel, onehot, qidx, (sc, ls), world)
+            else:
+                eng.g6_train_step(mel, onehot, qidx, (sc, ls))
+        elif dp:
             eng.dp_train_step(mel, f0, emb, lens, (sc, ls), world)
         else:
             eng.g3_train_step(mel, f0, emb, lens, (sc, ls))
@@ -275,10 +304,10 @@ def main():
 
     if rank == 0:
         print(f'[bench] gpu: {ms:.3f} ms/step, {value:.1f} utt/s on {world} GPU(s)', file=sys.stderr, flush=True)
-        roof, classes, recur = kernel_report(eng, args.steps, ms, args.precision, top, survey) if top else (None, None, None)
+        roof, classes, recur = kernel_report(eng, args.steps, ms, args.precision, top, survey, T if stream is None else frames_done[0] / max(1, args.steps + args.warmup + 8)) if top else (None, None, None)
         print(f'[bench] roofline: {roof}', file=sys.stderr, flush=True)
     alt = None
-    if not args.no_extras and args.precision == 'f32':
+    if not args.no_extras and args.precision == 'f32' and kind == 'G3' and args.workload == 'fixed':
         # the same step with the other product formats of the fp32 mode (every rank runs them: the collectives must match)
         alt = {}
         for name, knobs in (('bf16x3_exact_split_ms', {'fwd_f16x2': 0, 'bwd_f16x2': 0}), ('fp32_mfma_ms', {'gemm_mode': 0})):
@@ -294,13 +323,17 @@ def main():
             'value': round(value, 1), 'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.precision, 'data': 'synthetic',
-            'config': {'workload': f'Generator_3 full training step (host draws+resample+quantise+fwd+MSE+bwd+Adam), '
-                                   f'{B} utterances/GPU x {T} frames x 80 mel + F0, max_len_pad={T}',
+            'config': {'workload': (f'Generator_3 full training step (host draws+resample+quantise+fwd+MSE+bwd+Adam), '
+                                    f'{B} utterances/GPU x {T} frames x 80 mel + F0, max_len_pad={T}' if kind == 'G3' and args.workload == 'fixed' else
+                                    f'Generator_3 full training step over length-bucketed batches (BASELINE config 5): crops of 96..192 frames, one bucket '
+                                    f'(multiple of 8) per batch, max_len_pad = bucket, {B} utterances/GPU, mean {frames_done[0] / max(1, args.steps + args.warmup + (8 if not args.no_profile else 0)):.1f} frames/batch, '
+                                    f'batches assembled on the GPU + DevicePrefetcher inside the timed region' if kind == 'G3' else
+                                    f'Generator_6 full training step (host draws+fwd+cross-entropy+bwd+Adam; BASELINE config 4 shape), {B} utterances/GPU x {T} frames'),
                        'global_batch': B * world, 'seq_len': T, 'parallelism': f'dp{world}' + (' (forced DP path)' if args.force_dp and world == 1 else ''),
                        'products': PRODUCTS[args.precision]},
-            'step_tflops': round(3 * 2 * MAC_PER_FRAME_G3 * T * B * world / (dt / args.steps) / 1e12, 2),
+            'step_tflops': round(3 * 2 * (MAC_PER_FRAME_G3 if kind == 'G3' else MAC_PER_FRAME_G6) * (T if args.workload == 'fixed' else 144) * B * world / (dt / args.steps) / 1e12, 2),
             'roofline': roof, 'kernel_classes': classes, 'recurrence': recur, 'alt_precisions': alt,
-            'solver_loop': None if (args.no_extras or world > 1) else solver_loop(B, T),
+            'solver_loop': None if (args.no_extras or world > 1 or kind != 'G3' or args.workload != 'fixed') else solver_loop(B, T),
             'cpu_baseline': None if args.no_cpu_baseline else cpu_baseline(T),
         }
         print(json.dumps(out), flush=True)

@@ -42,6 +42,11 @@ typedef struct ss_hparams {
                                     GEMMs (they run on an engine stream beside the encoder backward, as in the one-call
                                     step); the consumer of the decoder range orders itself with ss_wait_decoder_grads() */
 
+#define SS_STEP_BUCKET 16 /* ss_*_train_step: T is the length bucket of THIS batch and the step runs with max_len_pad = T (what the
+                             reference does when its hparams.max_len_pad is set to the bucket length: InterpLnr pads to it, the
+                             encoders' len_org equals it, model.py:105,157,370).  T % 8 == 0, T <= max_frames.  A
+                             bucket change re-plans the workspace (one memset, 0.1 - 0.2 ms at batch 64). */
+
 const char* ss_last_error(void);
 int ss_abi_version(void);
 
@@ -101,6 +106,23 @@ int ss_wait_decoder_grads(ss_engine* e, void* consumer_stream);
 void* ss_side_stream(ss_engine* e);
 /* first arena offset (floats) of the decoder + head parameters; [0, split) is the encoder */
 long ss_grad_split(const ss_engine* e);
+
+/* ---- data parallel over RCCL (nothing to mirror: the reference is single-device, solver.py:38) ----
+ * One process per GPU.  Rank 0 obtains a 128-byte id (ss_comm_unique_id) and hands it to the other ranks by any means
+ * (a file, MPI, torch.distributed's store); every rank then calls ss_comm_init.  RCCL is dlopen'd -- inside a process that
+ * already loaded it (PyTorch) that copy is used. */
+int ss_comm_unique_id(char* id128);
+int ss_comm_init(ss_engine* e, const char* id128, int rank, int world);
+int ss_comm_destroy(ss_engine* e);
+/* in-place sum over the ranks of grads[offset, offset + count) (floats), enqueued on `stream` */
+int ss_allreduce_grads(ss_engine* e, long offset, long count, void* stream);
+/* The whole data-parallel step on this rank's shard (utterances [rank*B, (rank+1)*B) of the global batch and the matching
+ * slices of the draws): forward, decoder backward, all-reduce of the head + decoder bucket (arena offsets >= ss_grad_split(),
+ * 80 % of the bytes, incl. the status slot) ON the engine stream that carries the decoder's weight-gradient GEMMs -- so it
+ * runs beside the encoder backward --, encoder backward, all-reduce of the encoder bucket, Adam with the 1/world mean folded
+ * in.  loss: this rank's local mean loss. */
+int ss_g3_dp_train_step(ss_engine* e, const float* mel_dev, const float* f0_dev, const float* emb_dev, const int* len_org_dev,
+                        const float* scales_dev, const int* len_seg_dev, int B, int T, float* loss_dev, void* stream);
 
 /* torch.optim.Adam(G.parameters(), lr, [beta1, beta2]) (solver.py:62,172).  `step` = updates already applied. */
 int ss_set_adam(ss_engine* e, double lr, double beta1, double beta2, double eps, long step, void* stream);

@@ -5,6 +5,7 @@
 // order, but activations live in haloed time-major slabs (kernels.h), the three InterpLnr calls of Encoder_7
 // operate on one fused 768-channel slab, channel concats / splits / transposes are pointer arithmetic, and
 // every contraction is the one fp32 MFMA GEMM.
+#include <dlfcn.h>
 #include <map>
 #include <string>
 #include <vector>
@@ -123,6 +124,8 @@ struct ss_engine {
     long arena = 0;                        // floats per arena, INCLUDING the 4-float status slot at the end
     long status_off = 0;                   // gradient arena: G[status_off] = 1 when this rank's step is invalid; the data-parallel
                                            // all-reduce sums it, so every rank's Adam kernel sees a non-zero value and skips
+    void* comm = nullptr;                  // ncclComm_t of ss_comm_init (RCCL, dlopen'd)
+    int comm_rank = 0, comm_world = 1;
     unsigned* sticky = nullptr;            // engine status word in host-coherent pinned memory (kernels.h SS_STICKY_*): written by
                                            // kernels, read by the host without synchronising; cleared only by ss_clear_abort
 
@@ -461,8 +464,9 @@ int geometry(ss_engine* e, int B, int T, hipStream_t s) {
         need = tmp.carve(B, T, false);
     }
     if (need > e->ws_bytes) return fail("workspace too small");
-    // new geometry: halo rows move, so everything except the Adam state (first 256 bytes) is re-zeroed
-    HIPCHK(hipMemsetAsync(e->ws + 256, 0, e->ws_bytes - 256, s));
+    // new geometry: halo rows move, so everything the new plan uses, except the Adam state (first 256 bytes), is re-zeroed
+    // (0.1 - 0.2 ms per switch at batch 64: the price of a length-bucket change, SS_STEP_BUCKET)
+    HIPCHK(hipMemsetAsync(e->ws + 256, 0, need - 256, s));
     e->carve(B, T, true);
     e->curB = B;
     e->curT = T;
@@ -1212,6 +1216,7 @@ int import_dout(ss_engine* e, const float* d_out, int B, int T, hipStream_t s) {
 
 extern "C" {
 
+int ss_comm_destroy(ss_engine* e);
 const char* ss_last_error(void) { return g_err.c_str(); }
 int ss_abi_version(void) { return 1; }
 
@@ -1246,6 +1251,7 @@ ss_engine* ss_create(int kind, const ss_hparams* hp, int max_batch, int max_fram
 void ss_destroy(ss_engine* e) {
     if (!e) return;
     drop_graphs(e);
+    if (e->comm) (void)ss_comm_destroy(e);
     if (e->sticky) {
         (void)hipDeviceSynchronize();
         (void)hipHostFree(e->sticky);
@@ -1503,13 +1509,21 @@ int ss_g3_train_step(ss_engine* e, const float* mel, const float* f0, const floa
     CHK(sticky_check(e));
     Own own(e, stream);
     hipStream_t s = own.s;
+    if (flags & SS_STEP_BUCKET) {      // this batch's length bucket: the step runs with max_len_pad = T
+        if (T < 8 || T > e->maxT || T % 8) return fail("SS_STEP_BUCKET: T must be a multiple of 8 within the engine's max_frames");
+        if (e->hp.max_len_pad != T) {
+            e->hp.max_len_pad = T;
+            e->curB = e->curT = 0;     // InterpLnr plans are sized by max_len_pad: carve again
+        }
+    }
     const ss_hparams& h = e->hp;
-    if (T != h.max_len_pad) return fail("training needs T == max_len_pad (model.py:105,157,370)");
+    if (T != h.max_len_pad) return fail("training needs T == max_len_pad (model.py:105,157,370); pass SS_STEP_BUCKET for a length-bucketed batch");
     CHK(geometry(e, B, T, s));
     if (e->graph_epoch != g_tune_epoch) {
         drop_graphs(e);
         e->graph_epoch = g_tune_epoch;
     }
+    flags &= ~SS_STEP_BUCKET;
     if (!g_graph || (flags & SS_STEP_SPLIT_BACKWARD)) return g3_step_body(e, mel, f0, emb, len_org, scales, len_seg, B, T, grad_scale, flags, loss, s);
 
     // stage the caller's inputs, then replay (or first capture) the step on engine-owned addresses.  All of it runs on
@@ -1579,6 +1593,10 @@ long ss_grad_split(const ss_engine* e) {
 int ss_g6_train_step(ss_engine* e, const float* mel, const float* f0_onehot, const int* target_idx, const float* scales,
                      const int* len_seg, int B, int T, float grad_scale, int flags, float* loss, void* stream) {
     if (e->kind != SS_GENERATOR_6) return fail("ss_g6_train_step on a Generator_3 engine");
+    if ((flags & SS_STEP_BUCKET) && T >= 8 && T <= e->maxT && T % 8 == 0 && e->hp.max_len_pad != T) {
+        e->hp.max_len_pad = T;
+        e->curB = e->curT = 0;
+    }
     Own own(e, stream);
     hipStream_t s = own.s;
     CHK(ss_g6_forward(e, mel, f0_onehot, scales, len_seg, B, T, 1, nullptr, (void*)s));
@@ -1899,6 +1917,132 @@ int ss_debug_names(ss_engine* e, char* buf, int cap) {
         buf[cap - 1] = 0;
     }
     return (int)all.size();
+}
+
+}  // extern "C"
+
+// ================================================================================================ RCCL (data parallel)
+// The reference is single-device (solver.py:38); this is the exchange step of SURVEY.md section 8(e).  RCCL is reached through
+// dlopen: no link-time dependency, and inside a PyTorch process the copy PyTorch already loaded is reused (two RCCL copies in
+// one process would each bring their own bootstrap state).
+namespace {
+
+struct NcclId {
+    char internal[128];
+};
+struct Rccl {
+    void* h = nullptr;
+    int (*GetUniqueId)(NcclId*) = nullptr;
+    int (*CommInitRank)(void**, int, NcclId, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load() {
+    if (g_rccl.h) return 0;
+    void* h = nullptr;
+    for (const char* n : {"librccl.so", "librccl.so.1"})
+        if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);                     // already in the process (PyTorch's)?
+    for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+        if (!h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return fail(std::string("RCCL not found: ") + dlerror());
+    Rccl r;
+    r.h = h;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.AllReduce = (decltype(r.AllReduce))dlsym(h, "ncclAllReduce");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString) return fail("RCCL: missing symbols");
+    g_rccl = r;
+    return 0;
+}
+#define NCCLCHK(x)                                                                          \
+    do {                                                                                    \
+        int _r = (x);                                                                       \
+        if (_r != 0) return fail(std::string(#x) + ": " + g_rccl.GetErrorString(_r));       \
+    } while (0)
+
+int allreduce_range(ss_engine* e, long off, long count, hipStream_t st) {
+    if (!e->comm) return fail("no communicator: call ss_comm_init first");
+    if (off < 0 || count < 0 || off + count > e->arena) return fail("ss_allreduce_grads: range outside the gradient arena");
+    if (count == 0) return 0;
+    NCCLCHK(g_rccl.AllReduce(e->G + off, e->G + off, (size_t)count, /*ncclFloat*/ 7, /*ncclSum*/ 0, e->comm, st));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ss_comm_unique_id(char* id128) {
+    if (!id128) return fail("ss_comm_unique_id: null pointer");
+    CHK(rccl_load());
+    NcclId id;
+    NCCLCHK(g_rccl.GetUniqueId(&id));
+    std::memcpy(id128, id.internal, 128);
+    return 0;
+}
+
+int ss_comm_init(ss_engine* e, const char* id128, int rank, int world) {
+    if (!e || !id128 || world < 1 || rank < 0 || rank >= world) return fail("ss_comm_init: bad arguments");
+    if (!e->G) return fail("ss_comm_init: engine is not bound");
+    if (e->comm) return fail("ss_comm_init: the engine already has a communicator");
+    CHK(rccl_load());
+    NcclId id;
+    std::memcpy(id.internal, id128, 128);
+    void* c = nullptr;
+    NCCLCHK(g_rccl.CommInitRank(&c, world, id, rank));
+    e->comm = c;
+    e->comm_rank = rank;
+    e->comm_world = world;
+    return 0;
+}
+
+int ss_comm_destroy(ss_engine* e) {
+    if (e && e->comm) {
+        (void)hipDeviceSynchronize();
+        NCCLCHK(g_rccl.CommDestroy(e->comm));
+        e->comm = nullptr;
+        e->comm_world = 1;
+    }
+    return 0;
+}
+
+int ss_allreduce_grads(ss_engine* e, long offset, long count, void* stream) {
+    Own own(e, stream);
+    return allreduce_range(e, offset, count, own.s);
+}
+
+int ss_g3_dp_train_step(ss_engine* e, const float* mel, const float* f0, const float* emb, const int* len_org, const float* scales,
+                        const int* len_seg, int B, int T, float* loss, void* stream) {
+    if (e->kind != SS_GENERATOR_3) return fail("ss_g3_dp_train_step on a Generator_6 engine");
+    if (!e->comm) return fail("ss_g3_dp_train_step: call ss_comm_init first");
+    if (T != e->hp.max_len_pad) return fail("training needs T == max_len_pad (model.py:105,157,370)");
+    CHK(sticky_check(e));
+    Own own(e, stream);
+    hipStream_t s = own.s;
+    CHK(geometry(e, B, T, s));
+    const long k = ss_grad_split(e);
+    const float gs = 1.0f / (float)e->comm_world;
+    if (!e->side || !g_overlap) {           // no branch streams: the plain step, one collective over the whole arena behind it
+        CHK(g3_step_body(e, mel, f0, emb, len_org, scales, len_seg, B, T, 1.0f, SS_STEP_NO_ADAM, loss, s));
+        CHK(allreduce_range(e, 0, e->arena, s));
+        return adam_enqueue(e, gs, s);
+    }
+    // forward + decoder backward exactly as in the one-GPU step; the decoder's weight-gradient GEMMs are on the side stream
+    CHK(g3_step_body(e, mel, f0, emb, len_org, scales, len_seg, B, T, 1.0f, SS_STEP_NO_ADAM | SS_STEP_SPLIT_BACKWARD | SS_STEP_SPLIT_NO_JOIN, loss, s));
+    // bucket 1 = head + decoder + status slot (80 % of the bytes, final first): reduced ON the side stream, i.e. behind those GEMMs
+    // by stream order and behind the decoder chain by ev_dec[0]; it runs while the encoder backward executes on the main stream
+    HIPCHK(hipStreamWaitEvent(e->side, e->ev_dec[0], 0));
+    e->dec_pending = 0;
+    CHK(allreduce_range(e, k, e->arena - k, e->side));
+    e->side_used = true;                                    // backward_encoder joins the side stream at its end
+    CHK(backward_encoder(e, s));
+    CHK(allreduce_range(e, 0, k, s));                       // bucket 2 = the encoder
+    return adam_enqueue(e, gs, s);                          // the mean is folded into the Adam kernel
 }
 
 }  // extern "C"

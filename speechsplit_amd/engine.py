@@ -139,14 +139,15 @@ class Engine:
         _capi.check(self.lib.ss_g3_rhythm(self.h, _ptr(x_org), B, T, _ptr(codes), _stream()))
         return codes
 
-    def g3_train_step(self, mel, f0, emb, len_org, draws, grad_scale=1.0, no_adam=False, split_backward=False):
+    def g3_train_step(self, mel, f0, emb, len_org, draws, grad_scale=1.0, no_adam=False, split_backward=False, bucket=False):
         """solver.py:160-172 fused.  split_backward: return after the decoder + head gradients (arena offsets >=
-        self.grad_split) are complete; train_finish() then runs the encoder backward (data-parallel overlap)."""
+        self.grad_split) are complete; train_finish() then runs the encoder backward (data-parallel overlap).
+        bucket: the batch's frame count is its length bucket and the step runs with max_len_pad = T (SS_STEP_BUCKET)."""
         B, T, _ = mel.shape
         mel, f0, emb, len_org = self._f(mel), self._f(f0), self._f(emb), self._i(len_org)
         sc, ls = self._draws(draws)
         assert sc.shape[0] == 4 and ls.shape[0] == 4
-        flags = (1 if no_adam else 0) | (2 if split_backward else 0)
+        flags = (1 if no_adam else 0) | (2 if split_backward else 0) | (16 if bucket else 0)
         _capi.check(self.lib.ss_g3_train_step(self.h, _ptr(mel), _ptr(f0), _ptr(emb), _ptr(len_org), _ptr(sc), _ptr(ls),
                                               B, T, float(grad_scale), flags, _ptr(self.loss), _stream()))
         return self.loss
@@ -158,59 +159,95 @@ class Engine:
     def grad_split(self):
         return int(self.lib.ss_grad_split(self.h))
 
-    def dp_train_step(self, mel, f0, emb, len_org, draws, world, group=None, schedule='overlap'):
-        """One data-parallel step on this rank's shard: backward, RCCL sum of the gradient arena, the same Adam update on
-        every rank with the 1/world mean folded in.
+    def dp_train_step(self, mel, f0, emb, len_org, draws, world, group=None, schedule='overlap', bucket=False):
+        """One data-parallel Generator_3 step on this rank's shard: backward, sum of the gradient arena over the ranks in the
+        two buckets of dist.bucket_plan (decoder + head + status slot first, then the encoder), the same Adam update on every
+        rank with the 1/world mean folded in.  Collectives: torch.distributed (backend 'nccl' = RCCL); the native path without
+        PyTorch in the data path is dp_train_step_native.
 
-        schedule='overlap' (default): two buckets -- decoder + head (80 % of the bytes, final first), then the encoder.
-            The backward is enqueued exactly as in the one-GPU step (SS_STEP_SPLIT_NO_JOIN: the decoder's weight-gradient
-            GEMMs run on an engine stream beside the encoder backward); the first bucket is reduced FROM THAT ENGINE
-            STREAM, i.e. behind those GEMMs by construction, and runs while the rest of the encoder backward executes.
-            World 1: +0.02 ms over the fused step.
-        schedule='after': the one-GPU step unchanged, one all-reduce of the whole arena (78 MB) behind it; nothing hidden.
-        schedule='join': SS_STEP_SPLIT_BACKWARD joins the engine streams, first bucket reduced right away (+0.6 ms: the
-            decoder's weight-gradient GEMMs then run alone instead of beside the encoder backward).
-        Why the engine's own stream: HIP streams share 4 hardware queues.  A collective launched from a separate
-        communication stream waits for its bucket at the head of whatever queue that stream was mapped to and holds the
-        compute stream sharing it back -- measured +0.4 .. +0.6 ms per step on one MI355X for 3 of 4 queue positions
-        (tools/rccl_queue_effect.py); on the stream it has to follow anyway it costs nothing."""
-        import torch.distributed as dist
+        schedule='overlap' (default): the backward is enqueued exactly as in the one-GPU step (SS_STEP_SPLIT_NO_JOIN: the
+            decoder's weight-gradient GEMMs stay on an engine stream beside the encoder backward); the first bucket's
+            all-reduce is issued from a stream ordered behind the decoder chain and those GEMMs, BEFORE the encoder backward is
+            enqueued, so it can run beside it.  (ProcessGroupNCCL launches the collective on its own internal stream, which
+            first waits for the stream the call was issued from.)  Unmeasured at world > 1 on hardware: the one-GPU boxes this
+            was developed on elide the collective.
+        schedule='after': the one-GPU step unchanged, then the buckets; nothing hidden.
+        schedule='join': SS_STEP_SPLIT_BACKWARD joins the engine streams, first bucket reduced right away (+0.6 ms at world 1:
+            the decoder's weight-gradient GEMMs then run alone instead of beside the encoder backward)."""
+        from . import dist as D
         k = self.grad_split
+        plan = D.bucket_plan(self.grads.numel(), k)
         side = self.lib.ss_side_stream(self.h) if schedule == 'overlap' else None
         if schedule == 'overlap' and not side:
             schedule = 'after'                         # engine without branch streams
-        if schedule == 'after':                        # nothing to overlap with: one collective over the whole arena
-            self.g3_train_step(mel, f0, emb, len_org, draws, no_adam=True)
-            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=group, async_op=True).wait()
-            self.adam_step(1.0 / world)
-            return self.loss
+        if schedule == 'after':
+            self.g3_train_step(mel, f0, emb, len_org, draws, no_adam=True, bucket=bucket)
+            handles = [D.reduce_bucket(self.grads, lo, hi, group) for lo, hi in plan]
         elif schedule == 'join':
-            self.g3_train_step(mel, f0, emb, len_org, draws, no_adam=True, split_backward=True)
-            h1 = dist.all_reduce(self.grads[k:], op=dist.ReduceOp.SUM, group=group, async_op=True)
+            self.g3_train_step(mel, f0, emb, len_org, draws, no_adam=True, split_backward=True, bucket=bucket)
+            handles = [D.reduce_bucket(self.grads, *plan[0], group)]
             self.train_finish(no_adam=True)
+            handles.append(D.reduce_bucket(self.grads, *plan[1], group))
         elif schedule == 'overlap':
             sc, ls = self._draws(draws)
             B, T, _ = mel.shape
             mel, f0, emb, len_org = self._f(mel), self._f(f0), self._f(emb), self._i(len_org)
             # SS_STEP_NO_ADAM | SS_STEP_SPLIT_BACKWARD | SS_STEP_SPLIT_NO_JOIN
             _capi.check(self.lib.ss_g3_train_step(self.h, _ptr(mel), _ptr(f0), _ptr(emb), _ptr(len_org), _ptr(sc), _ptr(ls),
-                                                  B, T, 1.0, 1 | 2 | 4, _ptr(self.loss), _stream()))
+                                                  B, T, 1.0, 1 | 2 | 4 | (16 if bucket else 0), _ptr(self.loss), _stream()))
             if getattr(self, '_side_stream', None) is None:
                 self._side_stream = torch.cuda.ExternalStream(side, device=self.device)
             cs = self._side_stream
-            # the engine stream already follows the decoder chain and carries its weight gradients; this also orders it
-            # behind the chain's last kernel explicitly (and must precede the encoder backward: a cross-stream wait on ROCm
-            # covers what the other stream holds when it is issued)
+            # order the issuing stream behind the decoder chain and its weight-gradient GEMMs; this must precede the encoder
+            # backward (a cross-stream wait on ROCm covers what the other stream holds when it is issued)
             _capi.check(self.lib.ss_wait_decoder_grads(self.h, C.c_void_p(cs.cuda_stream)))
-            self.train_finish(no_adam=True)
             with torch.cuda.stream(cs):
-                h1 = dist.all_reduce(self.grads[k:], op=dist.ReduceOp.SUM, group=group, async_op=True)
+                handles = [D.reduce_bucket(self.grads, *plan[0], group)]
+            self.train_finish(no_adam=True)
+            handles.append(D.reduce_bucket(self.grads, *plan[1], group))
         else:
             raise ValueError(f'unknown data-parallel schedule {schedule!r}')
-        h2 = dist.all_reduce(self.grads[:k], op=dist.ReduceOp.SUM, group=group, async_op=True)
-        h1.wait()                                  # the current stream waits for the collectives
-        h2.wait()
+        for h in handles:
+            if h is not None:
+                h.wait()                               # the current stream waits for the collectives
         self.adam_step(1.0 / world)
+        return self.loss
+
+    def dp_g6_train_step(self, mel, f0_onehot, target_idx, draws, world, group=None):
+        """Data-parallel Generator_6 step (BASELINE config 4): the arena is 14 MB, one pass of the bucket plan behind the backward."""
+        from . import dist as D
+        self.g6_train_step(mel, f0_onehot, target_idx, draws, no_adam=True)
+        D.reduce_arena(self.grads, self.grad_split, group)
+        self.adam_step(1.0 / world)
+        return self.loss
+
+    # ---- native RCCL (no PyTorch in the data path): ss_comm_* / ss_g3_dp_train_step of the C ABI
+    def comm_init(self, rank=0, world=1, group=None):
+        """Create this engine's RCCL communicator.  Rank 0 draws the 128-byte id; with world > 1 it is handed round through the
+        already initialised torch.distributed group (any backend: it is 128 bytes of bootstrap, not data)."""
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            _capi.check(self.lib.ss_comm_unique_id(buf))
+        if world > 1:
+            import torch.distributed as dist
+            box = [bytes(buf.raw)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            buf = C.create_string_buffer(box[0], 128)
+        _capi.check(self.lib.ss_comm_init(self.h, buf, int(rank), int(world)))
+        self.comm_world = int(world)
+
+    def allreduce_grads(self, lo=0, hi=None):
+        hi = self.grads.numel() if hi is None else hi
+        _capi.check(self.lib.ss_allreduce_grads(self.h, int(lo), int(hi - lo), _stream()))
+
+    def dp_train_step_native(self, mel, f0, emb, len_org, draws):
+        """ss_g3_dp_train_step: the overlapped two-bucket schedule with the collectives launched by the engine itself, the
+        decoder bucket ON the engine stream that carries the decoder's weight-gradient GEMMs."""
+        B, T, _ = mel.shape
+        mel, f0, emb, len_org = self._f(mel), self._f(f0), self._f(emb), self._i(len_org)
+        sc, ls = self._draws(draws)
+        _capi.check(self.lib.ss_g3_dp_train_step(self.h, _ptr(mel), _ptr(f0), _ptr(emb), _ptr(len_org), _ptr(sc), _ptr(ls), B, T,
+                                                 _ptr(self.loss), _stream()))
         return self.loss
 
     # ------------------------------------------------------------------ Generator_6
@@ -227,12 +264,12 @@ class Engine:
         d_out = self._f(d_out)
         _capi.check(self.lib.ss_g6_backward(self.h, _ptr(d_out), _stream()))
 
-    def g6_train_step(self, mel, f0_onehot, target_idx, draws, grad_scale=1.0, no_adam=False):
+    def g6_train_step(self, mel, f0_onehot, target_idx, draws, grad_scale=1.0, no_adam=False, bucket=False):
         B, T, _ = mel.shape
         mel, f0_onehot, target_idx = self._f(mel), self._f(f0_onehot), self._i(target_idx)
         sc, ls = self._draws(draws)
         _capi.check(self.lib.ss_g6_train_step(self.h, _ptr(mel), _ptr(f0_onehot), _ptr(target_idx), _ptr(sc), _ptr(ls), B, T,
-                                              float(grad_scale), 1 if no_adam else 0, _ptr(self.loss), _stream()))
+                                              float(grad_scale), (1 if no_adam else 0) | (16 if bucket else 0), _ptr(self.loss), _stream()))
         return self.loss
 
     # ------------------------------------------------------------------ optimiser / misc

@@ -112,18 +112,23 @@ class Solver(object):
     # ---- one iteration of solver.py:141-172 on a collated batch
     def train_on_batch(self, batch, draws=None):
         x_real_org, emb_org, f0_org, len_org = batch
-        Bg = x_real_org.shape[0]
+        per_rank = getattr(self.vcc_loader, 'per_rank', False)       # the loader already produced this rank's shard
+        Bg = x_real_org.shape[0] * (self.world if per_rank else 1)
         if draws is None:
             draws = draw_interp(Bg, 4, self.hparams)                 # same generator calls, same order as the reference
         if self.world > 1:
-            x_real_org, emb_org, f0_org, len_org = _dist.shard_batch(batch, self.rank, self.world)
+            if not per_rank:
+                x_real_org, emb_org, f0_org, len_org = _dist.shard_batch(batch, self.rank, self.world)
             draws = _dist.shard_draws(draws[0], draws[1], Bg, self.rank, self.world)
         to = dict(device=self.device, non_blocking=True)
+        # a batch whose frame count is not hparams.max_len_pad is a length bucket (speechsplit_amd/buckets.py): max_len_pad = T
+        bucket = x_real_org.shape[1] != self.hparams.max_len_pad
         if self.world > 1:
             loss = self.eng.dp_train_step(x_real_org.to(**to), f0_org.to(**to), emb_org.to(**to), len_org.to(**to), draws,
-                                          self.world)
+                                          self.world, bucket=bucket)
         else:
-            loss = self.eng.g3_train_step(x_real_org.to(**to), f0_org.to(**to), emb_org.to(**to), len_org.to(**to), draws)
+            loss = self.eng.g3_train_step(x_real_org.to(**to), f0_org.to(**to), emb_org.to(**to), len_org.to(**to), draws,
+                                          bucket=bucket)
         self.step_count += 1
         return loss
 
