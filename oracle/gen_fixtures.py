@@ -294,6 +294,20 @@ def main():
               open(os.path.join(GOLD, 'g6_train.json'), 'w'))
     np.save(os.path.join(GOLD, 'g6_train_logits.npy'), logits.detach().numpy())
 
+    # ---------------------------------------------------------------- S0: the collator (input contract of the hot path)
+    # reference data_loader.py:101-128.  As shipped, MyCollator.__call__ stops at a stray `pdb.set_trace()` with no `import pdb`
+    # (data_loader.py:108); a no-op `pdb` object is put into the module's namespace so the remaining statements
+    # -- crop, clip, pad -- run as written.  Inputs: items 0..5 of speechsplit_amd.data_loader.SyntheticUtterances(12, seed=3)
+    # (numpy's frozen RandomState stream) under np.random.seed(5).
+    import data_loader as ref_dl
+    ref_dl.pdb = types.SimpleNamespace(set_trace=lambda: None)
+    from speechsplit_amd import data_loader as DL
+    ds = DL.SyntheticUtterances(12, seed=3)
+    np.random.seed(5)
+    cm, ce, cf, cl = ref_dl.MyCollator(W.default_hparams())([ds[i] for i in range(6)])
+    np.savez_compressed(os.path.join(GOLD, 'collate.npz'), mel=cm.numpy(), emb=ce.numpy(), f0=cf.numpy(), len_org=cl.numpy(),
+                        corpus_seed=np.int64(3), corpus_n=np.int64(12), items=np.arange(6), np_seed=np.int64(5))
+
     # ---------------------------------------------------------------- reference-init statistics (for the init mirror)
     torch.manual_seed(0)
     M0 = ref_model.Generator_3(W.default_hparams())

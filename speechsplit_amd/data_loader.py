@@ -17,15 +17,19 @@ from torch.utils.data.sampler import Sampler
 
 
 class Utterances(data.Dataset):
-    """train.pkl = list of [speaker, onehot82, relpath...] (make_metadata.py); loads every .npy into RAM."""
+    """train.pkl = list of [speaker, onehot82, relpath...] (make_metadata.py); loads the .npy files into RAM.
 
-    def __init__(self, root_dir, feat_dir, mode):
+    As in the reference, ONE item per train.pkl entry, built from the entry's FIRST listed file (reference data_loader.py:63-64,72
+    reads sbmt[2] only; `len(dataset)` is the number of speakers, :88-90).  all_utterances=True loads every listed file instead
+    (one item per file) -- more data per epoch than the reference sees, so it is opt-in."""
+
+    def __init__(self, root_dir, feat_dir, mode, all_utterances=False):
         self.root_dir, self.feat_dir, self.mode = root_dir, feat_dir, mode
         meta = pickle.load(open(os.path.join(root_dir, 'train.pkl'), 'rb'))
         self.items = []
         for sbmt in meta:
             spk, emb = sbmt[0], sbmt[1]
-            for rel in sbmt[2:]:
+            for rel in (sbmt[2:] if all_utterances else sbmt[2:3]):
                 sp = np.load(os.path.join(root_dir, rel))
                 f0 = np.load(os.path.join(feat_dir, rel))
                 self.items.append((sp, np.asarray(emb, np.float32), f0))
@@ -68,9 +72,12 @@ class MyCollator(object):
     def __call__(self, batch):
         mels, embs, f0s, lens = [], [], [], []
         for mel, emb, f0 in batch:
-            n = int(np.random.randint(self.min_len_seq, self.max_len_seq + 1))          # data_loader.py:106
+            # the reference draws TWO values each time and uses the first (size=2, data_loader.py:106-107): same generator
+            # consumption here, so the same numpy seed gives the same crops.  (An utterance shorter than the crop makes the
+            # reference raise in randint(0, <= 0); here it is taken whole.)
+            n = int(np.random.randint(self.min_len_seq, self.max_len_seq + 1, size=2)[0])          # data_loader.py:106
             n = min(n, self.max_len_pad)
-            left = int(np.random.randint(0, max(len(mel) - n, 1)))                       # :107
+            left = int(np.random.randint(0, max(len(mel) - n, 1), size=2)[0])                       # :107
             a = np.clip(mel[left:left + n], 0, 1)                                        # :110-113
             c = f0[left:left + n]
             mels.append(np.pad(a, ((0, self.max_len_pad - a.shape[0]), (0, 0)), 'constant'))           # :115
@@ -124,7 +131,7 @@ class DeviceCorpus(object):
 class DeviceBatcher(object):
     """Iterable with the loader's contract -- (melsp [B,192,80], spk_emb [B,82], pitch [B,192,1], len_org int64[B]) -- whose
     batches are assembled ON the GPU from a DeviceCorpus by one kernel (ss_collate).  Per batch the host draws the crops
-    with exactly the collator's generator calls (two ``np.random.randint`` per utterance, data_loader.py:106-107) and sends
+    with exactly the collator's generator calls (two ``np.random.randint(..., size=2)`` per utterance, data_loader.py:106-107) and sends
     3*B integers; no mel / F0 crosses PCIe.  Same seeds + same sampler order => the same batches as MyCollator, bit for bit."""
 
     def __init__(self, hparams, corpus, sampler=None, drop_last=True):
@@ -141,9 +148,9 @@ class DeviceBatcher(object):
         hp, c = self.hp, self.corpus
         row0, lens = [], []
         for i in indices:
-            n = int(np.random.randint(hp.min_len_seq, hp.max_len_seq + 1))
+            n = int(np.random.randint(hp.min_len_seq, hp.max_len_seq + 1, size=2)[0])      # the collator's generator calls (size=2)
             n = min(n, hp.max_len_pad)
-            left = int(np.random.randint(0, max(int(c.lens[i]) - n, 1)))
+            left = int(np.random.randint(0, max(int(c.lens[i]) - n, 1), size=2)[0])
             lens.append(min(n, int(c.lens[i]) - left))
             row0.append(int(c.starts[i]) + left)
         B, T, dev = len(indices), hp.max_len_pad, c.device
@@ -188,6 +195,8 @@ def get_loader(hparams, dataset=None):
             print(f'[speechsplit_amd] {hparams.root_dir}/train.pkl not found: using the synthetic corpus')
             dataset = SyntheticUtterances(max(4 * hparams.batch_size, 64))
     sampler = MultiSampler(len(dataset), hparams.samplier, shuffle=hparams.shuffle)
+    # data_loader.py:165: without it every worker process inherits the same numpy state and produces identical crops
+    worker_init_fn = lambda x: np.random.seed((torch.initial_seed()) % (2 ** 32))
     return data.DataLoader(dataset=dataset, batch_size=hparams.batch_size, sampler=sampler,
                            num_workers=hparams.num_workers, drop_last=True, pin_memory=torch.cuda.is_available(),
-                           collate_fn=MyCollator(hparams))
+                           worker_init_fn=worker_init_fn, collate_fn=MyCollator(hparams))

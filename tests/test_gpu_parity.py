@@ -202,6 +202,19 @@ def test_device_batcher_equals_host_collator(E):
     assert n == len(batcher) == len(ds) * hp.samplier // hp.batch_size
 
 
+def test_device_batcher_against_reference_collator_fixture(E):
+    """The batch ss_collate assembles from the HBM-resident corpus equals the REFERENCE collator's batch (tests/golden/collate.npz)
+    for the same items under the same numpy seed."""
+    from speechsplit_amd import data_loader as DL, hparams as HPM
+    z = np.load(os.path.join(GOLD, 'collate.npz'))
+    ds = DL.SyntheticUtterances(int(z['corpus_n']), seed=int(z['corpus_seed']))
+    batcher = DL.DeviceBatcher(HPM.default_hparams(batch_size=6), DL.DeviceCorpus(ds, 'cuda'))
+    np.random.seed(int(z['np_seed']))
+    mel, emb, f0, ln = batcher.assemble([int(i) for i in z['items']])
+    assert np.array_equal(mel.cpu().numpy(), z['mel']) and np.array_equal(emb.cpu().numpy(), z['emb'])
+    assert np.array_equal(f0.cpu().numpy(), z['f0']) and np.array_equal(ln.cpu().numpy(), z['len_org'])
+
+
 def test_eval_forward_ragged_batch(E):
     """B not a multiple of the 16-utterance LSTM tile, T below max_len_pad (eval works at any T % 8 == 0)."""
     hp = W.default_hparams()

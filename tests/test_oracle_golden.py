@@ -258,3 +258,17 @@ def test_relu_mask_override_is_neutral_with_own_branches():
         assert ref_model.MASK_STATS['enc2.c'][0] == 1 and ref_model.MASK_STATS['enc2.c'][1] > 0
     finally:
         ref_model.MASK, ref_model.MASK_STATS = None, None
+
+
+def test_collator_against_reference_fixture(gold_dir):
+    """speechsplit_amd.data_loader.MyCollator against the REFERENCE collator's output
+    (tests/golden/collate.npz, generated by oracle/gen_fixtures.py from reference data_loader.py:101-128): same numpy seed,
+    same items -> the same crops, clipping, padding (mel with 0, F0 with -1e10) and lengths, bit for bit."""
+    from speechsplit_amd import data_loader as DL, hparams as HPM
+    z = np.load(os.path.join(gold_dir, 'collate.npz'))
+    ds = DL.SyntheticUtterances(int(z['corpus_n']), seed=int(z['corpus_seed']))
+    np.random.seed(int(z['np_seed']))
+    mel, emb, f0, ln = DL.MyCollator(HPM.default_hparams())([ds[int(i)] for i in z['items']])
+    assert mel.dtype == torch.float32 and ln.dtype == torch.int64 and f0.shape == (6, 192, 1)
+    assert np.array_equal(mel.numpy(), z['mel']) and np.array_equal(emb.numpy(), z['emb'])
+    assert np.array_equal(f0.numpy(), z['f0']) and np.array_equal(ln.numpy(), z['len_org'])
