@@ -180,6 +180,13 @@ int ss_op_lstm_fwd(float* gates_dev, const float* whh_f_dev, const float* whh_b_
 /* BPTT of the same: d_out [B,T+4,2H]; gates is replaced by the pre-activation gradients. */
 int ss_op_lstm_bwd(float* gates_dev, const float* whh_f_dev, const float* whh_b_dev, const float* d_out_dev,
                    const float* csave_dev, float* scratch_dev, long scratch_floats, int B, int T, int H, void* stream);
+/* The pre-split ("planes") GEMM: fp32 [rows][cols] -> two fp16 planes of the fp16 x 2 split (scale a power of two; transpose != 0:
+ * planes [cols][ldp] with the source rows along the contiguous axis), zero-padded to a multiple of 32 along the contiguous axis;
+ * and C[M,N] (+)= A . B^T over such planes (K % 32 == 0, lda / ldb in fp16 elements, multiples of 8), unscale = 1 / (sa * sb). */
+int ss_op_split_planes(const float* src_dev, long ld, int rows, int cols, int transpose, float scale, void* plane_h_dev, void* plane_l_dev,
+                       long ldp, void* stream);
+int ss_op_gemm_planes(const void* ah_dev, const void* al_dev, long lda, const void* bh_dev, const void* bl_dev, long ldb, float* c_dev,
+                      long ldc, const float* bias_dev, int M, int N, int K, int ksplit, float unscale, void* stream);
 /* One relu(GroupNorm(ConvNorm(x))) block (model.py:61-67,76-77; 16 channels per group) through the engine's own block
  * routines, forward and -- when dy is given -- backward.  x [B,T,Ci], w [Co,Ci,5], bias/gamma/beta [Co], y/dy [B,T,Co],
  * dx [B,T,Ci] (nullable), gw [Co,Ci,5], gb/ggamma/gbeta [Co]; scratch of ss_op_conv_block_scratch() floats. */

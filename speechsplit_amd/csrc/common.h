@@ -48,6 +48,29 @@ struct GemmDesc {
 // C[b][m][n] (+)= sum_k A(m,k) * B(n,k) (+ bias[n]);  fp32 in, fp32 MFMA accumulate (exact fp32 fma chain)
 hipError_t launch_gemm(const GemmDesc& d, hipStream_t stream);
 
+// ---- gemm_planes.hip: the same contraction over operands that are ALREADY split into fp16 hi / lo planes, K-contiguous ----
+struct PlanesDesc {
+    const _Float16 *ah, *al, *bh, *bl;      // A planes [M][lda], B planes [N][ldb] (fp16 elements), K % 32 == 0
+    long lda, ldb, a_bs, b_bs;              // row / batch strides in fp16 elements (multiples of 8)
+    float* c;
+    long ldc, c_bs;
+    const float* bias;                      // per output column, nullable
+    int M, N, K, batch, ksplit, accumulate; // ksplit > 1: fp32 atomics into a zeroed / live C
+    float unscale;                          // 1 / (product of the FIXED scales the planes were split with)
+    const float *amax_a, *amax_b;           // nullable: device words with the measured maximum of an operand that was split with
+                                            // pow2_scale_of(maximum); the result is divided by those scales as well
+    int diag;                               // SS_DIAG builds only (timing ablations, wrong results)
+    int row_period, row_lo, row_hi;         // row_period > 0: store only rows with row % row_period in [row_lo, row_hi) (slab halos)
+};
+hipError_t launch_gemm_planes(const PlanesDesc& d, hipStream_t s);
+// fp32 [rows][cols] (row stride ld) -> planes [rows][ldp], zero-filled up to the next multiple of 32 columns.  Scale:
+// pow2_scale_of(*amax) when amax is given (a device word), else fixed_scale.
+hipError_t split_planes(const float* src, long ld, int rows, int cols, const float* amax, float fixed_scale, void* ph, void* pl, long ldp,
+                        hipStream_t s);
+// transposing: -> planes [cols][ldp] with the source ROWS along the contiguous axis (zero-filled up to a multiple of 32 rows)
+hipError_t split_planes_t(const float* src, long ld, int rows, int cols, const float* amax, float fixed_scale, void* ph, void* pl, long ldp,
+                          hipStream_t s);
+
 // phase probe of the bf16x3 kernel (timing experiments): 4 waves x {5 phases, k-tile count} tick sums; see gemm_bf16x3.hip
 hipError_t gemm_phase_probe(unsigned long long out[24], bool reset);
 
@@ -55,6 +78,14 @@ hipError_t gemm_phase_probe(unsigned long long out[24], bool reset);
 // tanhf (range reduction, branches) cost a few hundred cycles per step; these use the hardware exp2 / rcp.  Absolute error
 // <= 2e-7 (sigmoid) and <= 3e-7 (tanh, with a series below |x| = 0.08 where the quotient form would cancel).
 #ifdef __HIPCC__
+// operand with a measured maximum m: the power of two that brings m into [128, 256) (256x headroom below fp16's 65504), capped
+// so that an all-zero / denormal tensor cannot produce an infinite scale (same rule as gemm_bf16x3.hip's pow2_scale)
+__device__ __forceinline__ float pow2_scale_of(float m) {
+    const int e = (int)((__float_as_uint(m) >> 23) & 0xFFu);
+    int se = 261 - e;
+    se = se < 1 ? 1 : (se > 187 ? 187 : se);
+    return __uint_as_float((unsigned)se << 23);
+}
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a release fence over ALL memory, for which
 // hipcc emits s_waitcnt vmcnt(0): every barrier then also waits for the outstanding global stores / loads of the wave
 // (~1 us each trip).  In the recurrence kernels the step barriers only hand LDS data between waves; what leaves for

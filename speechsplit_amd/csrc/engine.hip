@@ -1665,6 +1665,37 @@ int ss_op_gemm(const float* a, long lda, const float* b, long ldb, float* c, lon
     return 0;
 }
 
+int ss_op_split_planes(const float* src, long ld, int rows, int cols, int transpose, float scale, void* plane_h, void* plane_l, long ldp,
+                       void* stream) {
+    if (!src || !plane_h || !plane_l) return fail("ss_op_split_planes: null pointer");
+    HIPCHK(transpose ? split_planes_t(src, ld, rows, cols, nullptr, scale, plane_h, plane_l, ldp, S(stream))
+                     : split_planes(src, ld, rows, cols, nullptr, scale, plane_h, plane_l, ldp, S(stream)));
+    return 0;
+}
+
+int ss_op_gemm_planes(const void* ah, const void* al, long lda, const void* bh, const void* bl, long ldb, float* c, long ldc,
+                      const float* bias, int M, int N, int K, int ksplit, float unscale, void* stream) {
+    PlanesDesc d{};
+    d.ah = (const _Float16*)ah;
+    d.al = (const _Float16*)al;
+    d.bh = (const _Float16*)bh;
+    d.bl = (const _Float16*)bl;
+    d.lda = lda;
+    d.ldb = ldb;
+    d.c = c;
+    d.ldc = ldc;
+    d.bias = bias;
+    d.M = M;
+    d.N = N;
+    d.K = K;
+    d.batch = 1;
+    d.ksplit = ksplit < 1 ? 1 : ksplit;
+    d.unscale = unscale;
+    d.diag = g_gemm_diag;
+    HIPCHK(launch_gemm_planes(d, S(stream)));
+    return 0;
+}
+
 int ss_set_precision(ss_engine* e, int precision) {
     if (!e) return fail("ss_set_precision: null engine");
     if (precision != SS_PRECISION_F32 && precision != SS_PRECISION_BF16) return fail("ss_set_precision: unknown precision");

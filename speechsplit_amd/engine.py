@@ -369,6 +369,32 @@ class Engine:
         return flat.view(B, T + 4, cols.value)[:, 2:2 + T].clone()
 
 
+def split_planes(x, transpose=False, scale=16.0):
+    """Test hook (ss_op_split_planes): fp32 [rows, cols] -> (hi, lo) fp16 planes, [rows, pad32(cols)] or, transposed,
+    [cols, pad32(rows)]."""
+    lib = _capi.lib()
+    rows, cols = x.shape
+    x = x.contiguous()
+    shape = (cols, (rows + 31) // 32 * 32) if transpose else (rows, (cols + 31) // 32 * 32)
+    ph = torch.zeros(shape, dtype=torch.float16, device=x.device)
+    pl = torch.zeros(shape, dtype=torch.float16, device=x.device)
+    _capi.check(lib.ss_op_split_planes(_ptr(x), x.stride(0), rows, cols, int(transpose), float(scale), _ptr(ph), _ptr(pl), shape[1], _stream()))
+    return ph, pl
+
+
+def gemm_planes(a_planes, b_planes, M, N, bias=None, ksplit=1, scale_a=16.0, scale_b=16.0, out=None):
+    """Test hook (ss_op_gemm_planes): C[M,N] = A . B^T over pre-split planes ([M, Kp] and [N, Kp])."""
+    lib = _capi.lib()
+    ah, al = a_planes
+    bh, bl = b_planes
+    K = ah.shape[1]
+    assert bh.shape[1] == K
+    c = torch.zeros(M, N, device=ah.device) if out is None else out
+    _capi.check(lib.ss_op_gemm_planes(_ptr(ah), _ptr(al), ah.stride(0), _ptr(bh), _ptr(bl), bh.stride(0), _ptr(c), N, _ptr(bias), M, N, K,
+                                      int(ksplit), 1.0 / (scale_a * scale_b), _stream()))
+    return c
+
+
 def conv_block(x, w, bias, gamma, beta, dy=None, need_dx=True):
     """Test hook (ss_op_conv_block): relu(GroupNorm(conv5(x))) of one block through the engine's block routines.
     x [B,T,Ci] -> y [B,T,Co]; with dy also (dx, gw, gb, ggamma, gbeta)."""

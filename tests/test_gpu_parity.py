@@ -683,3 +683,17 @@ def test_solver_validation_path_and_prefetcher(E, tmp_path):
     assert mel.is_cuda and mel.shape == (2, 192, 80) and ln.dtype == torch.int64
     s.validation_pt = val
     s.train()                       # one iteration + validation print through the prefetcher
+
+
+def test_planes_gemm_against_fp64(E):
+    """gemm_planes.hip (pre-split fp16 x 2 operands, LDS-DMA, 256 x 256 tiles; parked -- not on the product path yet, see
+    DESIGN.md): the same fp32-grade result as the in-loop-split kernel, from row-major and from transposed sources."""
+    g = torch.Generator().manual_seed(11)
+    for M, N, K, ks in [(300, 200, 100, 1), (1000, 520, 1024, 1), (512, 512, 4096, 4)]:
+        A = torch.randn(M, K, generator=g).cuda()
+        Bm = (torch.randn(N, K, generator=g) * 0.05).cuda()
+        bias = torch.randn(N, generator=g).cuda() if ks == 1 else None
+        ref = A.double() @ Bm.double().t() + (bias.double() if bias is not None else 0)
+        c = E.gemm_planes(E.split_planes(A), E.split_planes(Bm), M, N, bias, ks)
+        ct = E.gemm_planes(E.split_planes(A.t().contiguous(), transpose=True), E.split_planes(Bm.t().contiguous(), transpose=True), M, N, bias, ks)
+        assert rel(c, ref) < 5e-6 and rel(ct, ref) < 5e-6, (M, N, K, ks)
