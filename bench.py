@@ -131,9 +131,9 @@ def kernel_report(eng, steps, ms_step, precision, top, survey, T):
              'conv_dx': 'gemm_bf16x3_kernel<.,.,NT> segmented-K: conv input gradients'}
     traffic = None
     try:      # HBM bytes per launch from the separate rocprofv3 --pmc passes kept under profiles/ (tools/pmc_summary.py)
-        for r in json.load(open(os.path.join(ROOT, 'profiles', 'r02', 'gemm_pmc.json'))):
-            if r.get('class') == top:
-                traffic = r['hbm_read_bytes'] + r['hbm_write_bytes']
+        recs = [r for r in json.load(open(os.path.join(ROOT, 'profiles', 'r02', 'gemm_pmc.json'))) if r.get('class') == top]
+        if recs:      # mean over the shapes of the class (dec_dw: dW_ih and dW_hh, six launches each per step)
+            traffic = sum(r['hbm_read_bytes'] + r['hbm_write_bytes'] for r in recs) / len(recs)
     except Exception:
         pass
     roof = {'bound': 'mfma', 'kernel': names.get(top, top), 'class': top, 'achieved': round(ach, 2), 'peak': round(peak, 1),

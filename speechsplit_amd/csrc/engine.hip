@@ -42,6 +42,7 @@ int g_own_streams = 0; // 1: every C-ABI call runs on the ENGINE's own main stre
                        //    least-loaded of its 4 hardware queues, and which engine stream ends up sharing a queue with the caller's still
                        //    moves the step by 5 % either way (profiles/r02/stream_order_effect.txt: 6.70 - 7.13 ms owned, 6.69 - 7.38 not).
                        //    Off by default until the engine can measure and pick its queue placement.
+int g_early_join = 1;  // 1: join events of branch streams are recorded right behind the last kernel the consumer needs (lstm_bwd's dx_ready)
 int g_tune_epoch = 0;  // bumped by ss_tune: captured graphs bake the knobs in, so they are dropped when it changes
 }
 
@@ -167,6 +168,7 @@ struct ss_engine {
     hipStream_t side3 = nullptr;          // third independent branch of the encoder backward (Encoder_t)
     hipStream_t cap = nullptr;            // graphs are captured and replayed here (a legacy default stream cannot capture)
     hipEvent_t ev_io[2] = {};             // caller stream <-> cap ordering
+    hipEvent_t ev_join[2] = {};           // join events recorded early (see lstm_bwd's dx_ready)
     hipEvent_t ev_dec[2] = {};            // split step without join: decoder chain done (caller stream) / its weight gradients done (side)
     int dec_pending = 0;                  // 0 none, 1 ev_dec[0] only, 2 both
     // captured training steps (hipGraph), keyed by geometry / flags / grad_scale; inputs are staged into engine-owned
@@ -853,7 +855,11 @@ int lstm_input_grad(ss_engine* e, LstmBlk& lb, int l, Slab dxi, long r0, long nr
 }
 
 // d_top: gradient slab of the last layer's output [B,TP,2H]; x: forward input; dx: input-gradient view or null
-int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hipStream_t s) {
+// dx_ready (nullable): recorded on `s` right behind the input-gradient GEMM of layer 0, i.e. BEFORE this block's weight-gradient
+// launches go to their branch stream.  A consumer that waits for it is not held up by whatever else shares a hardware queue with
+// `s`: an event recorded later would sit in that queue behind every packet enqueued in between (measured: the conv trunk's
+// backward idled 0.88 ms behind ~36 tiny weight-gradient launches of a sibling stream, profiles/r02/step_timeline_before.txt).
+int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hipStream_t s, hipEvent_t dx_ready = nullptr) {
     const int B = e->curB, T = e->curT, H = lb.H;
     const long TP = T + 2 * HALO, R = (long)B * TP;
     const float* dcur = d_top;
@@ -921,6 +927,7 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
         if (dxi.p)
             for (int c = 0; c < nch; ++c)
                 CHK(lstm_input_grad(e, lb, l, dxi, (long)ch[c].b0 * TP, nch == 2 ? (long)ch[c].nb * TP : R, am, ch[c].st));
+        if (l == 0 && dx_ready && nch == 1) HIPCHK(hipEventRecord(dx_ready, ch[0].st));
         CHK(lstm_weight_grads(e, lb, l, xi, am, bias_in_kernel, ws));
         dcur = dxi.p;
     }
@@ -1143,12 +1150,14 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
     CHK(zero_conv_grads(e, b2));                   // long done when the first conv weight gradient starts (b2 joins s, b3 forks after)
     if (par) CHK(fork_join(e, b2, b3));
     // encoder BLSTMs -> gradient of the last fused slab
-    CHK(lstm_bwd(e, e->l2, e->d_o2, Slab{e->xf[2] + off2, CE}, Slab{e->d_xf + off2, CE}, b2));
+    const bool early = par && !e->l2.big() && g_early_join;         // the join event of the lstm_2 branch is taken as soon as its last kernel is queued
+    CHK(lstm_bwd(e, e->l2, e->d_o2, Slab{e->xf[2] + off2, CE}, Slab{e->d_xf + off2, CE}, b2, early ? e->ev_join[0] : nullptr));
     if (g3) CHK(lstm_bwd(e, e->l1, e->d_o1, Slab{e->xf[2], CE}, Slab{e->d_xf, CE}, s));
     // Encoder_t
     CHK(lstm_bwd(e, e->lt, e->d_ot, Slab{e->act_t, h.dim_enc_2}, Slab{e->d_act_t, h.dim_enc_2}, b3));
     CHK(conv_block_bwd(e, e->ct, Slab{e->d_act_t, h.dim_enc_2}, Slab{e->org, h.dim_freq}, Slab{nullptr, 0}, b3));
-    if (par) CHK(fork_join(e, b2, s));
+    if (early) HIPCHK(hipStreamWaitEvent(s, e->ev_join[0], 0));
+    else if (par) CHK(fork_join(e, b2, s));
     // conv trunk, last layer first
     for (int i = 2; i >= 0; --i) {
         float* dy = e->d_xf;
@@ -1278,6 +1287,8 @@ void ss_destroy(ss_engine* e) {
                 if (ev) (void)hipEventDestroy(ev);
             for (auto& ev : e->ev_dec)
                 if (ev) (void)hipEventDestroy(ev);
+            for (auto& ev : e->ev_join)
+                if (ev) (void)hipEventDestroy(ev);
             (void)hipStreamDestroy(e->cap);
         }
     }
@@ -1344,6 +1355,7 @@ int ss_bind(ss_engine* e, float* params, float* grads, float* m, float* v, void*
         HIPCHK(hipStreamCreateWithFlags(&e->cap, hipStreamNonBlocking));
         for (auto& ev : e->ev_io) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         for (auto& ev : e->ev_dec) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        for (auto& ev : e->ev_join) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
     AdamState st{};
     st.lr = 1e-4;
@@ -1758,6 +1770,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "gemm_tr" && value >= 0 && value <= 2) g_gemm_tr = value;
     else if (k == "graph" && (value == 0 || value == 1)) g_graph = value;
     else if (k == "own_streams" && (value == 0 || value == 1)) g_own_streams = value;
+    else if (k == "early_join" && (value == 0 || value == 1)) g_early_join = value;
     else if (k == "deterministic" && (value == 0 || value == 1)) g_deterministic = value;
     else if (k == "split" && (value == 0 || value == 1)) g_split = value;
     else if (k == "persist" && (value == 0 || value == 1)) g_persist = value;

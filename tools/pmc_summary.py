@@ -9,6 +9,7 @@ import collections, csv, glob, json, sys
 SHAPES = ['proj NT 8192x4096x1024', 'conv NT 8192x512x2560', 'dX NN 8192x1024x4096', 'dW_ih TN 2048x1024x8448 ks4',
           'dW_hh TN 2048x512x8447 ks8']
 FLOPS = [2.0 * 8192 * 4096 * 1024, 2.0 * 8192 * 512 * 2560, 2.0 * 8192 * 1024 * 4096, 2.0 * 2048 * 1024 * 8448, 2.0 * 2048 * 512 * 8447]
+CLASSES = ['dec_proj', 'conv_fwd', 'dec_dx', 'dec_dw', 'dec_dw']      # bench.py's kernel classes (ss_profile)
 LAUNCHES = 4
 
 
@@ -34,7 +35,7 @@ def main():
         rd, wr = 2.0 * fetch[i]['c']['FETCH_SIZE'] * 1024, write[i]['c']['WRITE_SIZE'] * 1024
         cyc = c['GRBM_GUI_ACTIVE'] / 8.0                                  # summed over the 8 XCDs
         busy = 100.0 * c['SQ_VALU_MFMA_BUSY_CYCLES'] / (cyc * 1024) if 'SQ_VALU_MFMA_BUSY_CYCLES' in c else None
-        rec = {'shape': name, 'kernel': sq[i]['kernel'], 'us': sq[i]['us'], 'tflops': FLOPS[i] / sq[i]['us'] / 1e6,
+        rec = {'shape': name, 'class': CLASSES[i], 'kernel': sq[i]['kernel'], 'us': sq[i]['us'], 'tflops': FLOPS[i] / sq[i]['us'] / 1e6,
                'hbm_read_bytes': rd, 'hbm_write_bytes': wr, 'mfma_busy_pct': busy,
                'lds_bank_conflict_cycles': c.get('SQ_LDS_BANK_CONFLICT'), 'lds_idx_active_cycles': c.get('SQ_LDS_IDX_ACTIVE')}
         out.append(rec)

@@ -2,7 +2,7 @@
 # Regenerates everything kept under profiles/<round>/ on a GPU box: gpurun -- 'bash tools/run_profiles.sh r01'
 # (GPU tests first; later steps only run if the earlier ones succeeded)
 set -e -o pipefail
-R=${1:-r01}
+R=${1:-r02}
 O=gpurun_out/$R
 mkdir -p $O
 export TMPDIR=/tmp
