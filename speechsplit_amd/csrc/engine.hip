@@ -135,6 +135,9 @@ struct ss_engine {
     long ws_bytes = 0;
     int curB = 0, curT = 0;
     bool fwd_training = false;
+    const float *late_org = nullptr, *late_emb = nullptr;   // fused training step: x_org / emb still to be copied in (done on the Encoder_t branch)
+    bool prezero = false;                  // fused training step: zero the gradient arena on a branch stream during the forward
+    bool grads_zeroed = false;             // ... done: backward_decoder must not zero it again
     bool have_fwd = false;
     int enc_plan0 = 0;                     // plan[] index of the first encoder InterpLnr call of the last forward
 
@@ -967,9 +970,16 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
     // only); after the trunk the two encoder BLSTMs run side by side (`s`, `b1`).  Everything joins at the decoder input.
     const bool par = e->side && e->side2 && g_overlap;
     hipStream_t b1 = par ? e->side : s, b2 = par ? e->side2 : s;
+    e->grads_zeroed = false;               // set again below when this forward belongs to a fused training step
     if (g3) CHK(conv_pack_all(e, e->c1[0], s));
     CHK(conv_pack_all(e, e->c2[0], s));
     if (par) CHK(fork_join(e, s, b2));
+    if (e->late_org && !g_graph) {
+        const ss_hparams& hh = e->hp;
+        HIPCHK(copy_rows(e->late_org, hh.dim_freq, (long)T * hh.dim_freq, e->org + HALO * hh.dim_freq, hh.dim_freq, TP * hh.dim_freq, B, T,
+                         hh.dim_freq, b2));
+        if (e->late_emb) HIPCHK(hipMemcpyAsync(e->emb, e->late_emb, (long)B * hh.dim_spk_emb * 4, hipMemcpyDeviceToDevice, b2));
+    }
     for (int i = 1; i < 3; ++i) {
         if (g3) CHK(conv_pack_all(e, e->c1[i], b2));
         CHK(conv_pack_all(e, e->c2[i], b2));
@@ -995,6 +1005,11 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
             CHK(lstm_prep(e, e->lt, tb, b2));
             CHK(lstm_prep(e, e->ld, tb, b2));
             HIPCHK(prep_run(tb, b2));
+            if (e->prezero && !g_graph) {        // nothing touches the gradient arena before the decoder backward; b2 is joined long before
+                HIPCHK(hipMemsetAsync(e->G, 0, e->arena * 4, b2));
+                HIPCHK(hipMemsetAsync(e->amax, 0, 16 * 4, b2));
+                e->grads_zeroed = true;
+            }
             // fp16 x 2 products scale weights and activations by a FIXED 16 (forward and gradient contractions alike), valid while every parameter (weights, GroupNorm affine) stays
             // below 64 in magnitude: weights < 4094 / 16, and |GroupNorm output| <= 64 * sqrt(16 T) + 64 < 4094.  Outside that
             // range (or for a non-finite parameter) the step is marked invalid instead of silently overflowing to inf.
@@ -1066,8 +1081,11 @@ int backward_decoder(ss_engine* e, hipStream_t s) {
     if (!e->have_fwd) return fail("backward without a preceding forward");
     const int B = e->curB, T = e->curT;
     const long TP = T + 2 * HALO, R = (long)B * TP;
-    HIPCHK(hipMemsetAsync(e->G, 0, e->arena * 4, s));
-    HIPCHK(hipMemsetAsync(e->amax, 0, 16 * 4, s));
+    if (!e->grads_zeroed) {
+        HIPCHK(hipMemsetAsync(e->G, 0, e->arena * 4, s));
+        HIPCHK(hipMemsetAsync(e->amax, 0, 16 * 4, s));
+    }
+    e->grads_zeroed = false;
     // fragment-major W_hh^T of the decoder recurrences (overwrites the forward layout, no longer needed), beside the head
     const bool par = e->side2 && g_overlap;
     hipStream_t b2 = par ? e->side2 : s;
@@ -1080,10 +1098,12 @@ int backward_decoder(ss_engine* e, hipStream_t s) {
                 HIPCHK(lstm_pack_w(e->P + e->ld.pd[l * 2].whh, e->P + e->ld.pd[l * 2 + 1].whh, e->ld.wfrag[l], e->ld.H, 1, b2));
         }
     }
-    // head
+    // head.  Only its input gradient is on the critical path; when the decoder's weight gradients are deferred to the side
+    // stream (lstm_bwd), the head's weight / bias gradients go with them instead of running in front of the first recurrence.
     const long HD = 2L * e->ld.H;
     const float* h3 = e->ld.out[e->ld.L - 1];
-    {
+    const bool defer_head = !g_graph && e->ld.big() && g_persist && lstm_seq_supported(B, e->ld.H) && e->side && g_overlap && g_defer_dw;
+    auto head_weight_grads = [&](hipStream_t st) -> int {
         GemmDesc a{};
         a.A = {e->d_out_slab, e->head_out, 0, 0, 0};
         a.B = {h3, HD, 0, 0, 0};
@@ -1095,8 +1115,12 @@ int backward_decoder(ss_engine* e, hipStream_t s) {
         a.batch = 1;
         a.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM;
         a.ksplit = pick_ksplit(a.M, a.N, a.K);
-        PGEMM_ON(SS_PROF_HEAD, a, s);
-        HIPCHK(colsum_acc(e->d_out_slab, e->head_out, (int)R, e->head_out, e->G + e->head_b, s));
+        PGEMM_ON(SS_PROF_HEAD, a, st);
+        HIPCHK(colsum_acc(e->d_out_slab, e->head_out, (int)R, e->head_out, e->G + e->head_b, st));
+        return 0;
+    };
+    {
+        if (!defer_head) CHK(head_weight_grads(s));
         GemmDesc g{};
         g.A = {e->d_out_slab, e->head_out, 0, 0, 0};
         g.B = {e->P + e->head_w, HD, 0, 0, 0};
@@ -1112,6 +1136,7 @@ int backward_decoder(ss_engine* e, hipStream_t s) {
     }
     if (par) CHK(fork_join(e, b2, s));
     CHK(lstm_bwd(e, e->ld, e->d_top, Slab{e->dec_in, e->dec_in_dim}, Slab{e->d_dec_in, e->dec_in_dim}, s));
+    if (defer_head) CHK(head_weight_grads(e->side));      // behind the decoder's weight gradients, ordered after the chain by lstm_bwd's fork
     // every persistent recurrence of the step is behind this point: publish this rank's status into the gradient arena's
     // status slot (part of the decoder bucket, so a data-parallel all-reduce carries it to every rank's Adam kernel)
     if (e->sticky) HIPCHK(status_publish(e->sticky, e->G + e->status_off, s));
@@ -1489,10 +1514,19 @@ static int g3_step_body(ss_engine* e, const float* mel, const float* f0, const f
     HIPCHK(interp_plan(e->plan[0], scales, len_seg, len_org, 0, B, s));
     HIPCHK(interp_quant(e->plan[0], mel, f0, h.dim_freq, e->in_mel + HALO * h.dim_freq, h.dim_freq, TP * h.dim_freq,
                         e->in_f0 + HALO * e->f0p, e->f0p, TP * e->f0p, h.dim_f0, e->qidx, B, s));
-    HIPCHK(copy_rows(mel, h.dim_freq, (long)T * h.dim_freq, e->org + HALO * h.dim_freq, h.dim_freq, TP * h.dim_freq, B, T,
-                     h.dim_freq, s));
-    HIPCHK(hipMemcpyAsync(e->emb, emb, (long)B * h.dim_spk_emb * 4, hipMemcpyDeviceToDevice, s));
-    CHK(forward_core(e, true, scales, len_seg, 1, s));                                      // solver.py:165
+    // x_org and the speaker embedding are first read by Encoder_t / the decoder input: their copies ride on the branch stream
+    e->late_org = mel;
+    e->late_emb = emb;
+    if (g_graph) {      // hipGraph capture keeps round 1's branch structure: each extra parallel branch in the captured step made
+                        // hipGraphLaunch crash inside hip::Graph::UpdateStreams (ROCm 7.2) once the process had run other engines before
+        HIPCHK(copy_rows(mel, h.dim_freq, (long)T * h.dim_freq, e->org + HALO * h.dim_freq, h.dim_freq, TP * h.dim_freq, B, T, h.dim_freq, s));
+        HIPCHK(hipMemcpyAsync(e->emb, emb, (long)B * h.dim_spk_emb * 4, hipMemcpyDeviceToDevice, s));
+    }
+    e->prezero = true;
+    const int frc = forward_core(e, true, scales, len_seg, 1, s);                           // solver.py:165
+    e->prezero = false;
+    e->late_org = e->late_emb = nullptr;
+    CHK(frc);
     const int C = e->head_out;
     HIPCHK(mse_loss(e->out_slab + HALO * C, C, TP * C, e->org + HALO * C, C, TP * C, e->d_out_slab + HALO * C, C, TP * C, B, T,
                     C, 1.0f, e->loss_part, loss, s));                                       // solver.py:166
