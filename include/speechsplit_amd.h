@@ -138,6 +138,17 @@ int ss_interp_forward(ss_engine* e, const float* x_dev, const int* len_seq_dev, 
 /* adjoint of the last ss_interp_forward: dy [B,P,C] -> dx [B,T,C] */
 int ss_interp_backward(ss_engine* e, const float* dy_dev, int B, int T, int C, float* dx_dev, void* stream);
 
+/* ---- offline feature extraction, the part that can be pinned without librosa / pysptk (make_spect_f0.py:57-71, utils.py:18-42) ----
+ * wav: float64 [n] AFTER the host-side high-pass filtfilt and dither (make_spect_f0.py:53-54); mel_basis: float64 [513][n_mels]
+ * (make_spect_f0.py:15 takes librosa's, transposed; here an input); out: float32 [ss_melspec_frames(n)][n_mels] =
+ * (20 log10(max(1e-5, |STFT| . mel)) - 16 + 100) / 100 with the reference's reflect padding, periodic Hann window, 1024-point
+ * transform and hop 256, computed in float64 as numpy does.  No engine needed. */
+int ss_melspec_frames(int n);
+int ss_melspec(const double* wav_dev, int n, const double* mel_basis_dev, int n_mels, float* out_dev, void* stream);
+/* f0 float64 [n], -1e10 = unvoiced (RAPT's otype=2 convention, make_spect_f0.py:63-64) -> float32: (f0 - mean) / std / 4 clipped to
+ * [-1, 1] and mapped to [0, 1] for voiced frames, mean / std over the voiced frames (utils.py:35-42). */
+int ss_f0_normalize(const double* f0_dev, int n, float* out_dev, void* stream);
+
 /* Batch producer on the GPU side (replaces the host loop of MyCollator.__call__, reference data_loader.py:101-128, for a
  * corpus kept resident in HBM): utterance b of the batch is rows [row0[b], row0[b] + len[b]) of the concatenated corpus
  * mel_cat [rows, n_mel] / f0_cat [rows]; the host only draws the crops (same generator calls, same order as the reference).

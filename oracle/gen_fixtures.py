@@ -308,6 +308,43 @@ def main():
     np.savez_compressed(os.path.join(GOLD, 'collate.npz'), mel=cm.numpy(), emb=ce.numpy(), f0=cf.numpy(), len_org=cl.numpy(),
                         corpus_seed=np.int64(3), corpus_n=np.int64(12), items=np.arange(6), np_seed=np.int64(5))
 
+    # ---------------------------------------------------------------- N4 (pinnable half): spectrogram + F0 normalisation
+    # The REFERENCE's utils.butter_highpass / pySTFT / speaker_normalization, and make_spect_f0.py:49-66's statements around them
+    # restated (that script cannot be imported: soundfile / pysptk / spk2gen.pkl are absent and it runs at import).  The mel
+    # filter bank is librosa's in the reference (absent): a triangular bank built here stands in -- it is an INPUT of the code
+    # under test -- and RAPT's output is a synthetic track with its -1e10 unvoiced convention.
+    from scipy import signal
+    feat = {}
+    edges = np.linspace(3, 512, 82)
+    kk = np.arange(513)[:, None]
+    lo_e, mid_e, hi_e = edges[None, :-2], edges[None, 1:-1], edges[None, 2:]
+    mel_basis = np.maximum(0.0, np.minimum((kk - lo_e) / (mid_e - lo_e), (hi_e - kk) / (hi_e - mid_e))) * (2.0 / (hi_e - lo_e))
+    feat['mel_basis'] = mel_basis.astype(np.float64)
+    min_level = np.exp(-100 / 20 * np.log(10))
+    b_hp, a_hp = ref_utils.butter_highpass(30, 16000, order=5)
+    for u, (n, spk) in enumerate(((12345, 226), (10240, 231))):
+        rs = np.random.RandomState(100 + u)
+        tt = np.arange(n) / 16000.0
+        x = 0.3 * np.sin(2 * np.pi * (110 + 40 * tt) * tt) + 0.1 * np.sin(2 * np.pi * 1900 * tt) * (tt > 0.2) + 0.01 * rs.randn(n) + 0.02
+        x[:500] *= 1e-4                                                   # a near-silent stretch: exercises the dB floor
+        feat[f'u{u}_x'] = x
+        if x.shape[0] % 256 == 0:
+            x = np.concatenate((x, np.array([1e-06])), axis=0)            # make_spect_f0.py:51-52
+        y = signal.filtfilt(b_hp, a_hp, x)                                # :53
+        prng = np.random.RandomState(spk)                                 # :46
+        wav = y * 0.96 + (prng.rand(y.shape[0]) - 0.5) * 1e-06            # :54
+        D = ref_utils.pySTFT(wav).T                                       # :57
+        D_db = 20 * np.log10(np.maximum(min_level, np.dot(D, mel_basis))) - 16    # :58-59
+        feat[f'u{u}_wav'] = wav
+        feat[f'u{u}_S'] = ((D_db + 100) / 100).astype(np.float32)         # :60,:71
+        feat[f'u{u}_spk'] = np.int64(spk)
+        nf = feat[f'u{u}_S'].shape[0]
+        f0 = np.where(rs.rand(nf) < 0.45, -1e10, 120 + 60 * rs.rand(nf)).astype(np.float32)   # what sptk.rapt(..., otype=2) returns
+        idx = f0 != -1e10                                                 # :64
+        feat[f'u{u}_f0'] = f0
+        feat[f'u{u}_f0norm'] = ref_utils.speaker_normalization(f0, idx, np.mean(f0[idx]), np.std(f0[idx])).astype(np.float32)   # :65-66,:73
+    np.savez_compressed(os.path.join(GOLD, 'features.npz'), **feat)
+
     # ---------------------------------------------------------------- reference-init statistics (for the init mirror)
     torch.manual_seed(0)
     M0 = ref_model.Generator_3(W.default_hparams())

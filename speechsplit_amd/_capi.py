@@ -66,6 +66,9 @@ SYMBOLS = {
     'ss_op_conv_block_scratch': (_l, [_i, _i, _i, _i]),
     'ss_op_conv_block': (_i, [_fp] * 13 + [_l, _i, _i, _i, _i, _vp]),
     'ss_debug_relu_mask': (_i, [_vp, C.c_char_p, _fp, _vp]),
+    'ss_melspec_frames': (_i, [_i]),
+    'ss_melspec': (_i, [_vp, _i, _vp, _i, _fp, _vp]),
+    'ss_f0_normalize': (_i, [_vp, _i, _fp, _vp]),
     'ss_collate': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'ss_set_precision': (_i, [_vp, _i]),
     'ss_profile': (_i, [_vp, C.c_uint]),

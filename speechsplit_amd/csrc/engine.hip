@@ -1663,6 +1663,21 @@ int ss_collate(const float* mel_cat, const float* f0_cat, const float* emb_tab, 
     return 0;
 }
 
+int ss_melspec_frames(int n) { return n >= 513 ? (n + 256) / 256 : 0; }
+
+int ss_melspec(const double* wav, int n, const double* mel_basis, int n_mels, float* out, void* stream) {
+    if (!wav || !mel_basis || !out) return fail("ss_melspec: null pointer");
+    if (n < 513) return fail("ss_melspec: at least 513 samples (reflect padding by 512)");
+    HIPCHK(melspec(wav, n, mel_basis, n_mels, out, ss_melspec_frames(n), S(stream)));
+    return 0;
+}
+
+int ss_f0_normalize(const double* f0, int n, float* out, void* stream) {
+    if (!f0 || !out || n < 1) return fail("ss_f0_normalize: bad arguments");
+    HIPCHK(f0_normalize(f0, n, out, S(stream)));
+    return 0;
+}
+
 int ss_interp_forward(ss_engine* e, const float* x, const int* len_seq, const float* scales, const int* len_seg, int B, int T,
                       int C, float* y, int* i0, float* lam, int* counts, void* stream) {
     Own own(e, stream);

@@ -110,6 +110,12 @@ hipError_t status_publish(const unsigned* sticky, float* status, hipStream_t s);
 // sticky |= SS_STICKY_RANGE if any of the n parameters is not finite or |p| >= limit
 hipError_t param_guard(const float* p, long n, float limit, unsigned* sticky, hipStream_t s);
 
+// ---------------------------------------------------------------- features.hip  (offline feature extraction, float64)
+// x [n] -> S [frames][n_mels] float32, frames = (n + 256) / 256 (utils.py:18-31, make_spect_f0.py:57-60); mel [513][n_mels]
+hipError_t melspec(const double* x, int n, const double* mel, int n_mels, float* out, int frames, hipStream_t s);
+// utils.py:35-42 with mean / std over the voiced frames (make_spect_f0.py:64-66); -1e10 marks unvoiced frames
+hipError_t f0_normalize(const double* f0, int n, float* out, hipStream_t s);
+
 // ---------------------------------------------------------------- lstm_small.hip  (hidden <= 32: whole recurrence in one launch)
 // gates: [B, TP, 8H] holds x.W_ih^T + b_ih + b_hh on entry (column = dir*4H + gate*H + j, gate order i,f,g,o) and the
 // activated gates on exit.  out: [B, TP, 2H].  csave: [B, TP, 2H] cell states.  whh: [2][4H][H].

@@ -215,6 +215,22 @@ def test_device_batcher_against_reference_collator_fixture(E):
     assert np.array_equal(f0.cpu().numpy(), z['f0']) and np.array_equal(ln.cpu().numpy(), z['len_org'])
 
 
+def test_mel_spectrogram_and_f0_normalisation_against_reference_fixture(E):
+    """SURVEY.md section 8(f) row N4, device half (csrc/features.hip): STFT magnitude -> mel -> dB -> [0, 1] scaling and the F0
+    normalisation against what the REFERENCE's pySTFT / speaker_normalization produced (tests/golden/features.npz).  float64
+    arithmetic on both sides, float32 results: agreement to float32 rounding (stated: 2e-6 absolute on values of order 1)."""
+    from speechsplit_amd import features as F
+    z = np.load(os.path.join(GOLD, 'features.npz'))
+    for u in range(2):
+        S = F.melspectrogram(z[f'u{u}_wav'], z['mel_basis']).cpu().numpy()
+        assert S.shape == z[f'u{u}_S'].shape and S.dtype == np.float32
+        assert float(np.abs(S - z[f'u{u}_S']).max()) <= 2e-6, u
+        fn = F.normalize_f0(z[f'u{u}_f0']).cpu().numpy()
+        ref = z[f'u{u}_f0norm']
+        assert np.array_equal(fn == -1e10, ref == -1e10)
+        assert float(np.abs(fn - ref)[ref != -1e10].max()) <= 2e-7, u
+
+
 def test_eval_forward_ragged_batch(E):
     """B not a multiple of the 16-utterance LSTM tile, T below max_len_pad (eval works at any T % 8 == 0)."""
     hp = W.default_hparams()

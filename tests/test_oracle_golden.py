@@ -272,3 +272,16 @@ def test_collator_against_reference_fixture(gold_dir):
     assert mel.dtype == torch.float32 and ln.dtype == torch.int64 and f0.shape == (6, 192, 1)
     assert np.array_equal(mel.numpy(), z['mel']) and np.array_equal(emb.numpy(), z['emb'])
     assert np.array_equal(f0.numpy(), z['f0']) and np.array_equal(ln.numpy(), z['len_org'])
+
+
+def test_feature_preprocessing_against_reference_fixture(gold_dir):
+    """SURVEY.md section 8(f) row N4, host half: the 30 Hz Butterworth filtfilt + 0.96 scaling + per-speaker dither of
+    make_spect_f0.py:49-54 (speechsplit_amd.features.preprocess_wav) reproduces the waveform the reference's functions gave
+    (tests/golden/features.npz), including the one-sample append for lengths that are multiples of 256."""
+    from speechsplit_amd import features as F
+    z = np.load(os.path.join(gold_dir, 'features.npz'))
+    for u in range(2):
+        wav = F.preprocess_wav(z[f'u{u}_x'], np.random.RandomState(int(z[f'u{u}_spk'])))
+        assert wav.shape == z[f'u{u}_wav'].shape and np.array_equal(wav, z[f'u{u}_wav'])
+    b, a = F.butter_highpass(30, 16000, order=5)
+    assert b.shape == (6,) and abs(a[0] - 1.0) < 1e-12

@@ -6,7 +6,7 @@ R=${1:-r02}
 O=gpurun_out/$R
 mkdir -p $O
 export TMPDIR=/tmp
-timeout -k 10 900 python -u -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1 || { tail -30 $O/pytest_gpu.txt; exit 1; }
+timeout -k 10 1100 python -u -m pytest tests -m gpu -x -q -s > $O/pytest_gpu.txt 2>&1 || { tail -30 $O/pytest_gpu.txt; exit 1; }
 tail -3 $O/pytest_gpu.txt
 # counter passes first: bench.py reads the HBM traffic of its roofline kernel from profiles/<round>/gemm_pmc.json
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 tools/gemm_pmc.py 1024 > $O/pmc_f.log 2>&1
@@ -21,5 +21,8 @@ cp $(ls $O/prof/*/*kernel_stats.csv) $O/bench_kernel_stats.csv
 python3 tools/step_breakdown.py $(ls $O/prof/*/*kernel_trace.csv) > $O/step_breakdown.txt
 python3 tools/step_timeline.py $(ls $O/prof/*/*kernel_trace.csv) > $O/step_timeline.txt
 head -12 $O/step_breakdown.txt
-timeout -k 10 120 python3 tools/kbench.py seq 2>&1 | grep -v amdgpu.ids > $O/kbench_seq_ablation.txt
+SS_DIAG_LIB=1 timeout -k 10 120 python3 tools/kbench.py seq 2>&1 | grep -v amdgpu.ids > $O/kbench_seq_ablation.txt || true
+timeout -k 10 200 python3 tools/f16x2_error.py 2>&1 | grep -v amdgpu.ids > $O/f16x2_error.txt || true
+cp $O/bench_kernel_stats.csv $O/step_breakdown.txt $O/kbench_seq_ablation.txt $O/f16x2_error.txt $O/bench_n1.json profiles/$R/ 2>/dev/null || true
+cp $O/step_timeline.txt profiles/$R/step_timeline.txt
 rm -rf $O/prof/*/*.db
