@@ -27,7 +27,7 @@ int g_bwd_f16x2 = 1;   // 1: the decoder's and the conv trunk's gradient GEMMs a
                        //    of two its producer kernel measured (max |value| of the slab), the activation / weight operand by the fixed one
 int g_overlap = 1;     // 1: weight-gradient GEMMs on the side stream
 int g_dx_batched = 2;  // input-gradient GEMMs per utterance without halo rows; 2: with 128 x 128 tiles from 512 workgroups on
-int g_conv_want = 0;    // experiment: workgroup target of the conv GEMMs' tile choice (0: library default)
+int g_conv_want = 256;    // experiment: workgroup target of the conv GEMMs' tile choice (0: library default)
 int g_defer_dw = 1;    // 1: the decoder's weight-gradient GEMMs start after its last input gradient (see lstm_bwd)
 int g_side_prio = 0;   // 1: create the side stream with the lowest priority (read at ss_bind).  Measured: 2.3x SLOWER
                        //    (35 ms vs 14.8 ms per step): the low-priority queue starves behind 768 tiny step launches.
@@ -42,6 +42,7 @@ int g_own_streams = 0; // 1: every C-ABI call runs on the ENGINE's own main stre
                        //    least-loaded of its 4 hardware queues, and which engine stream ends up sharing a queue with the caller's still
                        //    moves the step by 5 % either way (profiles/r02/stream_order_effect.txt: 6.70 - 7.13 ms owned, 6.69 - 7.38 not).
                        //    Off by default until the engine can measure and pick its queue placement.
+int g_conv_par = 1;    // 1: the two conv streams of an Encoder_7 layer (and the layer's resampling plan) run on two engine streams in the forward
 int g_early_join = 1;  // 1: join events of branch streams are recorded right behind the last kernel the consumer needs (lstm_bwd's dx_ready)
 int g_tune_epoch = 0;  // bumped by ss_tune: captured graphs bake the knobs in, so they are dropped when it changes
 }
@@ -1018,17 +1019,30 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
             CHK(conv_block_fwd(e, e->ct, Slab{e->org, e->hp.dim_freq}, Slab{e->act_t, e->hp.dim_enc_2}, b2));
             CHK(lstm_fwd(e, e->lt, Slab{e->act_t, e->hp.dim_enc_2}, b2));
         }
+        // The content (512 ch) and pitch (256 ch) blocks of a layer are independent: with g_conv_par the pitch block and the layer's
+        // resampling plan run on the first branch stream beside the content block.
+        const bool cpar = g3 && par && g_conv_par && !g_graph;
+        hipStream_t sp = cpar ? b1 : s;
+        if (cpar) CHK(fork_join(e, s, b1));
         if (g3) {
             Slab x1 = i == 0 ? Slab{e->in_mel, e->hp.dim_freq} : Slab{e->xf[i - 1], CE};
-            CHK(conv_block_fwd(e, e->c1[i], x1, Slab{y, CE}, s));
+            if (!cpar) CHK(conv_block_fwd(e, e->c1[i], x1, Slab{y, CE}, s));
         }
         Slab x2 = i == 0 ? Slab{e->in_f0, e->f0p} : Slab{e->xf[i - 1] + off2, CE};
-        CHK(conv_block_fwd(e, e->c2[i], x2, Slab{y + off2, CE}, s));
+        CHK(conv_block_fwd(e, e->c2[i], x2, Slab{y + off2, CE}, sp));
         if (training) {
             // one warp for both streams (model.py:202-206), len_seq = max_len_pad for every utterance (:105,157,203)
             InterpPlan& pl = e->plan[draw0 + i];
             HIPCHK(interp_plan(pl, scales + (long)(draw0 + i) * B * S7, len_seg + (long)(draw0 + i) * B * S7, nullptr,
-                               e->hp.max_len_pad, B, s));
+                               e->hp.max_len_pad, B, sp));
+        }
+        if (cpar) {
+            Slab x1 = i == 0 ? Slab{e->in_mel, e->hp.dim_freq} : Slab{e->xf[i - 1], CE};
+            CHK(conv_block_fwd(e, e->c1[i], x1, Slab{y, CE}, s));
+            CHK(fork_join(e, b1, s));
+        }
+        if (training) {
+            InterpPlan& pl = e->plan[draw0 + i];
             HIPCHK(interp_gather(pl, e->act + HALO * CE, CE, TP * CE, e->xf[i] + HALO * CE, CE, TP * CE, CE, B, s));
         }
     }
@@ -1820,6 +1834,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "graph" && (value == 0 || value == 1)) g_graph = value;
     else if (k == "own_streams" && (value == 0 || value == 1)) g_own_streams = value;
     else if (k == "early_join" && (value == 0 || value == 1)) g_early_join = value;
+    else if (k == "conv_par" && (value == 0 || value == 1)) g_conv_par = value;
     else if (k == "deterministic" && (value == 0 || value == 1)) g_deterministic = value;
     else if (k == "split" && (value == 0 || value == 1)) g_split = value;
     else if (k == "persist" && (value == 0 || value == 1)) g_persist = value;
