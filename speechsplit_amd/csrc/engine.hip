@@ -1268,7 +1268,7 @@ extern "C" {
 
 int ss_comm_destroy(ss_engine* e);
 const char* ss_last_error(void) { return g_err.c_str(); }
-int ss_abi_version(void) { return 1; }
+int ss_abi_version(void) { return 2; }      // 2: ss_profile(mask) / ss_profile_read, status word, RCCL entry points, SS_STEP_BUCKET
 
 ss_engine* ss_create(int kind, const ss_hparams* hp, int max_batch, int max_frames) {
     if (!hp || (kind != SS_GENERATOR_3 && kind != SS_GENERATOR_6 && kind != SS_INTERP_ONLY)) {

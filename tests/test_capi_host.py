@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ss_abi_version() == 1
+    assert lib.ss_abi_version() == 2
 
 
 @pytest.mark.parametrize('kind', ['G3', 'G6'])
