@@ -38,6 +38,9 @@ struct GemmDesc {
     int flags;
     int diag;               // timing experiments only (gemm_f32.hip g_gemm_diag); 0 in production
     int want;               // >0: least number of workgroups the tile choice should produce (0: the library default)
+    // row_period > 0: a result row m is stored only if (m + row_off) % row_period lies in [row_lo, row_hi).  Lets a contraction run
+    // over ALL rows of a haloed slab as one matrix (no 128-row tile cut at every utterance) while its halo rows stay untouched.
+    int row_period, row_off, row_lo, row_hi;
     int ksplit;             // >1: split the reduction over blockIdx.z, atomically accumulate into C (C pre-zeroed or ACCUM)
     // GEMM_F16X2 only: device words holding max|A| / max|B| (as produced by the kernels that wrote the operand); the kernel
     // scales the operand by the power of two that brings this maximum into [128, 256).  Null: the fixed scale for O(1) data.

@@ -42,6 +42,7 @@ int g_own_streams = 0; // 1: every C-ABI call runs on the ENGINE's own main stre
                        //    least-loaded of its 4 hardware queues, and which engine stream ends up sharing a queue with the caller's still
                        //    moves the step by 5 % either way (profiles/r02/stream_order_effect.txt: 6.70 - 7.13 ms owned, 6.69 - 7.38 not).
                        //    Off by default until the engine can measure and pick its queue placement.
+int g_flat_rows = 1;   // 1: batched-per-utterance GEMMs run flat over the slab rows when T % 128 != 0 (flatten_rows)
 int g_exp = 0;         // bits that switch individual schedule choices back for same-box A/B runs (bench.py --tune exp=N); 0 in production
 int g_conv_par = 1;    // 1: the two conv streams of an Encoder_7 layer (and the layer's resampling plan) run on two engine streams in the forward
 int g_early_join = 1;  // 1: join events of branch streams are recorded right behind the last kernel the consumer needs (lstm_bwd's dx_ready)
@@ -580,6 +581,24 @@ double gemm_flops(const GemmDesc& d) { return 2.0 * d.M * d.N * (double)d.K * (d
         prof_end(e, _pi, st);                                \
     } while (0)
 
+// A per-utterance batched contraction over haloed slabs (M = T rows per batch entry, A / C pointing at slab row HALO) rewritten as
+// ONE matrix over all slab rows between the first and the last halo, halo rows masked in the epilogue.  Batched, every utterance
+// starts a new row tile: T = 144 needs two 128-row tiles per utterance (78 % of the rows computed are padding), T = 192 wastes 25 %.
+// Worth it whenever T is not a multiple of the 128-row tile.  The A operand's rows are addressed exactly as before (row m of the
+// flat matrix is slab row m + HALO, taps reach into the neighbouring rows; rows computed for halo positions are never stored).
+void flatten_rows(GemmDesc& d, int B, int T) {
+    if (T % 128 == 0 || d.batch != B || B < 2 || g_flat_rows == 0) return;
+    const int TP = T + 2 * HALO;
+    d.M = B * TP - 2 * HALO;
+    d.batch = 1;
+    d.A.bstride = 0;
+    d.cstride = 0;
+    d.row_period = TP;
+    d.row_off = HALO;
+    d.row_lo = HALO;
+    d.row_hi = HALO + T;
+}
+
 // ---- convolution block -------------------------------------------------------------------------------------
 int conv_pack_all(ss_engine* e, ConvBlk& cb, hipStream_t s) {
     HIPCHK(conv_pack(e->P + cb.w, cb.Co, cb.Ci, cb.Cp, cb.wf, cb.wb, s));
@@ -608,6 +627,7 @@ int conv_block_fwd(ss_engine* e, ConvBlk& cb, Slab x, Slab y, hipStream_t s) {
     d.batch = B;
     d.ksplit = 1;
     d.want = g_conv_want;
+    flatten_rows(d, B, T);
     PGEMM_FWD_ON(SS_PROF_CONV_FWD, d, s);
     HIPCHK(gn_relu_fwd(cb.cout, cb.Co, TP * cb.Co, y.p, y.ld, TP * y.ld, e->P + cb.ga, e->P + cb.be, cb.stats, B, T, cb.Co, s));
     return 0;
@@ -651,6 +671,7 @@ int conv_block_bwd(ss_engine* e, ConvBlk& cb, Slab dy, Slab x, Slab dx, hipStrea
         g.flags = am ? GEMM_F16X2 : 0;
         g.amax_a = am;
         g.want = g_conv_want;
+        flatten_rows(g, B, T);
         PGEMM_ON(SS_PROF_CONV_DX, g, s);
     }
     return 0;
@@ -721,6 +742,7 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
                 d.K = In;
                 d.batch = ch[c].nb;
                 d.ksplit = 1;
+                if (nch == 1) flatten_rows(d, B, T);
                 PGEMM_FWD_ON(l > 0 ? SS_PROF_DEC_PROJ : SS_PROF_DEC_PROJ0, d, ch[c].st);
             }
             if (!persist) {
@@ -768,6 +790,7 @@ int lstm_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
             d.K = In;
             d.batch = B;
             d.ksplit = 1;
+            flatten_rows(d, B, T);
             PGEMM_FWD_ON(SS_PROF_ENC_LSTM, d, s);
         }
         HIPCHK(lstm_small_fwd(lb.gates[l], e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.out[l], lb.csave[l], B, T, H,
@@ -1084,6 +1107,7 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
     d.K = (int)HD;
     d.batch = B;
     d.ksplit = 1;
+    flatten_rows(d, B, T);
     PGEMM_FWD_ON(SS_PROF_HEAD, d, s);
     e->fwd_training = training;
     e->enc_plan0 = draw0;
@@ -1838,6 +1862,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "early_join" && (value == 0 || value == 1)) g_early_join = value;
     else if (k == "conv_par" && (value == 0 || value == 1)) g_conv_par = value;
     else if (k == "exp" && value >= 0) g_exp = value;
+    else if (k == "flat_rows" && (value == 0 || value == 1)) g_flat_rows = value;
     else if (k == "deterministic" && (value == 0 || value == 1)) g_deterministic = value;
     else if (k == "split" && (value == 0 || value == 1)) g_split = value;
     else if (k == "persist" && (value == 0 || value == 1)) g_persist = value;

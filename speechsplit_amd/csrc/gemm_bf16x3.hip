@@ -365,6 +365,10 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
                 if (m >= d.M) continue;
+                if (d.row_period) {
+                    const int q = (m + d.row_off) % d.row_period;
+                    if (q < d.row_lo || q >= d.row_hi) continue;
+                }
                 float* c = Cb + (long)m * d.ldc + n;
                 const float v = acc[mi][ni][r] * unscale + bv;
                 if (d.ksplit > 1) atomicAdd(c, v);
