@@ -134,11 +134,19 @@ class DeviceBatcher(object):
     with exactly the collator's generator calls (two ``np.random.randint(..., size=2)`` per utterance, data_loader.py:106-107) and sends
     3*B integers; no mel / F0 crosses PCIe.  Same seeds + same sampler order => the same batches as MyCollator, bit for bit."""
 
-    def __init__(self, hparams, corpus, sampler=None, drop_last=True):
+    def __init__(self, hparams, corpus, sampler=None, drop_last=True, rank=0, world=1):
+        """rank / world: data parallel with one batcher per rank (same seeds on every rank).  Every rank walks the same sampler
+        order and draws the crops of the whole global batch -- the generator stays aligned with a single-process run -- but
+        assembles, i.e. launches ss_collate for, only its own batch_size / world utterances (`per_rank`: Solver does not slice
+        these batches again)."""
         self.hp, self.corpus = hparams, corpus
         self.sampler = sampler or MultiSampler(len(corpus), hparams.samplier, shuffle=hparams.shuffle)
         self.B = hparams.batch_size
         self.drop_last = drop_last
+        self.rank, self.world = rank, world
+        self.per_rank = world > 1
+        if self.B % world:
+            raise ValueError('batch_size must divide over the ranks')
 
     def __len__(self):
         return len(self.sampler) // self.B
@@ -153,8 +161,11 @@ class DeviceBatcher(object):
             left = int(np.random.randint(0, max(int(c.lens[i]) - n, 1), size=2)[0])
             lens.append(min(n, int(c.lens[i]) - left))
             row0.append(int(c.starts[i]) + left)
+        if self.world > 1 and len(indices) == self.B:      # this rank's shard of the global batch
+            lo, hi = self.rank * (self.B // self.world), (self.rank + 1) * (self.B // self.world)
+            row0, lens, indices = row0[lo:hi], lens[lo:hi], indices[lo:hi]
         B, T, dev = len(indices), hp.max_len_pad, c.device
-        meta = torch.tensor([row0, lens, list(map(int, indices))], dtype=torch.int64).to(dev, non_blocking=True)
+        meta = torch.tensor([row0, lens, list(map(int, indices))], dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
         row0_d, len_d, item_d = meta[0].contiguous(), meta[1].to(torch.int32), meta[2].to(torch.int32)
         mel = torch.empty(B, T, c.mel.shape[1], device=dev)
         f0 = torch.empty(B, T, 1, device=dev)
@@ -175,15 +186,16 @@ class DeviceBatcher(object):
             yield self.assemble(batch)
 
 
-def get_device_loader(hparams, dataset=None, device='cuda'):
-    """Like get_loader, but the corpus lives in HBM and batches are assembled there (DeviceBatcher)."""
+def get_device_loader(hparams, dataset=None, device='cuda', rank=0, world=1):
+    """Like get_loader, but the corpus lives in HBM and batches are assembled there (DeviceBatcher); rank / world: each rank
+    assembles its own shard."""
     if dataset is None:
         if os.path.exists(os.path.join(hparams.root_dir, 'train.pkl')):
             dataset = Utterances(hparams.root_dir, hparams.feat_dir, hparams.mode)
         else:
             print(f'[speechsplit_amd] {hparams.root_dir}/train.pkl not found: using the synthetic corpus')
             dataset = SyntheticUtterances(max(4 * hparams.batch_size, 64))
-    return DeviceBatcher(hparams, DeviceCorpus(dataset, device))
+    return DeviceBatcher(hparams, DeviceCorpus(dataset, device), rank=rank, world=world)
 
 
 def get_loader(hparams, dataset=None):

@@ -18,6 +18,7 @@ import torch
 from . import dist as _dist
 from .engine import draw_interp
 from .model import Generator_3 as Generator
+from .model import Generator_6
 from .model import InterpLnr
 from .staging import DevicePrefetcher
 from .utils import pad_seq_to_2, quantize_f0_numpy
@@ -50,9 +51,11 @@ class Solver(object):
         self.model_save_step = config.model_save_step
         self.build_model()
 
+    GENERATOR = Generator          # SolverF0 below trains Generator_6 with the same shell
+
     def build_model(self):
         per_rank = self.hparams.batch_size // max(self.world, 1)
-        self.G = Generator(self.hparams, max_batch=per_rank)
+        self.G = self.GENERATOR(self.hparams, max_batch=per_rank)
         self.Interp = InterpLnr(self.hparams)
         self.print_network(self.G, 'G')
         self.G.to(self.device)                      # creates the engine, parameters now live in its arena
@@ -200,3 +203,40 @@ class Solver(object):
             if (i + 1) % self.sample_step == 0 and validation_pt is not None and self.rank == 0:
                 val_loss, _ = self.validate(validation_pt)
                 print('Validation loss: {}'.format(val_loss))
+
+
+class SolverF0(Solver):
+    """Trainer for Generator_6, the F0 converter (reference model.py:324-351; demo.ipynb cell 0 uses a pretrained one, `640000-P.ckpt`).
+    The reference ships NO training loop for it: this one is this repo's choice and says so -- the `Solver` shell
+    unchanged (constructor, config attributes, log line, `<iter>-G.ckpt` layout with the reference's Generator_6 key names), the step
+    body = quantise the batch's F0 (utils.quantize_f0_torch), feed the one-hot as `f0_trg`, cross-entropy of the 257-way logits
+    against the same classes (demo.ipynb takes their argmax), backward, Adam: ONE `ss_g6_train_step` call.  BASELINE config 4."""
+    GENERATOR = Generator_6
+
+    def train_on_batch(self, batch, draws=None):
+        from .utils import quantize_f0_torch
+        x_real_org, emb_org, f0_org, len_org = batch
+        per_rank = getattr(self.vcc_loader, 'per_rank', False)
+        Bg = x_real_org.shape[0] * (self.world if per_rank else 1)
+        if draws is None:
+            draws = draw_interp(Bg, 3, self.hparams)                 # Encoder_6 resamples three times (model.py:128)
+        if self.world > 1:
+            if not per_rank:
+                x_real_org, emb_org, f0_org, len_org = _dist.shard_batch(batch, self.rank, self.world)
+            draws = _dist.shard_draws(draws[0], draws[1], Bg, self.rank, self.world)
+        to = dict(device=self.device, non_blocking=True)
+        mel, f0 = x_real_org.to(**to), f0_org.to(**to)
+        onehot, idx = quantize_f0_torch(f0[:, :, 0])
+        bucket = mel.shape[1] != self.hparams.max_len_pad
+        if self.world > 1:
+            self.eng.g6_train_step(mel, onehot, idx.to(torch.int32), draws, no_adam=True, bucket=bucket)
+            _dist.reduce_arena(self.eng.grads, self.eng.grad_split)
+            self.eng.adam_step(1.0 / self.world)
+            loss = self.eng.loss
+        else:
+            loss = self.eng.g6_train_step(mel, onehot, idx.to(torch.int32), draws, bucket=bucket)
+        self.step_count += 1
+        return loss
+
+    def validate(self, validation_pt, ablations=False):
+        raise NotImplementedError('the reference validates Generator_3 only (solver.py:206-227)')

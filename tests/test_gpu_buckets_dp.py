@@ -147,3 +147,40 @@ def test_g6_dp_step_on_a_one_rank_group(E):
         assert abs(res[0][0] - res[1][0]) <= 1e-6 * res[0][0] and rel(res[1][1], res[0][1]) < 1e-6
     finally:
         dist.destroy_process_group()
+
+
+def test_generator6_trainer_and_per_rank_batcher(E, tmp_path):
+    """SolverF0: the Solver shell around ss_g6_train_step (BASELINE config 4's model; the reference has no trainer for it) trains,
+    logs and writes a checkpoint with the reference's Generator_6 key names; DeviceBatcher(rank, world) hands each rank its shard of
+    the batch a single process would assemble."""
+    import json
+    import os
+    from types import SimpleNamespace
+    from speechsplit_amd import data_loader as DL, hparams as HP, solver
+    hp = HP.default_hparams(batch_size=4)
+    ds = DL.SyntheticUtterances(16, seed=2)
+    cfg = SimpleNamespace(num_iters=3, g_lr=1e-4, beta1=0.9, beta2=0.999, resume_iters=None, use_tensorboard=False, device_id=0,
+                          log_dir=str(tmp_path), sample_dir=str(tmp_path), model_save_dir=str(tmp_path), log_step=1, sample_step=1000,
+                          model_save_step=3)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    s = solver.SolverF0(DL.get_device_loader(hp, dataset=ds), cfg, hp)
+    p0 = s.eng.params.clone()
+    s.train()
+    s.eng.check()
+    assert not torch.equal(p0, s.eng.params)
+    ck = torch.load(os.path.join(str(tmp_path), '3-G.ckpt'), weights_only=False)
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'keys_G6.json')
+    assert list(ck['model'].keys()) == json.load(open(gold))['keys']
+    assert float(ck['optimizer']['state'][0]['step']) == 3.0
+    # per-rank assembly: the two ranks' shards, concatenated, are the single-process batch
+    corpus = DL.DeviceCorpus(ds, 'cuda')
+    idx = [3, 7, 1, 12]
+    np.random.seed(5)
+    whole = DL.DeviceBatcher(hp, corpus).assemble(idx)
+    parts = []
+    for r in range(2):
+        np.random.seed(5)
+        parts.append(DL.DeviceBatcher(hp, corpus, rank=r, world=2).assemble(idx))
+    for k in range(4):
+        assert torch.equal(torch.cat([parts[0][k], parts[1][k]]), whole[k])
