@@ -317,6 +317,16 @@ def main():
             for k in knobs:
                 tune(k, 1)
         eng.check()
+    sl = None
+    if rank == 0 and not (args.no_extras or world > 1 or kind != 'G3' or args.workload != 'fixed'):
+        # Solver builds its own engine: release this one first (its four streams would otherwise change which hardware queues the
+        # second engine's streams land on -- measured 7.4 vs 6.7 ms per iteration)
+        eng_hp = eng.hp
+        del eng
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        sl = solver_loop(B, T)
     if rank == 0:
         out = {
             'metric': 'utterances/sec (fwd+bwd, 128-frame 80-mel, batch 64) at 1/2/4/8 MI355X',
@@ -333,7 +343,7 @@ def main():
                        'products': PRODUCTS[args.precision]},
             'step_tflops': round(3 * 2 * (MAC_PER_FRAME_G3 if kind == 'G3' else MAC_PER_FRAME_G6) * (T if args.workload == 'fixed' else 144) * B * world / (dt / args.steps) / 1e12, 2),
             'roofline': roof, 'kernel_classes': classes, 'recurrence': recur, 'alt_precisions': alt,
-            'solver_loop': None if (args.no_extras or world > 1 or kind != 'G3' or args.workload != 'fixed') else solver_loop(B, T),
+            'solver_loop': sl,
             'cpu_baseline': None if args.no_cpu_baseline else cpu_baseline(T),
         }
         print(json.dumps(out), flush=True)
