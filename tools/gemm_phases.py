@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
 """Where a wave of the 128x128 NT bf16x3 GEMM spends its cycles per k-tile (ss_debug_gemm_phases)."""
+import os
+os.environ.setdefault('SS_DIAG_LIB', '1')      # the k-loop phase probe (gemm_diag 16) exist only in the -DSS_DIAG build: make -C speechsplit_amd/csrc diag
 import ctypes as C, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -7,7 +7,7 @@ from speechsplit_amd import engine as E, _capi
 lib = _capi.lib()
 want = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 _capi.check(lib.ss_tune(b'gemm_want', want))
-if len(sys.argv) > 2:
+if len(sys.argv) > 2:      # timing ablations: run with SS_DIAG_LIB=1 (make -C speechsplit_amd/csrc diag)
     _capi.check(lib.ss_tune(b'gemm_diag', int(sys.argv[2])))
 shapes = [(8192, 4096, 1024, False, False, 1), (8192, 512, 2560, False, False, 1), (8192, 1024, 4096, False, True, 1),
           (2048, 1024, 8448, True, True, 4), (2048, 512, 8447, True, True, 8)]

@@ -2,6 +2,8 @@
 """Kernel micro-benchmarks on the GPU box: A/B the tuning knobs of the step-LSTM and GEMM kernels in ONE process
 (interleaved rounds, HIP events on the launch stream), each variant first checked against a PyTorch fp32 reference.
 Writes gpurun_out/kbench.txt.   Usage: python tools/kbench.py [lstm] [gemm] [step]"""
+import os
+os.environ.setdefault('SS_DIAG_LIB', '1')      # the ablation modes (seq_prio > 1, gemm_diag, lstm_mode) exist only in the -DSS_DIAG build: make -C speechsplit_amd/csrc diag
 import ctypes as C
 import os
 import sys

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Persistent recurrence kernels vs. the per-step kernels on one layer: seq_debug.py <B> [ablation bits].
 B = 64 gives XCD-local groups (ordinary payload stores), B = 16 / 48 groups that span XCDs (sc1 path)."""
+import os
+os.environ.setdefault('SS_DIAG_LIB', '1')      # the recurrence ablation bits exist only in the -DSS_DIAG build: make -C speechsplit_amd/csrc diag
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
