@@ -526,13 +526,14 @@ def test_full_size_data_parallel_linearity_and_descent(E):
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
 
 
-def _shard_linearity(E, kind, B, T, len_lo, parts, wseed=0, bseed=11, descent=True):
+def _shard_linearity(E, kind, B, T, len_lo, parts, wseed=0, bseed=11, descent=True, precision='f32', tol=TOL):
     """Gradient of a B-utterance batch == mean of the gradients of its `parts` equal shards given the matching draw slices,
     and a few Adam steps on the fixed batch reduce the loss.  The shards may run a different recurrence schedule than the
     whole batch (persistent kernels, XCD-local or not, or one launch per time step), which this cross-checks at full size."""
     from speechsplit_amd import dist as D
     hp = W.default_hparams(max_len_pad=T)
     eng = E.Engine(kind, hp, B, T)
+    eng.set_precision(precision)
     eng.load_weights(W.make_weights(kind, hp, wseed))
     mel, f0, emb, lens = synth_batch(bseed, B, T, len_lo)
     ncalls = 4 if kind == 'G3' else 3
@@ -560,7 +561,7 @@ def _shard_linearity(E, kind, B, T, len_lo, parts, wseed=0, bseed=11, descent=Tr
     assert abs(l_sh - l_full) <= 1e-5 * abs(l_full), (l_sh, l_full)
     gv_f, gv_s = eng.views(g_full), eng.views(acc)
     for n in gv_f:
-        assert rel(gv_s[n], gv_f[n]) < TOL, n
+        assert rel(gv_s[n], gv_f[n]) < tol, n
     if descent:
         eng.adam_m.zero_()
         eng.adam_v.zero_()
@@ -580,6 +581,15 @@ def test_full_size_192_frames(E):
     """BASELINE config 4's frame count: Generator_3, 64 utterances x 192 frames, lengths 96..192 (padded, as the
     reference does); shards of 32 run the persistent recurrences with groups that span XCDs."""
     _shard_linearity(E, 'G3', 64, 192, 96, 2)
+
+
+@pytest.mark.parametrize('case', [('G3', 64, 128, 64), ('G6', 64, 192, 96)], ids=['config3_g3_2x32x128', 'config4_g6_2x32x192'])
+def test_bf16_configs_data_parallel_linearity(E, case):
+    """BASELINE configs 3 and 4 name bf16 arithmetic at 32 utterances per GPU: in the bf16 product mode the gradient of a 64-utterance
+    batch equals the mean of its two 32-utterance shards' gradients given the matching draw slices (the N-rank == 1-rank identity; operand
+    rounding is per element, so only the summation order differs), and a few Adam steps reduce the loss."""
+    kind, B, T, len_lo = case
+    _shard_linearity(E, kind, B, T, len_lo, 2, wseed=0 if kind == 'G3' else 4, precision='bf16', tol=2e-4)
 
 
 def test_batch_beyond_one_workgroup_per_cu(E):
