@@ -6,7 +6,8 @@
 N=1: one process.  N>1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`,
 one rank per GPU; each rank processes its own 64-utterance shard (weak scaling), gradients are summed with RCCL
 all-reduces over the flat gradient arena (decoder bucket beside the encoder backward, then the encoder bucket), then every
-rank applies the same Adam update with the 1/N mean folded in.
+rank applies the same Adam update with the 1/N mean folded in.  The collectives are launched by the engine itself on its own
+streams (ss_g3_dp_train_step; torch.distributed only hands the 128-byte communicator id round and reduces the timing).
 
 Workload (BASELINE.json metric / SURVEY.md section 8(d)): batch 64 per GPU, 128 frames, 80-bin mel + F0, max_len_pad=128,
 synthetic batch resident in HBM before the timed region, weights from a fixed seed.  A step = resample -> quantise ->
@@ -195,6 +196,11 @@ def main():
                     help='config5: BASELINE config 5 -- crops of 96..192 frames, every batch from one length bucket (speechsplit_amd/buckets.py), '
                          'assembled on the GPU and staged by DevicePrefetcher inside the timed region; use with --frames 192')
     ap.add_argument('--force-dp', action='store_true', help='run the data-parallel step (bucketed all-reduce, sliced draws) even at world size 1')
+    ap.add_argument('--dp-backend', choices=['torch', 'native'], default='native',
+                    help="data-parallel collectives: torch.distributed's ProcessGroupNCCL (Engine.dp_train_step) or the engine's own RCCL "
+                         "communicator (ss_g3_dp_train_step: the decoder bucket is launched on the engine's side stream itself).  Default native: "
+                         "at world 1 it costs nothing over the plain step (6.32 ms) while the torch path costs +0.5 ms -- ProcessGroupNCCL's own "
+                         "stream shares a hardware queue with one of the engine's.  (Length buckets and Generator_6 always take the torch path.)")
     ap.add_argument('--no-profile', action='store_true', help='no hipEvent brackets in the timed region (to measure their cost)')
     ap.add_argument('--tune', action='append', default=[], metavar='KEY=VALUE', help='experiment knob of the HIP library (ss_tune)')
     args = ap.parse_args()
@@ -226,6 +232,9 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     eng.set_adam(1e-4, 0.9, 0.999, 1e-8, 0)
     eng.set_precision(args.precision)
+    native = dp and args.dp_backend == 'native' and kind == 'G3' and args.workload == 'fixed'
+    if native:
+        eng.comm_init(rank, world)
     mel, f0, emb, lens = synth(B, T, 1000 + rank, dev)
     torch.manual_seed(1234)
     S = hp.max_len_seq // hp.min_len_seg + 1
@@ -260,6 +269,8 @@ def main():
                 eng.dp_g6_train_step(mel, onehot, qidx, (sc, ls), world)
             else:
                 eng.g6_train_step(mel, onehot, qidx, (sc, ls))
+        elif native:
+            eng.dp_train_step_native(mel, f0, emb, lens, (sc, ls))
         elif dp:
             eng.dp_train_step(mel, f0, emb, lens, (sc, ls), world)
         else:
@@ -339,7 +350,7 @@ def main():
                                     f'(multiple of 8) per batch, max_len_pad = bucket, {B} utterances/GPU, mean {frames_done[0] / max(1, args.steps + args.warmup + (8 if not args.no_profile else 0)):.1f} frames/batch, '
                                     f'batches assembled on the GPU + DevicePrefetcher inside the timed region' if kind == 'G3' else
                                     f'Generator_6 full training step (host draws+fwd+cross-entropy+bwd+Adam; BASELINE config 4 shape), {B} utterances/GPU x {T} frames'),
-                       'global_batch': B * world, 'seq_len': T, 'parallelism': f'dp{world}' + (' (forced DP path)' if args.force_dp and world == 1 else ''),
+                       'global_batch': B * world, 'seq_len': T, 'parallelism': f'dp{world}' + (' (forced DP path)' if args.force_dp and world == 1 else '') + (f', {args.dp_backend} RCCL' if dp else ''),
                        'products': PRODUCTS[args.precision]},
             'step_tflops': round(3 * 2 * (MAC_PER_FRAME_G3 if kind == 'G3' else MAC_PER_FRAME_G6) * (T if args.workload == 'fixed' else 144) * B * world / (dt / args.steps) / 1e12, 2),
             'roofline': roof, 'kernel_classes': classes, 'recurrence': recur, 'alt_precisions': alt,

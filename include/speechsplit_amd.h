@@ -104,6 +104,12 @@ int ss_wait_decoder_grads(ss_engine* e, void* consumer_stream);
 /* the engine stream that carries the decoder's weight-gradient GEMMs (a hipStream_t; NULL if the engine runs without
  * branch streams).  A collective launched from it is ordered behind those GEMMs by construction. */
 void* ss_side_stream(ss_engine* e);
+/* How ss_bind chose the engine's branch streams.  The step forks three branches off the stream it is issued on; HIP maps a process's
+ * streams onto 4 in-order hardware queues without saying which, and two streams on one queue cannot overlap (measured +14 % on the
+ * step).  ss_bind therefore creates a pool of streams, MEASURES which of them share a queue with the caller's stream and with each
+ * other (a 400 us spin kernel on one stream delays a trivial kernel on another only if they share a queue; ~10 ms once), keeps three
+ * on queues of their own and destroys the rest.  Issue the steps on the stream that was passed to ss_bind. */
+const char* ss_stream_report(const ss_engine* e);
 /* first arena offset (floats) of the decoder + head parameters; [0, split) is the encoder */
 long ss_grad_split(const ss_engine* e);
 

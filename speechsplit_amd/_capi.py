@@ -45,6 +45,7 @@ SYMBOLS = {
     'ss_wait_decoder_grads': (_i, [_vp, _vp]),
     'ss_side_stream': (_vp, [_vp]),
     'ss_grad_split': (_l, [_vp]),
+    'ss_stream_report': (C.c_char_p, [_vp]),
     'ss_comm_unique_id': (_i, [C.c_char_p]),
     'ss_comm_init': (_i, [_vp, C.c_char_p, _i, _i]),
     'ss_comm_destroy': (_i, [_vp]),

@@ -43,6 +43,11 @@ int g_own_streams = 0; // 1: every C-ABI call runs on the ENGINE's own main stre
                        //    moves the step by 5 % either way (profiles/r02/stream_order_effect.txt: 6.70 - 7.13 ms owned, 6.69 - 7.38 not).
                        //    Off by default until the engine can measure and pick its queue placement.
 int g_flat_rows = 1;   // 1: batched-per-utterance GEMMs run flat over the slab rows when T % 128 != 0 (flatten_rows)
+int g_prio_order = 1;  // 1: within every phase the critical-path launches are ENQUEUED first and the work that only has to be done by the end of
+                       //    the step (decoder / encoder-BLSTM weight gradients, Encoder_t) last.  HIP multiplexes streams onto 4 in-order hardware
+                       //    queues; when two engine streams share one (other streams in the process, e.g. RCCL's, shift the assignment), enqueue
+                       //    order is execution order, and filler work enqueued first would run in front of the critical path.
+int g_probe_queues = 1; // 1: ss_bind measures which candidate streams share a hardware queue and picks branch streams that do not (pick_streams)
 int g_exp = 0;         // bits that switch individual schedule choices back for same-box A/B runs (bench.py --tune exp=N); 0 in production
 int g_conv_par = 1;    // 1: the two conv streams of an Encoder_7 layer (and the layer's resampling plan) run on two engine streams in the forward
 int g_early_join = 1;  // 1: join events of branch streams are recorded right behind the last kernel the consumer needs (lstm_bwd's dx_ready)
@@ -139,6 +144,7 @@ struct ss_engine {
     int curB = 0, curT = 0;
     bool fwd_training = false;
     const float *late_org = nullptr, *late_emb = nullptr;   // fused training step: x_org / emb still to be copied in (done on the Encoder_t branch)
+    bool dec_w_pending = false;            // backward_decoder(late): the decoder's + head's weight gradients are still to be enqueued
     bool prezero = false;                  // fused training step: zero the gradient arena on a branch stream during the forward
     bool grads_zeroed = false;             // ... done: backward_decoder must not zero it again
     bool have_fwd = false;
@@ -168,13 +174,14 @@ struct ss_engine {
     std::map<std::string, std::pair<float*, long>> dbg;   // name -> (ptr, cols)
     // weight-gradient GEMMs of a BLSTM layer run on this side stream while the next layer's recurrence (latency-bound,
     // one launch per time step) proceeds on the caller's stream
+    std::string stream_report;            // what pick_streams found (ss_stream_report)
     hipStream_t main_s = nullptr;         // the stream the step's dependency chain runs on (see g_own_streams)
     hipStream_t side = nullptr;
     hipStream_t side2 = nullptr;          // independent branches (per-step weight re-layouts, Encoder_t, second encoder BLSTM); second batch-half chain
     hipStream_t side3 = nullptr;          // third independent branch of the encoder backward (Encoder_t)
     hipStream_t cap = nullptr;            // graphs are captured and replayed here (a legacy default stream cannot capture)
     hipEvent_t ev_io[2] = {};             // caller stream <-> cap ordering
-    hipEvent_t ev_join[2] = {};           // join events recorded early (see lstm_bwd's dx_ready)
+    hipEvent_t ev_join[4] = {};           // events recorded early: [0] lstm_2 branch's input gradient, [1] decoder chain done, [2] dec_in_grad done, [3] lstm_1 chain done
     hipEvent_t ev_dec[2] = {};            // split step without join: decoder chain done (caller stream) / its weight gradients done (side)
     int dec_pending = 0;                  // 0 none, 1 ev_dec[0] only, 2 both
     // captured training steps (hipGraph), keyed by geometry / flags / grad_scale; inputs are staged into engine-owned
@@ -548,6 +555,92 @@ struct Own {
     Own& operator=(const Own&) = delete;
 };
 
+
+// ---- hardware-queue probe ---------------------------------------------------------------------------------------------------------
+// HIP multiplexes a process's streams onto a few in-order hardware queues (4 by default) and does not say which stream got which.
+// Two streams on one queue execute strictly one after the other, so the step's branches lose the concurrency they exist for:
+// measured 6.34 ms with the four engine streams on four queues against 7.22 ms with the side stream on the main stream's queue
+// (profiles/r02/stream_order_effect.txt; which case one gets depends on how many streams the process -- PyTorch, RCCL -- created
+// before).  The serialisation is also what makes the assignment MEASURABLE: a kernel that spins for ~400 us on stream A delays a
+// trivial kernel on stream B only if A and B share a queue.
+__global__ void queue_probe_spin_kernel(long long ticks) {      // wall_clock64: constant 100 MHz
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+__global__ void queue_probe_nop_kernel() {}
+
+// true if a and b are served by the same hardware queue
+bool same_queue(hipStream_t a, hipStream_t b, hipEvent_t ea, hipEvent_t eb0, hipEvent_t eb1) {
+    constexpr long long SPIN_TICKS = 40000;                       // 400 us
+    (void)hipStreamSynchronize(a);
+    (void)hipStreamSynchronize(b);
+    hipLaunchKernelGGL(queue_probe_spin_kernel, dim3(1), dim3(1), 0, a, SPIN_TICKS);
+    (void)hipEventRecord(ea, a);
+    (void)hipEventRecord(eb0, b);
+    hipLaunchKernelGGL(queue_probe_nop_kernel, dim3(1), dim3(1), 0, b);
+    (void)hipEventRecord(eb1, b);
+    // poll (a blocking wait may wake up later than the spin lasts): b's kernel finished -- had a's spin finished by then?  On separate
+    // queues b is done after a few microseconds and the spin is not.
+    bool spin_done = false;
+    for (;;) {
+        const bool a_done = hipEventQuery(ea) == hipSuccess;
+        if (hipEventQuery(eb1) == hipSuccess) {
+            spin_done = a_done;
+            break;
+        }
+        if (a_done) {              // the spin ended first: b was held up behind it
+            spin_done = true;
+            break;
+        }
+    }
+    (void)hipStreamSynchronize(a);
+    return spin_done;
+}
+
+// Choose the engine's three branch streams from a pool of fresh streams so that they and `main` sit on four different hardware queues
+// (as far as the device's queue count allows); the rest of the pool is destroyed.
+int pick_streams(ss_engine* e, hipStream_t main) {
+    constexpr int POOL = 10;
+    hipStream_t pool[POOL] = {};
+    hipEvent_t ev[3] = {};
+    for (auto& x : ev) HIPCHK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+    for (auto& st : pool) {
+        HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        hipLaunchKernelGGL(queue_probe_nop_kernel, dim3(1), dim3(1), 0, st);      // first use of a stream sets its queue up: not inside a measurement
+    }
+    hipLaunchKernelGGL(queue_probe_nop_kernel, dim3(1), dim3(1), 0, main);
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<hipStream_t> chosen;
+    char buf[64];
+    e->stream_report.clear();
+    for (int pass = 0; pass < 2 && chosen.size() < 3; ++pass)       // pass 1: accept streams that only differ from the main stream's queue
+        for (int i = 0; i < POOL && chosen.size() < 3; ++i) {
+            if (!pool[i]) continue;
+            bool clash = same_queue(main, pool[i], ev[0], ev[1], ev[2]);
+            for (size_t k = 0; k < chosen.size() && !clash && pass == 0; ++k) clash = same_queue(chosen[k], pool[i], ev[0], ev[1], ev[2]);
+            if (!clash) {
+                std::snprintf(buf, sizeof buf, "%scandidate %d%s", chosen.empty() ? "" : ", ", i, pass ? " (shares a queue with another branch)" : "");
+                e->stream_report += buf;
+                chosen.push_back(pool[i]);
+                pool[i] = nullptr;
+            }
+        }
+    for (int i = 0; i < POOL && chosen.size() < 3; ++i)             // a device with fewer queues than streams: take what is there
+        if (pool[i]) {
+            chosen.push_back(pool[i]);
+            pool[i] = nullptr;
+            e->stream_report += " +fallback";
+        }
+    for (auto& st : pool)
+        if (st) (void)hipStreamDestroy(st);
+    for (auto& x : ev) (void)hipEventDestroy(x);
+    e->side = chosen[0];
+    e->side2 = chosen[1];
+    e->side3 = chosen[2];
+    e->stream_report = "branch streams on hardware queues of their own: " + e->stream_report;
+    return 0;
+}
+
 // ss_profile: bracket one launch with hipEvents on the stream it is launched on
 int prof_begin(ss_engine* e, int klass, hipStream_t st, double flops) {
     if (!((e->prof_mask >> klass) & 1u) || g_graph || e->prof_n >= ss_engine::PROF_CAP) return -1;
@@ -887,7 +980,11 @@ int lstm_input_grad(ss_engine* e, LstmBlk& lb, int l, Slab dxi, long r0, long nr
 // launches go to their branch stream.  A consumer that waits for it is not held up by whatever else shares a hardware queue with
 // `s`: an event recorded later would sit in that queue behind every packet enqueued in between (measured: the conv trunk's
 // backward idled 0.88 ms behind ~36 tiny weight-gradient launches of a sibling stream, profiles/r02/step_timeline_before.txt).
-int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hipStream_t s, hipEvent_t dx_ready = nullptr) {
+int lstm_late_weights(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t ws);
+
+// late_w: enqueue the recurrence chain and the input gradients only; the caller enqueues the block's weight gradients later
+// (lstm_late_weights) -- after the phase's critical path -- on a stream it has ordered behind this chain.
+int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hipStream_t s, hipEvent_t dx_ready = nullptr, bool late_w = false) {
     const int B = e->curB, T = e->curT, H = lb.H;
     const long TP = T + 2 * HALO, R = (long)B * TP;
     const float* dcur = d_top;
@@ -934,9 +1031,10 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
         // they stretch the latency-bound recurrence steps and halve the rate of the input-gradient GEMMs on the critical
         // path (measured: chain 2.95 ms with the GEMMs beside it against 1.93 ms alone + 0.78 ms of GEMMs), whereas the
         // encoder backward that follows is a string of small launches they can run beside.
-        const bool defer = persist && e->side && g_overlap && g_defer_dw;
+        const bool defer = (persist && e->side && g_overlap && g_defer_dw) || (late_w && nch == 1);
         if (defer) {
             if (dxi.p) CHK(lstm_input_grad(e, lb, l, dxi, 0, R, am, s));
+            if (l == 0 && dx_ready) HIPCHK(hipEventRecord(dx_ready, s));
             dcur = dxi.p;
             continue;
         }
@@ -960,15 +1058,23 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
         dcur = dxi.p;
     }
     if (nch == 2) CHK(fork_join(e, ch[1].st, s));
-    if (persist && e->side && g_overlap && g_defer_dw) {
+    if (persist && e->side && g_overlap && g_defer_dw && !late_w) {
         CHK(fork_join(e, s, e->side));
         e->side_used = true;
-        for (int l = lb.L - 1; l >= 0; --l) {
-            Slab xi = l == 0 ? x : Slab{lb.out[l - 1], 2L * H};
-            float* am = (g_bwd_f16x2 && lb.amax0 >= 0) ? e->amax + lb.amax0 + l : nullptr;
-            const bool bias_in_kernel = !g_deterministic && lb.pd[l * 2].bhh == lb.pd[l * 2].bih + 4L * H && lb.pd[l * 2 + 1].bhh == lb.pd[l * 2 + 1].bih + 4L * H;
-            CHK(lstm_weight_grads(e, lb, l, xi, am, bias_in_kernel, e->side));
-        }
+        CHK(lstm_late_weights(e, lb, x, e->side));
+    }
+    return 0;
+}
+
+// all layers' weight / bias gradients of a block whose chain ran with deferred weights (the decoder's deferred batch; every block under late_w)
+int lstm_late_weights(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t ws) {
+    const int H = lb.H;
+    const bool persist = lb.big() && g_persist && lstm_seq_supported(e->curB, H);
+    for (int l = lb.L - 1; l >= 0; --l) {
+        Slab xi = l == 0 ? x : Slab{lb.out[l - 1], 2L * H};
+        float* am = (persist && g_bwd_f16x2 && lb.amax0 >= 0) ? e->amax + lb.amax0 + l : nullptr;
+        const bool bias_in_kernel = persist && !g_deterministic && lb.pd[l * 2].bhh == lb.pd[l * 2].bih + 4L * H && lb.pd[l * 2 + 1].bhh == lb.pd[l * 2 + 1].bih + 4L * H;
+        CHK(lstm_weight_grads(e, lb, l, xi, am, bias_in_kernel, ws));
     }
     return 0;
 }
@@ -1016,6 +1122,33 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
         e->ev_next = (e->ev_next + 1) & 15;
         HIPCHK(hipEventRecord(packed, b2));
     }
+    // The branch stream's work that nobody needs before the trunk is through: bias sums / W_ih stackings, start state of the
+    // persistent recurrences, the gradient-arena memset, the parameter guard, and Encoder_t (model.py:74-89).  With g_prio_order it
+    // is ENQUEUED behind the trunk's three layers (it still runs beside them: the host is far ahead of the GPU), so that on a shared
+    // hardware queue it can never sit in front of trunk launches.
+    const bool prio_fwd = par && g_prio_order && !g_graph;
+    auto branch_work = [&]() -> int {
+        PrepTable tb;
+        tb.n = 0;
+        if (g3) CHK(lstm_prep(e, e->l1, tb, b2));
+        CHK(lstm_prep(e, e->l2, tb, b2));
+        CHK(lstm_prep(e, e->lt, tb, b2));
+        CHK(lstm_prep(e, e->ld, tb, b2));
+        HIPCHK(prep_run(tb, b2));
+        if (e->prezero && !g_graph) {        // nothing touches the gradient arena before the decoder backward; b2 is joined long before
+            HIPCHK(hipMemsetAsync(e->G, 0, e->arena * 4, b2));
+            HIPCHK(hipMemsetAsync(e->amax, 0, 16 * 4, b2));
+            e->grads_zeroed = true;
+        }
+        // fp16 x 2 products scale weights and activations by a FIXED 16 (forward and gradient contractions alike), valid while every parameter (weights, GroupNorm affine) stays
+        // below 64 in magnitude: weights < 4094 / 16, and |GroupNorm output| <= 64 * sqrt(16 T) + 64 < 4094.  Outside that
+        // range (or for a non-finite parameter) the step is marked invalid instead of silently overflowing to inf.
+        if ((g_fwd_f16x2 || g_bwd_f16x2) && e->precision == SS_PRECISION_F32 && e->sticky) HIPCHK(param_guard(e->P, e->arena, 64.0f, e->sticky, b2));
+        // Encoder_t (model.py:74-89)
+        CHK(conv_block_fwd(e, e->ct, Slab{e->org, e->hp.dim_freq}, Slab{e->act_t, e->hp.dim_enc_2}, b2));
+        CHK(lstm_fwd(e, e->lt, Slab{e->act_t, e->hp.dim_enc_2}, b2));
+        return 0;
+    };
     for (int i = 0; i < 3; ++i) {
         float* y = training ? e->act : e->xf[i];
         if (i == 1) {
@@ -1023,25 +1156,7 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
             // the WAIT was issued, not only up to the recorded event (measured: the trunk stalled ~250 us behind the tiny
             // launches below).  So: first trunk layer, the wait for the re-layouts, and only then the rest of b2's work.
             if (packed) HIPCHK(hipStreamWaitEvent(s, packed, 0));
-            PrepTable tb;
-            tb.n = 0;
-            if (g3) CHK(lstm_prep(e, e->l1, tb, b2));
-            CHK(lstm_prep(e, e->l2, tb, b2));
-            CHK(lstm_prep(e, e->lt, tb, b2));
-            CHK(lstm_prep(e, e->ld, tb, b2));
-            HIPCHK(prep_run(tb, b2));
-            if (e->prezero && !g_graph) {        // nothing touches the gradient arena before the decoder backward; b2 is joined long before
-                HIPCHK(hipMemsetAsync(e->G, 0, e->arena * 4, b2));
-                HIPCHK(hipMemsetAsync(e->amax, 0, 16 * 4, b2));
-                e->grads_zeroed = true;
-            }
-            // fp16 x 2 products scale weights and activations by a FIXED 16 (forward and gradient contractions alike), valid while every parameter (weights, GroupNorm affine) stays
-            // below 64 in magnitude: weights < 4094 / 16, and |GroupNorm output| <= 64 * sqrt(16 T) + 64 < 4094.  Outside that
-            // range (or for a non-finite parameter) the step is marked invalid instead of silently overflowing to inf.
-            if ((g_fwd_f16x2 || g_bwd_f16x2) && e->precision == SS_PRECISION_F32 && e->sticky) HIPCHK(param_guard(e->P, e->arena, 64.0f, e->sticky, b2));
-            // Encoder_t (model.py:74-89)
-            CHK(conv_block_fwd(e, e->ct, Slab{e->org, e->hp.dim_freq}, Slab{e->act_t, e->hp.dim_enc_2}, b2));
-            CHK(lstm_fwd(e, e->lt, Slab{e->act_t, e->hp.dim_enc_2}, b2));
+            if (!prio_fwd) CHK(branch_work());
         }
         // The content (512 ch) and pitch (256 ch) blocks of a layer are independent: with g_conv_par the pitch block and the layer's
         // resampling plan run on the first branch stream beside the content block.
@@ -1070,6 +1185,7 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
             HIPCHK(interp_gather(pl, e->act + HALO * CE, CE, TP * CE, e->xf[i] + HALO * CE, CE, TP * CE, CE, B, s));
         }
     }
+    if (prio_fwd) CHK(branch_work());
     if (par) {
         CHK(fork_join(e, b2, s));                  // bias sums of every block are ready (and Encoder_t is done)
         CHK(fork_join(e, s, b1));
@@ -1116,7 +1232,30 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
 }
 
 // gradient of the loss w.r.t. the head output is in d_out_slab (halo rows zero)
-int backward_decoder(ss_engine* e, hipStream_t s) {
+// weight and bias gradient of the LinearNorm head from d_out_slab and the last decoder layer's output (both untouched by the backward chain)
+int head_weight_grads(ss_engine* e, hipStream_t st) {
+    const long TP = e->curT + 2 * HALO, R = (long)e->curB * TP;
+    const long HD = 2L * e->ld.H;
+    const float* h3 = e->ld.out[e->ld.L - 1];
+    GemmDesc a{};
+    a.A = {e->d_out_slab, e->head_out, 0, 0, 0};
+    a.B = {h3, HD, 0, 0, 0};
+    a.C = e->G + e->head_w;
+    a.ldc = HD;
+    a.M = e->head_out;
+    a.N = (int)HD;
+    a.K = (int)R;
+    a.batch = 1;
+    a.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM;
+    a.ksplit = pick_ksplit(a.M, a.N, a.K);
+    PGEMM_ON(SS_PROF_HEAD, a, st);
+    HIPCHK(colsum_acc(e->d_out_slab, e->head_out, (int)R, e->head_out, e->G + e->head_b, st));
+    return 0;
+}
+
+// late: only the critical chain is enqueued here (head input gradient, recurrences, input gradients); the decoder's and the head's
+// weight gradients are enqueued by backward_encoder behind ITS critical path, ordered after the chain through ev_join[1]
+int backward_decoder(ss_engine* e, hipStream_t s, bool late = false) {
     if (!e->have_fwd) return fail("backward without a preceding forward");
     const int B = e->curB, T = e->curT;
     const long TP = T + 2 * HALO, R = (long)B * TP;
@@ -1142,24 +1281,10 @@ int backward_decoder(ss_engine* e, hipStream_t s) {
     const long HD = 2L * e->ld.H;
     const float* h3 = e->ld.out[e->ld.L - 1];
     const bool defer_head = !g_graph && e->ld.big() && g_persist && lstm_seq_supported(B, e->ld.H) && e->side && g_overlap && g_defer_dw;
-    auto head_weight_grads = [&](hipStream_t st) -> int {
-        GemmDesc a{};
-        a.A = {e->d_out_slab, e->head_out, 0, 0, 0};
-        a.B = {h3, HD, 0, 0, 0};
-        a.C = e->G + e->head_w;
-        a.ldc = HD;
-        a.M = e->head_out;
-        a.N = (int)HD;
-        a.K = (int)R;
-        a.batch = 1;
-        a.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM;
-        a.ksplit = pick_ksplit(a.M, a.N, a.K);
-        PGEMM_ON(SS_PROF_HEAD, a, st);
-        HIPCHK(colsum_acc(e->d_out_slab, e->head_out, (int)R, e->head_out, e->G + e->head_b, st));
-        return 0;
-    };
+    late = late && defer_head;
+    e->dec_w_pending = late;
     {
-        if (!defer_head) CHK(head_weight_grads(s));
+        if (!defer_head) CHK(head_weight_grads(e, s));
         GemmDesc g{};
         g.A = {e->d_out_slab, e->head_out, 0, 0, 0};
         g.B = {e->P + e->head_w, HD, 0, 0, 0};
@@ -1174,8 +1299,9 @@ int backward_decoder(ss_engine* e, hipStream_t s) {
         PGEMM_ON(SS_PROF_HEAD, g, s);
     }
     if (par) CHK(fork_join(e, b2, s));
-    CHK(lstm_bwd(e, e->ld, e->d_top, Slab{e->dec_in, e->dec_in_dim}, Slab{e->d_dec_in, e->dec_in_dim}, s));
-    if (defer_head) CHK(head_weight_grads(e->side));      // behind the decoder's weight gradients, ordered after the chain by lstm_bwd's fork
+    CHK(lstm_bwd(e, e->ld, e->d_top, Slab{e->dec_in, e->dec_in_dim}, Slab{e->d_dec_in, e->dec_in_dim}, s, nullptr, late));
+    if (late) HIPCHK(hipEventRecord(e->ev_join[1], s));          // the chain is through: what the side stream's batch waits for
+    else if (defer_head) CHK(head_weight_grads(e, e->side));      // behind the decoder's weight gradients, ordered after the chain by lstm_bwd's fork
                                                             // (measured: on the third branch stream instead 6.395 vs 6.365 ms)
     // every persistent recurrence of the step is behind this point: publish this rank's status into the gradient arena's
     // status slot (part of the decoder bucket, so a data-parallel all-reduce carries it to every rank's Adam kernel)
@@ -1208,20 +1334,31 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
     // and Encoder_t (`b3`; joins at the end).  Their weight-gradient GEMMs share the side stream.
     const bool par = e->side2 && e->side3 && g_overlap;
     hipStream_t b2 = par ? e->side2 : s, b3 = par ? e->side3 : s;
+    // prio: critical path first (g_prio_order) -- lstm_2's and lstm_1's chains and the conv trunk are enqueued before anything that only
+    // has to be done by the end of the step; the latter (decoder + head weight gradients, the encoder BLSTMs' weight gradients,
+    // Encoder_t's whole backward) follow below, each ordered behind its producer by an event that was recorded when the producer
+    // was enqueued.
+    const bool prio = par && g_prio_order && !g_graph && !e->l2.big() && !e->l1.big() && !e->lt.big();
     if (par) {
+        if (prio) HIPCHK(hipEventRecord(e->ev_join[2], s));                 // dec_in_grad done: what Encoder_t's backward needs
         CHK(fork_join(e, s, b2));
-        CHK(fork_join(e, s, b3));
+        if (!prio) CHK(fork_join(e, s, b3));
     }
     CHK(zero_conv_grads(e, b2));                   // long done when the first conv weight gradient starts (b2 joins s, b3 forks after)
-    if (par) CHK(fork_join(e, b2, b3));
+    if (par && !prio) CHK(fork_join(e, b2, b3));
     // encoder BLSTMs -> gradient of the last fused slab
     const bool early = par && !e->l2.big() && g_early_join;         // the join event of the lstm_2 branch is taken as soon as its last kernel is queued
-    CHK(lstm_bwd(e, e->l2, e->d_o2, Slab{e->xf[2] + off2, CE}, Slab{e->d_xf + off2, CE}, b2, early ? e->ev_join[0] : nullptr));
-    if (g3) CHK(lstm_bwd(e, e->l1, e->d_o1, Slab{e->xf[2], CE}, Slab{e->d_xf, CE}, s));
-    // Encoder_t
-    CHK(lstm_bwd(e, e->lt, e->d_ot, Slab{e->act_t, h.dim_enc_2}, Slab{e->d_act_t, h.dim_enc_2}, b3));
-    CHK(conv_block_bwd(e, e->ct, Slab{e->d_act_t, h.dim_enc_2}, Slab{e->org, h.dim_freq}, Slab{nullptr, 0}, b3));
-    if (early) HIPCHK(hipStreamWaitEvent(s, e->ev_join[0], 0));
+    CHK(lstm_bwd(e, e->l2, e->d_o2, Slab{e->xf[2] + off2, CE}, Slab{e->d_xf + off2, CE}, b2, (early || prio) ? e->ev_join[0] : nullptr, prio));
+    if (g3) {
+        CHK(lstm_bwd(e, e->l1, e->d_o1, Slab{e->xf[2], CE}, Slab{e->d_xf, CE}, s, nullptr, prio));
+        if (prio) HIPCHK(hipEventRecord(e->ev_join[3], s));                 // lstm_1's chain done: its weight gradients may start
+    }
+    if (!prio) {
+        // Encoder_t
+        CHK(lstm_bwd(e, e->lt, e->d_ot, Slab{e->act_t, h.dim_enc_2}, Slab{e->d_act_t, h.dim_enc_2}, b3));
+        CHK(conv_block_bwd(e, e->ct, Slab{e->d_act_t, h.dim_enc_2}, Slab{e->org, h.dim_freq}, Slab{nullptr, 0}, b3));
+    }
+    if (early || prio) HIPCHK(hipStreamWaitEvent(s, e->ev_join[0], 0));
     else if (par) CHK(fork_join(e, b2, s));
     // conv trunk, last layer first
     for (int i = 2; i >= 0; --i) {
@@ -1244,13 +1381,32 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
             HIPCHK(hipMemcpyAsync(e->d_xf, e->d_act, R * CE * 4, hipMemcpyDeviceToDevice, s));
         }
     }
+    // ---- everything that only has to be finished by the end of the step
+    if (e->dec_w_pending) {                        // backward_decoder(late): decoder + head weight gradients, behind the decoder chain
+        HIPCHK(hipStreamWaitEvent(e->side, e->ev_join[1], 0));
+        CHK(lstm_late_weights(e, e->ld, Slab{e->dec_in, e->dec_in_dim}, e->side));
+        CHK(head_weight_grads(e, e->side));
+        e->side_used = true;
+        e->dec_w_pending = false;
+    }
+    if (prio) {
+        HIPCHK(hipStreamWaitEvent(b3, e->ev_join[0], 0));                   // lstm_2's pre-activation gradients (and the zeroed conv images)
+        CHK(lstm_late_weights(e, e->l2, Slab{e->xf[2] + off2, CE}, b3));
+        if (g3) {
+            HIPCHK(hipStreamWaitEvent(b3, e->ev_join[3], 0));
+            CHK(lstm_late_weights(e, e->l1, Slab{e->xf[2], CE}, b3));
+        }
+        HIPCHK(hipStreamWaitEvent(b3, e->ev_join[2], 0));                   // d_ot from dec_in_grad
+        CHK(lstm_bwd(e, e->lt, e->d_ot, Slab{e->act_t, h.dim_enc_2}, Slab{e->d_act_t, h.dim_enc_2}, b3));
+        CHK(conv_block_bwd(e, e->ct, Slab{e->d_act_t, h.dim_enc_2}, Slab{e->org, h.dim_freq}, Slab{nullptr, 0}, b3));
+    }
     if (par) CHK(fork_join(e, b3, s));
     CHK(join_side(e, s));
     return 0;
 }
 
 int backward_core(ss_engine* e, hipStream_t s) {
-    CHK(backward_decoder(e, s));
+    CHK(backward_decoder(e, s, g_prio_order && !g_graph));
     return backward_encoder(e, s);
 }
 
@@ -1408,15 +1564,19 @@ int ss_bind(ss_engine* e, float* params, float* grads, float* m, float* v, void*
     if (!e->side && e->kind != SS_INTERP_ONLY) {
         // main + three branch streams, created back to back: HIP deals a process's streams onto its hardware queues in creation
         // order, so these four get one queue each no matter how many streams (PyTorch's, RCCL's) existed before
-        HIPCHK(hipStreamCreateWithFlags(&e->main_s, hipStreamNonBlocking));
-        {
+        if (g_own_streams) HIPCHK(hipStreamCreateWithFlags(&e->main_s, hipStreamNonBlocking));
+        if (g_probe_queues && !g_side_prio) {
+            // branch streams chosen by MEASURING which candidates share a hardware queue with the stream the step will be issued on
+            CHK(pick_streams(e, (g_own_streams && e->main_s) ? e->main_s : S(stream)));
+        } else {
             int least = 0, greatest = 0;
             HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
             HIPCHK(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, g_side_prio ? least : 0));
+            HIPCHK(hipStreamCreateWithFlags(&e->side2, hipStreamNonBlocking));
+            HIPCHK(hipStreamCreateWithFlags(&e->side3, hipStreamNonBlocking));
+            e->stream_report = "branch streams as created (probe off)";
         }
         for (auto& ev : e->ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        HIPCHK(hipStreamCreateWithFlags(&e->side2, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&e->side3, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&e->cap, hipStreamNonBlocking));
         for (auto& ev : e->ev_io) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         for (auto& ev : e->ev_dec) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -1862,6 +2022,8 @@ int ss_tune(const char* key, int value) {
     else if (k == "early_join" && (value == 0 || value == 1)) g_early_join = value;
     else if (k == "conv_par" && (value == 0 || value == 1)) g_conv_par = value;
     else if (k == "exp" && value >= 0) g_exp = value;
+    else if (k == "probe_queues" && (value == 0 || value == 1)) g_probe_queues = value;
+    else if (k == "prio_order" && (value == 0 || value == 1)) g_prio_order = value;
     else if (k == "flat_rows" && (value == 0 || value == 1)) g_flat_rows = value;
     else if (k == "deterministic" && (value == 0 || value == 1)) g_deterministic = value;
     else if (k == "split" && (value == 0 || value == 1)) g_split = value;
@@ -2044,6 +2206,8 @@ int ss_op_conv_block(const float* x, const float* w, const float* bias, const fl
     }
     return 0;
 }
+
+const char* ss_stream_report(const ss_engine* e) { return e ? e->stream_report.c_str() : ""; }
 
 int ss_debug_names(ss_engine* e, char* buf, int cap) {
     std::string all;

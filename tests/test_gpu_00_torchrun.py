@@ -22,9 +22,9 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize('extra', [[], ['--workload', 'config5', '--frames', '192', '--precision', 'bf16'],
+@pytest.mark.parametrize('extra', [[], ['--dp-backend', 'torch'], ['--workload', 'config5', '--frames', '192', '--precision', 'bf16'],
                                    ['--model', 'G6', '--batch', '32', '--frames', '192', '--precision', 'bf16']],
-                         ids=['headline', 'config5_buckets_bf16', 'config4_g6_bf16'])
+                         ids=['headline_native_rccl', 'headline_torch_distributed', 'config5_buckets_bf16', 'config4_g6_bf16'])
 def test_bench_dp_path_under_torchrun(extra):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--force-dp', '--steps', '4', '--warmup', '2',
