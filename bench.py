@@ -200,7 +200,7 @@ def main():
                     help="data-parallel collectives: torch.distributed's ProcessGroupNCCL (Engine.dp_train_step) or the engine's own RCCL "
                          "communicator (ss_g3_dp_train_step: the decoder bucket is launched on the engine's side stream itself).  Default native: "
                          "at world 1 it costs nothing over the plain step (6.32 ms) while the torch path costs +0.5 ms -- ProcessGroupNCCL's own "
-                         "stream shares a hardware queue with one of the engine's.  (Length buckets and Generator_6 always take the torch path.)")
+                         "stream shares a hardware queue with one of the engine's.  (Generator_6 always takes the torch path.)")
     ap.add_argument('--no-profile', action='store_true', help='no hipEvent brackets in the timed region (to measure their cost)')
     ap.add_argument('--tune', action='append', default=[], metavar='KEY=VALUE', help='experiment knob of the HIP library (ss_tune)')
     args = ap.parse_args()
@@ -232,7 +232,7 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     eng.set_adam(1e-4, 0.9, 0.999, 1e-8, 0)
     eng.set_precision(args.precision)
-    native = dp and args.dp_backend == 'native' and kind == 'G3' and args.workload == 'fixed'
+    native = dp and args.dp_backend == 'native' and kind == 'G3'
     if native:
         eng.comm_init(rank, world)
     mel, f0, emb, lens = synth(B, T, 1000 + rank, dev)
@@ -260,7 +260,9 @@ def main():
         if stream is not None:                       # config 5: the next length-bucketed batch, already staged on the device
             bm, be, bf, bl = next(stream)
             frames_done[0] += bm.shape[1]
-            if dp:
+            if native:
+                eng.dp_train_step_native(bm, bf, be, bl, (sc, ls), bucket=True)
+            elif dp:
                 eng.dp_train_step(bm, bf, be, bl, (sc, ls), world, bucket=True)
             else:
                 eng.g3_train_step(bm, bf, be, bl, (sc, ls), bucket=True)

@@ -126,9 +126,9 @@ int ss_allreduce_grads(ss_engine* e, long offset, long count, void* stream);
  * slices of the draws): forward, decoder backward, all-reduce of the head + decoder bucket (arena offsets >= ss_grad_split(),
  * 80 % of the bytes, incl. the status slot) ON the engine stream that carries the decoder's weight-gradient GEMMs -- so it
  * runs beside the encoder backward --, encoder backward, all-reduce of the encoder bucket, Adam with the 1/world mean folded
- * in.  loss: this rank's local mean loss. */
+ * in.  flags: 0 or SS_STEP_BUCKET (every rank passes the same T).  loss: this rank's local mean loss. */
 int ss_g3_dp_train_step(ss_engine* e, const float* mel_dev, const float* f0_dev, const float* emb_dev, const int* len_org_dev,
-                        const float* scales_dev, const int* len_seg_dev, int B, int T, float* loss_dev, void* stream);
+                        const float* scales_dev, const int* len_seg_dev, int B, int T, int flags, float* loss_dev, void* stream);
 
 /* torch.optim.Adam(G.parameters(), lr, [beta1, beta2]) (solver.py:62,172).  `step` = updates already applied. */
 int ss_set_adam(ss_engine* e, double lr, double beta1, double beta2, double eps, long step, void* stream);

@@ -2317,10 +2317,17 @@ int ss_allreduce_grads(ss_engine* e, long offset, long count, void* stream) {
 }
 
 int ss_g3_dp_train_step(ss_engine* e, const float* mel, const float* f0, const float* emb, const int* len_org, const float* scales,
-                        const int* len_seg, int B, int T, float* loss, void* stream) {
+                        const int* len_seg, int B, int T, int flags, float* loss, void* stream) {
     if (e->kind != SS_GENERATOR_3) return fail("ss_g3_dp_train_step on a Generator_6 engine");
     if (!e->comm) return fail("ss_g3_dp_train_step: call ss_comm_init first");
-    if (T != e->hp.max_len_pad) return fail("training needs T == max_len_pad (model.py:105,157,370)");
+    if (flags & SS_STEP_BUCKET) {      // every rank runs the same bucket (speechsplit_amd/buckets.py)
+        if (T < 8 || T > e->maxT || T % 8) return fail("SS_STEP_BUCKET: T must be a multiple of 8 within the engine's max_frames");
+        if (e->hp.max_len_pad != T) {
+            e->hp.max_len_pad = T;
+            e->curB = e->curT = 0;
+        }
+    }
+    if (T != e->hp.max_len_pad) return fail("training needs T == max_len_pad (model.py:105,157,370); pass SS_STEP_BUCKET for a length-bucketed batch");
     CHK(sticky_check(e));
     Own own(e, stream);
     hipStream_t s = own.s;

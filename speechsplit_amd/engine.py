@@ -240,14 +240,14 @@ class Engine:
         hi = self.grads.numel() if hi is None else hi
         _capi.check(self.lib.ss_allreduce_grads(self.h, int(lo), int(hi - lo), _stream()))
 
-    def dp_train_step_native(self, mel, f0, emb, len_org, draws):
+    def dp_train_step_native(self, mel, f0, emb, len_org, draws, bucket=False):
         """ss_g3_dp_train_step: the overlapped two-bucket schedule with the collectives launched by the engine itself, the
         decoder bucket ON the engine stream that carries the decoder's weight-gradient GEMMs."""
         B, T, _ = mel.shape
         mel, f0, emb, len_org = self._f(mel), self._f(f0), self._f(emb), self._i(len_org)
         sc, ls = self._draws(draws)
         _capi.check(self.lib.ss_g3_dp_train_step(self.h, _ptr(mel), _ptr(f0), _ptr(emb), _ptr(len_org), _ptr(sc), _ptr(ls), B, T,
-                                                 _ptr(self.loss), _stream()))
+                                                 16 if bucket else 0, _ptr(self.loss), _stream()))
         return self.loss
 
     # ------------------------------------------------------------------ Generator_6
