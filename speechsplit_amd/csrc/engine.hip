@@ -20,7 +20,7 @@ using namespace ss;
 
 namespace ss {
 extern int g_small_lds, g_gemm_tr, g_deterministic;
-extern int g_lstm_nw, g_lstm_g, g_lstm_mode, g_gemm_bk, g_gemm_want, g_gemm_diag, g_seq_prio, g_gemm_mode, g_seq_spin_log2;
+extern int g_lstm_nw, g_lstm_g, g_lstm_mode, g_gemm_bk, g_gemm_want, g_gemm_diag, g_seq_prio, g_gemm_mode, g_seq_spin_log2, g_seq_tag, g_seq_wlead;
 int g_fwd_f16x2 = 1;   // 1: forward contractions (operands bounded by construction: mel, one-hot, GroupNorm/ReLU outputs, |h| < 1, weights)
                        //    use the fp16 x 2 split (3 MFMAs) instead of bf16 x 3 (6 MFMAs); gradients keep bf16 x 3 (their range is not bounded)
 int g_bwd_f16x2 = 1;   // 1: the decoder's and the conv trunk's gradient GEMMs also use fp16 x 2: the gradient operand is scaled by the power
@@ -31,6 +31,7 @@ int g_conv_want = 256;    // experiment: workgroup target of the conv GEMMs' til
 int g_defer_dw = 1;    // 1: the decoder's weight-gradient GEMMs start after its last input gradient (see lstm_bwd)
 int g_side_prio = 0;   // 1: create the side stream with the lowest priority (read at ss_bind).  Measured: 2.3x SLOWER
                        //    (35 ms vs 14.8 ms per step): the low-priority queue starves behind 768 tiny step launches.
+int g_op_time_major = 0;   // experiment: ss_op_lstm_fwd / _bwd take time-major slabs [T+4, B, C] (persistent kernels only)
 int g_persist = 1;     // 1: decoder recurrences run as ONE persistent launch per layer (lstm_seq.hip) when the batch fits
 int g_split = 0;       // 1: decoder recurrences run as two batch-half chains on two streams (GEMMs of one half fill the
                        //    machine while the other half sits in its latency-bound time loop)
@@ -104,14 +105,15 @@ struct LstmBlk {
     float* dc[2] = {nullptr, nullptr};     // per chain: [2][B][H]
     unsigned* sync = nullptr;              // persistent kernels: group counters + abort word (one-off ops path)
     // persistent schedule: per-layer start state, contiguous so ONE memset per pass readies every layer's launch.
-    //   zf = [L][LSTM_SEQ_SYNC_WORDS] ++ [L][hf]      (forward)        zb = [L][LSTM_SEQ_SYNC_WORDS]   (backward)
+    //   zf = [L][LSTM_SEQ_SYNC_WORDS] ++ [L][hf]      (forward)        zb = [L][LSTM_SEQ_SYNC_WORDS] ++ [L][exchange tiles]   (backward)
     char *zf = nullptr, *zb = nullptr;
     long zf_bytes = 0, zb_bytes = 0, hf_bytes = 0, gf_bytes = 0;
     unsigned* sync_f(int l) const { return (unsigned*)zf + LSTM_SEQ_SYNC_WORDS * l; }
     unsigned* sync_b(int l) const { return (unsigned*)zb + LSTM_SEQ_SYNC_WORDS * l; }
     void* hf_l(int l) const { return zf + 4L * LSTM_SEQ_SYNC_WORDS * L + hf_bytes * l; }
     int amax0 = -1;                        // first slot in ss_engine::amax (one per layer) when the block's gradient GEMMs may use fp16 x 2
-    void* px = nullptr;                    // backward exchange tiles (shared by the layers, needs no initial state)
+    // backward exchange tiles, one set per layer: the tagged hand-off (lstm_seq.hip) needs them zero at launch
+    void* px_l(int l) const { return zb + 4L * LSTM_SEQ_SYNC_WORDS * L + gf_bytes * l; }
     float* dmid[2] = {nullptr, nullptr};   // gradient slabs of inner layer outputs [B,TP,2H]
     bool big() const { return H > 32; }
     int in_of(int l) const { return l == 0 ? In : 2 * H; }
@@ -361,10 +363,9 @@ long ss_engine::carve(int B, int T, bool assign) {
             lb.hf_bytes = lstm_seq_xbytes(B, lb.H, false);       // exchange buffers of the persistent kernels
             lb.gf_bytes = lstm_seq_xbytes(B, lb.H, true);
             lb.zf_bytes = lb.L * (4L * LSTM_SEQ_SYNC_WORDS + lb.hf_bytes);
-            lb.zb_bytes = lb.L * 4L * LSTM_SEQ_SYNC_WORDS;
+            lb.zb_bytes = lb.L * (4L * LSTM_SEQ_SYNC_WORDS + lb.gf_bytes);
             lb.zf = (char*)take(lb.zf_bytes);
             lb.zb = (char*)take(lb.zb_bytes);
-            lb.px = take(lb.gf_bytes);
         }
         if (lb.L > 1) {
             lb.dmid[0] = slab((name + ".dmid0").c_str(), 2L * lb.H);
@@ -846,7 +847,7 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
         if (persist) {   // start state zeroed by lstm_prep
             const int pi = prof_begin(e, SS_PROF_REC_FWD, s, 2.0 * 2 * B * T * 4.0 * H * H);
             HIPCHK(lstm_seq_fwd(lb.gates[l], e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.hf_l(l), lb.out[l], lb.csave[l],
-                                lb.sync_f(l), e->sticky, B, T, H, false, s));
+                                lb.sync_f(l), e->sticky, B, T, H, false, false, s));
             prof_end(e, pi, s);
             continue;
         }
@@ -1011,9 +1012,9 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
             // persistent: start state zeroed by backward_decoder
             if (persist) {
                 const int pi = prof_begin(e, SS_PROF_REC_BWD, s, 2.0 * 2 * B * T * 4.0 * H * H);
-                HIPCHK(lstm_seq_bwd(dG, e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.px, dcur, lb.csave[l], lb.sync_b(l),
+                HIPCHK(lstm_seq_bwd(dG, e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.px_l(l), dcur, lb.csave[l], lb.sync_b(l),
                                     e->sticky, am, bias_in_kernel ? e->G + lb.pd[l * 2].bih : nullptr,
-                                    bias_in_kernel ? e->G + lb.pd[l * 2 + 1].bih : nullptr, B, T, H, false, s));
+                                    bias_in_kernel ? e->G + lb.pd[l * 2 + 1].bih : nullptr, B, T, H, false, false, s));
                 prof_end(e, pi, s);
             }
             for (int st = 0; st < T && !persist; ++st)
@@ -1270,7 +1271,8 @@ int backward_decoder(ss_engine* e, hipStream_t s, bool late = false) {
     if (par) CHK(fork_join(e, s, b2));
     if (e->ld.big()) {
         if (g_persist && lstm_seq_supported(e->curB, e->ld.H)) {
-            HIPCHK(hipMemsetAsync(e->ld.zb, 0, e->ld.zb_bytes, b2));   // the group counters of every layer
+            // the group counters of every layer and, for the tagged hand-off, their exchange tiles
+            HIPCHK(hipMemsetAsync(e->ld.zb, 0, (g_seq_tag & 2) ? e->ld.zb_bytes : e->ld.L * 4L * LSTM_SEQ_SYNC_WORDS, b2));
         } else {
             for (int l = 0; l < e->ld.L; ++l)
                 HIPCHK(lstm_pack_w(e->P + e->ld.pd[l * 2].whh, e->P + e->ld.pd[l * 2 + 1].whh, e->ld.wfrag[l], e->ld.H, 1, b2));
@@ -2006,10 +2008,13 @@ int ss_tune(const char* key, int value) {
 #ifdef SS_DIAG
     else if (k == "lstm_mode" && value >= 0 && value <= 4) g_lstm_mode = value;
     else if (k == "gemm_diag" && value >= 0 && value < 512) g_gemm_diag = value;
-    else if (k == "seq_prio" && value >= 0 && value < 1024) g_seq_prio = value;
+    else if (k == "seq_prio" && value >= 0 && value < 65536) g_seq_prio = value;
 #else
     else if (k == "seq_prio" && (value == 0 || value == 1)) g_seq_prio = value;
 #endif
+    else if (k == "seq_tag" && value >= 0 && value <= 3) g_seq_tag = value;
+    else if (k == "op_time_major" && (value == 0 || value == 1)) g_op_time_major = value;
+    else if (k == "seq_wlead" && value >= 0 && value < 32) g_seq_wlead = value;
     else if (k == "seq_spin_log2" && value >= 0 && value <= 24) g_seq_spin_log2 = value;
     else if (k == "overlap" && (value == 0 || value == 1)) g_overlap = value;
     else if (k == "defer_dw" && (value == 0 || value == 1)) g_defer_dw = value;
@@ -2052,7 +2057,7 @@ int ss_op_lstm_fwd(float* gates, const float* whh_f, const float* whh_b, float* 
         float* hf = scratch + wn;
         if (g_persist && lstm_seq_supported(B, H) && wn * 4 >= lstm_seq_xbytes(B, H, false)) {
             // exchange buffer in the (unused) packed-weight area, counters behind it
-            HIPCHK(lstm_seq_fwd(gates, whh_f, whh_b, scratch, out, csave, (unsigned*)hf, nullptr, B, T, H, true, s));
+            HIPCHK(lstm_seq_fwd(gates, whh_f, whh_b, scratch, out, csave, (unsigned*)hf, nullptr, B, T, H, true, g_op_time_major != 0, s));
             return 0;
         }
         HIPCHK(lstm_pack_w(whh_f, whh_b, scratch, H, 0, s));
@@ -2076,7 +2081,7 @@ int ss_op_lstm_bwd(float* gates, const float* whh_f, const float* whh_b, const f
         const long xbytes = lstm_seq_xbytes(B, H, true);
         if (g_persist && lstm_seq_supported(B, H) && scratch_floats * 4 >= xbytes + 4L * LSTM_SEQ_SYNC_WORDS) {     // [exchange tiles][flags]
             HIPCHK(lstm_seq_bwd(gates, whh_f, whh_b, scratch, d_out, csave, (unsigned*)((char*)scratch + xbytes), nullptr, nullptr, nullptr, nullptr, B, T,
-                                H, true, s));
+                                H, true, g_op_time_major != 0, s));
             return 0;
         }
         HIPCHK(lstm_pack_w(whh_f, whh_b, scratch, H, 1, s));

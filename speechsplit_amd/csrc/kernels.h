@@ -148,13 +148,13 @@ bool lstm_seq_supported(int B, int H);
 long lstm_seq_xbytes(int B, int H, bool backward);
 // sticky (nullable): engine-wide word, host-visible, that a launch ORs 1 into when its bounded wait expires (never cleared by a step)
 hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, float* out, float* csave,
-                        unsigned* sync, unsigned* sticky, int B, int T, int H, bool zero_state, hipStream_t s);
+                        unsigned* sync, unsigned* sticky, int B, int T, int H, bool zero_state, bool time_major, hipStream_t s);
 // amax (nullable): device word that receives max |pre-activation gradient| written (atomic max of the float's bit pattern;
 // zero it first) -- the scale the fp16 x 2 GEMMs that consume the gradient slab need
 // gbias_f / gbias_b (nullable): [2][4H] gradient accumulators of (b_ih, b_hh) of the forward / reverse direction; the kernel
 // adds the sum over utterances and time of the pre-activation gradients to both halves (f32 atomics)
 hipError_t lstm_seq_bwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, const float* d_out,
                         const float* csave, unsigned* sync, unsigned* sticky, float* amax, float* gbias_f, float* gbias_b, int B, int T,
-                        int H, bool zero_state, hipStream_t s);
+                        int H, bool zero_state, bool time_major, hipStream_t s);
 
 }  // namespace ss

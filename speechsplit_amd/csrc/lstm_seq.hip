@@ -40,6 +40,9 @@
 namespace ss {
 
 int g_seq_prio = 1;    // 1: persistent recurrence waves run at s_setprio 3
+int g_seq_tag = 3;     // the hand-off payload carries its own step tag (no flag round trip, see "Tagged payload" below) instead of a flag line
+                       // per group: bit 0 forward, bit 1 backward
+int g_seq_wlead = 0;   // backward kernel: steps between a warm-up read and the operand request it serves (0: the kernel's default)
 int g_seq_spin_log2 = 18;   // bounded wait of the group hand-off: 2^18 polls ~ tens of ms.  ss_tune("seq_spin_log2", 4) makes the
                             // first wait of a launch expire, which is how the tests exercise the abort path on hardware
 
@@ -48,7 +51,8 @@ namespace {
 __device__ __forceinline__ float sigmoidf_(float x) { return ss_sigmoid(x); }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-// `prio` kernel argument: bit 0 s_setprio, bits 1..15 timing experiments (SS_DIAG builds only), bits 16..20 log2 of the spin limit
+// `prio` kernel argument: bit 0 s_setprio, bits 1..15 timing experiments (SS_DIAG builds only), bits 16..20 log2 of the spin limit,
+// bit 21 time-major slabs, bits 22..26 warm-up lead of the backward kernel (0: default)
 __device__ __forceinline__ unsigned spin_limit_of(int prio) { return 1u << ((prio >> 16) & 31); }
 
 // Group hand-off without read-modify-write traffic: every member owns one word of its group's flag line (32 words = one
@@ -81,6 +85,35 @@ __device__ __forceinline__ bool wait_flags(const unsigned* flags, int members, u
 }
 __device__ __forceinline__ void publish(unsigned* flag, unsigned v) {
     __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Tagged payload (TAG kernels).  The flag protocol costs three dependent L2 trips per step: payload stores acknowledged ->
+// flag store -> a poll that sees it -> payload loads.  Here every payload DWORD carries the tag of its step in bit 0, so the
+// consumer polls the payload itself and needs no ordering between dwords at all: one trip.  A ping-pong half is reused every
+// second step; its tag alternates per use and starts at 1, so the buffers must be ZERO when a launch starts (the engine keeps
+// one exchange buffer per layer and clears them all with one memset per pass).  The tag displaces the last significand bit
+// of an fp32 partial sum (backward) or of one fp16 piece per dword (forward, where the low piece absorbs the change of the
+// high one): below the fp16 x 2 product's own 2^-22.
+__device__ __forceinline__ unsigned tag_of(int st) { return (((unsigned)(st - 1) >> 1) + 1u) & 1u; }      // payload consumed at step st >= 1
+// bounded-poll bookkeeping shared by the tagged loops: false = give up (abort raised here or elsewhere)
+__device__ __forceinline__ bool poll_continue(unsigned spins, const SeqAbort& ab) {
+    if ((spins & 63) == 63 && __hip_atomic_load(ab.launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+    if (spins > ab.limit) {
+        if ((threadIdx.x & 63) == 0) {
+            __hip_atomic_store(ab.launch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ab.sticky) __hip_atomic_fetch_or(ab.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+    return true;
+}
+
+// LDS read the compiler cannot see: a wave with LDS-DMA in flight would otherwise be made to wait for all of it first
+__device__ __forceinline__ int lds_peek(const int* p) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(unsigned long)(__attribute__((address_space(3))) const int*)p) : "memory");
+    return v;
 }
 
 __device__ __forceinline__ void store_sc1(float* p, float v) {
@@ -259,26 +292,52 @@ __device__ __forceinline__ long xb_group(int dir, int nbt, int bt, int KC) { ret
 
 // one lane's bf16 pieces of value (b % 16 = bi, k) go to chunk k/32, lane 16*(k%32/8)+bi, element k%8.  Two lanes with
 // adjacent k (even, odd) combine their 16-bit pieces so that the even one stores whole dwords (write-through).
-__device__ __forceinline__ void xb_store(unsigned char* xb_plane0, long plane_stride, int k, int bi, float v, bool local) {
+// One 16-byte write-through store per lane (whole 1 KiB tiles per wave: no partial sectors).  NOTE: hipcc inserts the
+// MFMA -> VMEM-read wait states only for consumers it can see, so the value handed in must come from a VALU instruction
+// (here: the accumulator times the row's unscale factor), never straight out of an MFMA.  The trailing s_nop covers the other
+// hazard hipcc cannot see through the asm: the data registers of a store wider than 64 bits must not be rewritten in the two
+// wait states after it.
+__device__ __forceinline__ void store16_sc1(unsigned char* p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store16_plain(unsigned char* p, f32x4 v) {      // XCD-local groups only
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
+// tag < 0: untagged (flag protocol).  Otherwise bit 0 of each stored dword -- the last significand bit of the EVEN element's
+// piece -- is the step tag: the high piece is forced first and the low piece is taken from what is then left, so the pair still
+// represents the value to within the low piece's own last bit.
+// The eight lanes that hold k % 8 = 0 .. 7 of one utterance row (consecutive lanes of one wave) gather their pieces in three
+// exchange rounds, and the first of them stores whole 16-byte fragment slots: a workgroup's h lands as 512 contiguous bytes per
+// plane in 2 x 32 lane-stores instead of 2 x 128 four-byte ones (-0.1 us per step).
+__device__ __forceinline__ void xb_store(unsigned char* xb_plane0, long plane_stride, int k, int bi, float v, bool local, int tag = -1) {
     unsigned h, l;
-    split1_f16(v * HSCALE, h, l);
-    const unsigned ph = __shfl_xor((int)h, 1), pl = __shfl_xor((int)l, 1);
-    if ((k & 1) == 0) {
-        unsigned char* q = xb_plane0 + (long)(k >> 5) * 1024 + ((((k & 31) >> 3) * 16 + bi) << 4) + ((k & 7) << 1);
+    if (tag >= 0 && (k & 1) == 0) {
+        const float y = v * HSCALE;
+        h = ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)y) & ~1u) | (unsigned)tag;
+        const float hv = (float)__builtin_bit_cast(_Float16, (unsigned short)h);
+        l = ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)(y - hv)) & ~1u) | (unsigned)tag;
+    } else split1_f16(v * HSCALE, h, l);
+    const unsigned h0 = h | ((unsigned)__shfl_xor((int)h, 1) << 16), l0 = l | ((unsigned)__shfl_xor((int)l, 1) << 16);      // lanes k % 2 == 0: (k, k+1)
+    const unsigned h1 = (unsigned)__shfl_xor((int)h0, 2), l1 = (unsigned)__shfl_xor((int)l0, 2);                             // lanes k % 4 == 0: (k+2, k+3)
+    const u32x4 hq = {h0, h1, (unsigned)__shfl_xor((int)h0, 4), (unsigned)__shfl_xor((int)h1, 4)};                           // lanes k % 8 == 0: k .. k+7
+    const u32x4 lq = {l0, l1, (unsigned)__shfl_xor((int)l0, 4), (unsigned)__shfl_xor((int)l1, 4)};
+    if ((k & 7) == 0) {
+        unsigned char* q = xb_plane0 + (long)(k >> 5) * 1024 + ((((k & 31) >> 3) * 16 + bi) << 4);
         if (local) {                                   // group on one XCD: ordinary stores reach the shared L2
-            *reinterpret_cast<unsigned*>(q) = h | (ph << 16);
-            *reinterpret_cast<unsigned*>(q + plane_stride) = l | (pl << 16);
-            return;
+            store16_plain(q, __builtin_bit_cast(f32x4, hq));
+            store16_plain(q + plane_stride, __builtin_bit_cast(f32x4, lq));
+        } else {
+            store16_sc1(q, __builtin_bit_cast(f32x4, hq));
+            store16_sc1(q + plane_stride, __builtin_bit_cast(f32x4, lq));
         }
-        __hip_atomic_store(reinterpret_cast<unsigned*>(q), h | (ph << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(reinterpret_cast<unsigned*>(q + plane_stride), l | (pl << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
 // grid = ngroups * (H/16), block = 64*NW.   sync (LSTM_SEQ_SYNC_WORDS, all zero on entry, like xb): [0] abort word,
 // [1 + group] XCD masks, [64 + 32 * group + member] completion flags
-template <int H, int NW>
-__global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict__ gates, const float* __restrict__ whh_f,
+template <int H, int NW, bool TAG>
+__global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_fwd_kernel(float* __restrict__ gates, const float* __restrict__ whh_f,
                                                                const float* __restrict__ whh_b, unsigned char* __restrict__ xb,
                                                                float* __restrict__ out, float* __restrict__ csave,
                                                                unsigned* __restrict__ sync, unsigned* __restrict__ sticky, int B, int T,
@@ -287,10 +346,20 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
     static_assert(KS == 2, "the persistent forward kernel is written for 64 reduction elements per wave");
     // per-wave partial sums, [unit column][utterance row], rows padded to 20 floats: a lane writes its four accumulator rows
     // with one ds_write_b128 and the cell threads' reads spread over all 32 banks
-    __shared__ __attribute__((aligned(16))) float red[NW][4][16][20];
+    // Tagged hand-off: two copies, alternating per step, and ONE barrier per step (a fast wave's partial sums of step t+1 must not
+    // land on the copy the cell threads of step t are still reading; by step t+2 they are behind step t+1's barrier).
+    __shared__ __attribute__((aligned(16))) float red[TAG ? 2 : 1][NW][4][16][20];
+    // Waves NW and NW + 1 are the memory waves (see the backward kernel): the first brings the input projections of the coming
+    // steps into a ring in LDS by LDS-DMA, the second writes the activated gates, c and h the cell threads leave in LDS to the
+    // slabs one step later.  The waves on the hand-off path then have nothing in flight but the payload and their polls, and the
+    // step barriers order LDS traffic only.
+    constexpr int OPD = 4;                                                          // steps between a request and its use
+    __shared__ __attribute__((aligned(16))) float ops[OPD + 2][16 * 64];            // slot = step % (OPD + 2), float utterance * 64 + gate * 16 + unit
+    __shared__ __attribute__((aligned(16))) float st_buf[2][6][16][16];             // [step parity][i, f, g, o, c, h][utterance][unit]
     __shared__ int s_ok;
     if (prio & 1) __builtin_amdgcn_s_setprio(3);  // the recurrence is the critical path; co-resident GEMM waves are filler
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool loader = w == NW, helper = w >= NW;         // wave NW + 1 stores
     const int ngroups = 2 * nbt;
     const int grp = blockIdx.x % ngroups, jt = blockIdx.x / ngroups;
     const int dir = grp / nbt, bt = grp % nbt;
@@ -313,6 +382,79 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
     if (s_ok < 0) return;
     const bool local = s_ok == 1 || (diag & 32);
     __syncthreads();                                       // s_ok is reused by the step loop
+    if (TAG && tid == 0) s_ok = 1;                         // tagged: cleared by a wave whose poll gave up; first read behind step 0's barrier
+
+    auto tau_of = [&](int st) { return HALO + (dir == 0 ? st : T - 1 - st); };
+    // slab row of (utterance, haloed time): batch-major [B, T+4, C] or time-major [T+4, B, C] (prio bit 21)
+    const bool tm = (prio >> 21) & 1;
+    auto row_of = [&](int bb, int tau) { return tm ? (long)tau * B + bb : (long)bb * TP + tau; };
+    if (helper) {
+        // the working waves' barriers of one step, in the same order; false: the launch is being abandoned
+        auto step_barriers = [&](int st) -> bool {
+            if constexpr (!TAG) {
+                if (st > 0) {
+                    lds_barrier();
+                    if (!lds_peek(&s_ok)) return false;
+                }
+            }
+            lds_barrier();
+            if (TAG && !lds_peek(&s_ok)) return false;
+            if constexpr (!TAG) lds_barrier();
+            return true;
+        };
+        if (loader) {
+            // request i of a step: idx = lane + 64 i -> utterance idx / 16, gate (idx % 16) / 4, units 4 * (idx % 4) .. + 3; steps past
+            // the end re-request the last one (into slots nobody reads any more) so that the count below stays a constant
+            auto request = [&](int st) {
+                const int tau = tau_of(st < T ? st : T - 1);
+                typedef __attribute__((address_space(3))) void* lds_t;
+                float* slot = ops[st % (OPD + 2)];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int idx = lane + 64 * i, u = idx >> 4, g = (idx & 15) >> 2, q = idx & 3;
+                    const int bu = bt * 16 + u < B ? bt * 16 + u : B - 1;
+                    __builtin_amdgcn_global_load_lds((const void*)(gates + row_of(bu, tau) * (8 * H) + dir * 4 * H + g * H + jt * 16 + 4 * q), (lds_t)(slot + 256 * i), 16, 0, 0);
+                }
+            };
+            if (!(diag & 4)) {
+                for (int st = 0; st < OPD; ++st) request(st);
+            }
+            bool ok = true;
+            for (int st = 0; st < T && ok; ++st) {
+                if (!(diag & 4)) {
+                    request(st + OPD);                 // its slot held step st - 2: read before step st - 1's barrier
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * OPD) : "memory");      // in order: everything up to step st has landed
+                }
+                ok = step_barriers(st);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing may land in this LDS after the workgroup has gone
+            if (!ok) return;
+            lds_barrier();                                         // the storer's last step
+        } else {
+            // step st - 1's results, behind step st's barrier (the cell threads are writing the other copy by then)
+            auto store_step = [&](int st) {
+                if (diag & 8) return;
+                const int tau = tau_of(st);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const int idx = lane + 64 * i, u = idx / 24, o = (idx % 24) >> 2, q = idx & 3;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(&st_buf[st & 1][o][u][4 * q]);
+                    if (bt * 16 + u >= B) continue;
+                    const long r = row_of(bt * 16 + u, tau);
+                    float* dst = o < 4 ? gates + r * (8 * H) + dir * 4 * H + o * H + jt * 16 + 4 * q
+                                       : (o == 4 ? csave : out) + r * (2 * H) + dir * H + jt * 16 + 4 * q;
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                }
+            };
+            for (int st = 0; st < T; ++st) {
+                if (!step_barriers(st)) return;
+                if (st > 0) store_step(st - 1);
+            }
+            lds_barrier();
+            store_step(T - 1);
+        }
+        return;
+    }
 
     // this wave's slice of W_hh as fp16 pieces, resident in registers for the whole sequence:
     // B fragment of gate g, k-step ks: lane holds W_hh[g*H + jt*16 + li][(w*KS + ks)*32 + 8*lq .. +7]
@@ -334,61 +476,49 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
     const unsigned char* xrd = xb + xb_group(dir, nbt, bt, KC) + (long)(w * KS) * 1024 + lane * 16;
     unsigned char* xwr = xb + xb_group(dir, nbt, bt, KC);
     const int bi = (tid >> 4) & 15, jj = tid & 15;
-    const int b = bt * 16 + bi, j = jt * 16 + jj;
-    const int bc = b < B ? b : B - 1;
+    const int j = jt * 16 + jj;
     const bool cell = tid < 256;
     float c_state = 0.f, h_val = 0.f;
-    float sv[4] = {0.f, 0.f, 0.f, 0.f};
-    float xg[4] = {0.f, 0.f, 0.f, 0.f}, xn[4] = {0.f, 0.f, 0.f, 0.f};
-    auto tau_of = [&](int st) { return HALO + (dir == 0 ? st : T - 1 - st); };
-    auto grow_of = [&](int tau) { return gates + ((long)bc * TP + tau) * (8 * H) + dir * 4 * H + j; };
-    if (cell) {
-        const float* g0 = grow_of(tau_of(0));
-#pragma unroll
-        for (int g = 0; g < 4; ++g) xg[g] = g0[g * H];
-    }
-    float sv_p[4] = {0.f, 0.f, 0.f, 0.f}, c_p = 0.f, h_p = 0.f;
-    int tau_p = -1;
-    auto flush_slabs = [&]() {
-        if (cell && b < B && tau_p >= 0 && !(diag & 8)) {
-            float* gr = grow_of(tau_p);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) gr[g * H] = sv_p[g];
-            const long o = ((long)b * TP + tau_p) * (2 * H) + dir * H + j;
-            csave[o] = c_p;
-            out[o] = h_p;
-        }
-        tau_p = -1;
-    };
 
     for (int st = 0; st < T; ++st) {
-        const int tau = tau_of(st);
-        if (cell && st + 1 < T && !(diag & 4)) {        // next step's input projection, requested before the wait
-            const float* gn = grow_of(tau_of(st + 1));
-#pragma unroll
-            for (int g = 0; g < 4; ++g) xn[g] = gn[g * H];
-        }
         f32x4 acc[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (st > 0) {                                   // h(-1) = 0: nothing to multiply at the first step
-            // two waves watch the flag line half a round trip apart: the arrival is seen a quarter of a round trip earlier on
-            // average (more watchers only delay the members' flag stores: eight per workgroup tripled the step)
-            if (w < 2) {
-                if (w == 1) __builtin_amdgcn_s_sleep(8);
-                const bool ok = (diag & 16) ? true : wait_flags(flags, JT, (unsigned)(st + 1), abortp);
-                if (lane == 0 && (w == 0 || !ok)) s_ok = ok ? 1 : 0;
-            }
-            __syncthreads();
-            if (!s_ok) return;                          // uniform: every thread reads the same LDS word
             const unsigned char* p0 = xrd + (st & 1) * half;
             const unsigned char* p1 = p0 + plane;
             u32x4 r[KS][2];
+            if constexpr (!TAG) {
+                // two waves watch the flag line half a round trip apart: the arrival is seen a quarter of a round trip earlier on
+                // average (more watchers only delay the members' flag stores: eight per workgroup tripled the step)
+                if (w < 2) {
+                    if (w == 1) __builtin_amdgcn_s_sleep(8);
+                    const bool ok = (diag & 16) ? true : wait_flags(flags, JT, (unsigned)(st + 1), abortp);
+                    if (lane == 0 && (w == 0 || !ok)) s_ok = ok ? 1 : 0;
+                }
+                lds_barrier();
+                if (!s_ok) return;                      // uniform: every thread reads the same LDS word
+            }
             if (diag & 1) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) r[ks][0] = r[ks][1] = u32x4{0u, 0u, 0u, 0u};
+            } else if constexpr (TAG) {
+                // every wave polls its own four fragments (64 hidden units = four producers) until all dwords carry this step's tag
+                const unsigned tg = tag_of(st);
+                for (unsigned spins = 0;; ++spins) {
+                    load2x2_sc1(p0, p1, r);
+                    unsigned bad = 0;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                        for (int pc = 0; pc < 2; ++pc) bad |= (r[ks][pc][0] ^ tg) | (r[ks][pc][1] ^ tg) | (r[ks][pc][2] ^ tg) | (r[ks][pc][3] ^ tg);
+                    if (__all(!(bad & 1u)) || (diag & 16) != 0) break;
+                    if (!poll_continue(spins, abortp)) {
+                        if (lane == 0) s_ok = 0;
+                        break;
+                    }
+                }
             } else load2x2_sc1(p0, p1, r);
-            flush_slabs();                              // last step's slab copies: their acks hide behind the products below
             {
                 const f16x8 a[2] = {__builtin_bit_cast(f16x8, r[0][0]), __builtin_bit_cast(f16x8, r[0][1])};
                 mfma3_each<4>(a, [&](int g, int pc) -> const f16x8& { return bw[g][0][pc]; }, acc);
@@ -398,54 +528,41 @@ __global__ __launch_bounds__(64 * NW) void lstm_seq_fwd_kernel(float* __restrict
                 mfma3_each<4>(a, [&](int g, int pc) -> const f16x8& { return bw[g][1][pc]; }, acc);
             }
         }
+        auto& rd = red[TAG ? (st & 1) : 0];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(&red[w][g][li][lq * 4]) = acc[g];
-        __syncthreads();
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(&rd[w][g][li][lq * 4]) = acc[g];
+        lds_barrier();
+        if (TAG && !s_ok) return;                       // uniform
         if (cell) {
+            const float* xg = ops[st % (OPD + 2)] + bi * 64 + jj;
             float pre[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float s = 0.f;
 #pragma unroll
-                for (int ww = 0; ww < NW; ++ww) s += red[ww][g][jj][bi];
-                pre[g] = xg[g] + s * (1.0f / (HSCALE * WSCALE));
+                for (int ww = 0; ww < NW; ++ww) s += rd[ww][g][jj][bi];
+                pre[g] = xg[g * 16] + s * (1.0f / (HSCALE * WSCALE));
             }
             const float gi = sigmoidf_(pre[0]), gf = sigmoidf_(pre[1]), gg = ss_tanh(pre[2]), go = sigmoidf_(pre[3]);
             c_state = gf * c_state + gi * gg;
             h_val = go * ss_tanh(c_state);
-            sv[0] = gi;
-            sv[1] = gf;
-            sv[2] = gg;
-            sv[3] = go;
             // the hand-off payload: write-through, first (rows past B carry garbage nobody stores downstream)
-            if (!(diag & 2)) xb_store(xwr + ((st + 1) & 1) * half, plane, j, bi, h_val, local);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) xg[g] = xn[g];
+            if (!(diag & 2)) xb_store(xwr + ((st + 1) & 1) * half, plane, j, bi, h_val, local, TAG ? (int)tag_of(st + 1) : -1);
+            float(*sb)[16][16] = st_buf[st & 1];         // slab copies: the storing wave picks them up behind the next barrier
+            sb[0][bi][jj] = gi;
+            sb[1][bi][jj] = gf;
+            sb[2][bi][jj] = gg;
+            sb[3][bi][jj] = go;
+            sb[4][bi][jj] = c_state;
+            sb[5][bi][jj] = h_val;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains before the barrier
-        __syncthreads();
-        if (tid == 0) publish(flags + jt, (unsigned)(st + 2));
-        // slab copies (consumed only by later kernels) are held back until the next step's fragments have arrived: issued
-        // right here, their acknowledgements would sit in front of those loads' s_waitcnt vmcnt(0)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) sv_p[g] = sv[g];
-        c_p = c_state;
-        h_p = h_val;
-        tau_p = tau;
+        if constexpr (!TAG) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains before the barrier
+            lds_barrier();
+            if (tid == 0) publish(flags + jt, (unsigned)(st + 2));
+        }
     }
-    flush_slabs();
-}
-
-// One 16-byte write-through store per lane (whole 1 KiB tiles per wave: no partial sectors).  NOTE: hipcc inserts the
-// MFMA -> VMEM-read wait states only for consumers it can see, so the value handed in must come from a VALU instruction
-// (here: the accumulator times the row's unscale factor), never straight out of an MFMA.  The trailing s_nop covers the other
-// hazard hipcc cannot see through the asm: the data registers of a store wider than 64 bits must not be rewritten in the two
-// wait states after it.
-__device__ __forceinline__ void store16_sc1(unsigned char* p, f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void store16_plain(unsigned char* p, f32x4 v) {      // XCD-local groups only
-    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    lds_barrier();                                      // hands the last step's slab copies to the storing wave
 }
 
 // Backward: dh(t) = d_out(t) + da(t+1) . W_hh.  The reduction runs over all 4H gate units, which live 64 per workgroup,
@@ -459,8 +576,8 @@ __device__ __forceinline__ void store16_plain(unsigned char* p, f32x4 v) {      
 // Tiles are stored write-through (sc1) unless round 0 found the whole group on one XCD (group_locality): then ordinary
 // stores are used, which is what makes this formulation pay (8 MB of sc1 traffic per step costs ~1.8 us of every step).
 // sync: as in the forward kernel.
-template <int H, int NW>
-__global__ __launch_bounds__(64 * (NW + 1)) void lstm_seq_bwd_kernel(float* __restrict__ gates, const float* __restrict__ whh_f,
+template <int H, int NW, bool TAG>
+__global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __restrict__ gates, const float* __restrict__ whh_f,
                                                                const float* __restrict__ whh_b, unsigned char* __restrict__ xb,
                                                                const float* __restrict__ d_out, const float* __restrict__ csave,
                                                                unsigned* __restrict__ sync, unsigned* __restrict__ sticky,
@@ -471,6 +588,13 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_seq_bwd_kernel(float* __re
     __shared__ __attribute__((aligned(16))) float red[NW][16][20];      // [unit column][utterance row, padded], see the forward kernel
     __shared__ __attribute__((aligned(16))) unsigned short a_lds[2][2][64][8];      // own da(t) as A fragments: [k-step][piece]
     __shared__ __attribute__((aligned(16))) float row_unscale[16];                  // 1 / (row scale * WSCALE) per utterance
+    // the memory wave's two mailboxes: the cell threads' operands of a step (gi, gf, gg, go, d_out, c, c_prev) and their da
+    // ring of OPD + 1 steps, filled by LDS-DMA: slot = step % (OPD + 1), then float (utterance * 28 + operand * 4) * 4 + unit
+    constexpr int OPD = 4;                                                          // steps between an operand request and its use
+    const int WLEAD = ((prio >> 22) & 31) ? (prio >> 22) & 31 : 8;                  // ... and between a warm-up read and that request
+    __shared__ __attribute__((aligned(16))) float ops[OPD + 1][7 * 64 * 4];
+    __shared__ __attribute__((aligned(16))) float warm_sink[6 * 64 * 4];            // where the warm-up reads land (never read)
+    __shared__ __attribute__((aligned(16))) float da_st[4][16][16];                 // [gate][utterance][unit]
     __shared__ int s_ok;
     if (prio & 1) __builtin_amdgcn_s_setprio(3);
     // timing experiments (wrong results unless noted): 1 no exchange loads, 2 no products, 4 no operand fetch, 8 no slab stores,
@@ -482,11 +606,14 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_seq_bwd_kernel(float* __re
     constexpr int diag = 0;
 #endif
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    // Wave NW is a helper: it owns no tile and no cell, it only touches the operand rows the cell threads will fetch a few
-    // steps later, so that those fetches come out of the L2 (and a warm TLB) instead of HBM.  The memory counter is per
-    // wave: the helper can afford the ~2 us an HBM + TLB miss costs, the waves on the hand-off path cannot (whatever they
-    // have outstanding sits in front of their next s_waitcnt vmcnt(0)).
-    const bool helper = w == NW;
+    // Waves NW and NW + 1 are the MEMORY waves: they own no tile and no cell.  The first fetches the cell threads' operands
+    // (activated gates, d_out, c(t), c(t-1): seven 64-byte segments per utterance) two steps ahead of their use and hands them over
+    // through LDS; the second writes the cell threads' da (left in LDS) to the gradient slab.  The memory counter is per wave and
+    // counts loads and stores in order: whatever a wave on the hand-off path has outstanding sits in front of its next poll's
+    // s_waitcnt vmcnt(0), and the slab rows of one step are 2 MB apart (an HBM + TLB miss costs ~2 us).  These waves can afford
+    // that, those cannot.  Two waves because hipcc's wait-count bookkeeping gives up at the loop edge: with loads and stores in
+    // one wave it waited for the stores it had just issued before it touched a two-step-old load.
+    const bool loader = w == NW, helper = w >= NW;       // wave NW + 1 stores
     const int ngroups = 2 * nbt;
     const int grp = blockIdx.x % ngroups, jt = blockIdx.x / ngroups;
     const int dir = grp / nbt, bt = grp % nbt;
@@ -502,6 +629,99 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_seq_bwd_kernel(float* __re
     if (s_ok < 0) return;
     const bool local = s_ok == 1 || (diag & 32);
     __syncthreads();                                   // s_ok is reused by the step loop
+    if (TAG && tid == 0) s_ok = 1;                     // tagged: cleared by a wave whose poll gave up; first read behind step 0's barriers
+
+    auto tau_of = [&](int st) { return HALO + (dir == 0 ? T - 1 - st : st); };
+    const bool tm = (prio >> 21) & 1;                  // slabs time-major [T+4, B, C] instead of batch-major [B, T+4, C]
+    auto row_of = [&](int bb, int tau) { return tm ? (long)tau * B + bb : (long)bb * TP + tau; };
+    if (helper) {
+        // the working waves' barriers of one step, in the same order; false: the launch is being abandoned
+        auto barriers_to_products = [&](int st) -> bool {
+            if constexpr (TAG) {
+                lds_barrier();
+                if (!lds_peek(&s_ok)) return false;
+                lds_barrier();
+            } else {
+                if (st > 0) {
+                    lds_barrier();
+                    if (!lds_peek(&s_ok)) return false;
+                }
+                lds_barrier();
+                lds_barrier();
+            }
+            return true;
+        };
+        if (loader) {
+            // request i of a step: idx = lane + 64 i -> utterance idx / 28, operand (idx % 28) / 4, units 4 * (idx % 4) .. + 3.  The DMA
+            // puts lane's 16 bytes at slot + 1024 i + 16 lane, which is the layout the cell threads index.  Steps past the end
+            // re-request the last step (into slots nobody reads any more) so that the count below stays a constant.
+            auto request = [&](int st) {
+                const int sc = st < T ? st : T - 1;
+                const int tau = tau_of(sc), tau_prev = dir == 0 ? tau - 1 : tau + 1;
+                typedef __attribute__((address_space(3))) void* lds_t;
+                float* slot = ops[st % (OPD + 1)];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) {
+                    const int idx = lane + 64 * i, u = idx / 28, o = (idx % 28) >> 2, q = idx & 3;
+                    const int bu = bt * 16 + u < B ? bt * 16 + u : B - 1;
+                    const float* src = o < 4 ? gates + row_of(bu, tau) * (8 * H) + dir * 4 * H + o * H + jt * 16 + 4 * q
+                                             : (o == 4 ? d_out : csave) + row_of(bu, o == 6 ? tau_prev : tau) * (2 * H) + dir * H + jt * 16 + 4 * q;
+                    __builtin_amdgcn_global_load_lds((const void*)src, (lds_t)(slot + 256 * i), 16, 0, 0);
+                }
+                // Warm-up.  The requests above take 64-byte pieces out of rows that 32 workgroups pick apart at different moments:
+                // served from HBM that is one DRAM row activation per piece, and a step whose operands are cold takes 3.3 us
+                // instead of 2.2 (tools/seq_stride_probe.py; the depth of the ring does not matter, the layout of the slabs does
+                // not either).  So WLEAD steps earlier the group's operands are read ONCE in pieces DRAM likes -- 24 H bytes
+                // per utterance and step, 6 KB of them per workgroup as whole 1 KB lines -- into this XCD's L2.
+                if (!(diag & 64)) {
+                    const int sw = st + WLEAD < T ? st + WLEAD : T - 1;
+                    const int tw = tau_of(sw);
+                    constexpr int PER_U = 24 * H / 1024, NG = 16 * H / 1024, ND = 20 * H / 1024;      // 1 KB chunks per utterance: gates, then d_out, then c
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        const int c = jt * 6 + i, u = c / PER_U, k = c % PER_U;
+                        const int bu = bt * 16 + u < B ? bt * 16 + u : B - 1;
+                        const float* src = k < NG ? gates + row_of(bu, tw) * (8 * H) + dir * 4 * H + k * 256
+                                                  : (k < ND ? d_out + row_of(bu, tw) * (2 * H) + dir * H + (k - NG) * 256
+                                                            : csave + row_of(bu, tw) * (2 * H) + dir * H + (k - ND) * 256);
+                        __builtin_amdgcn_global_load_lds((const void*)(src + 4 * lane), (lds_t)(warm_sink + 256 * i), 16, 0, 0);
+                    }
+                }
+            };
+            if (!(diag & 4)) {
+                for (int st = 0; st < OPD; ++st) request(st);
+            }
+            bool ok = true;
+            for (int st = 0; st < T; ++st) {
+                if (!(diag & 4)) {
+                    request(st + OPD);                 // its slot held step st - 1: read before that step's second barrier
+                    if (diag & 64) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(7 * OPD) : "memory");      // in order: everything up to step st has landed
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(13 * OPD) : "memory");
+                }
+                if (!barriers_to_products(st)) {
+                    ok = false;
+                    break;
+                }
+                if constexpr (!TAG) lds_barrier();
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing may land in this LDS after the workgroup has gone
+            if (!ok) return;
+        } else {
+            for (int st = 0; st < T; ++st) {
+                if (!barriers_to_products(st)) return;
+                if (!(diag & 8)) {
+                    const int tau = tau_of(st);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int idx = lane + 64 * i, g = idx >> 6, u = (idx & 63) >> 2, q = idx & 3;
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(&da_st[g][u][4 * q]);
+                        if (bt * 16 + u < B) *reinterpret_cast<f32x4*>(gates + row_of(bt * 16 + u, tau) * (8 * H) + dir * 4 * H + g * H + jt * 16 + 4 * q) = v;
+                    }
+                }
+                if constexpr (!TAG) lds_barrier();
+            }
+        }
+    }
 
     // B fragments, resident for the whole sequence.  Local reduction index k = gate*16 + unit (64 per workgroup): k-step ks,
     // lane (li = column, lq) holds k = 32*ks + 8*lq + e  ->  W_hh[(2*ks + lq/2)*H + jt*16 + 8*(lq%2) + e][(w*CT + ct)*16 + li]
@@ -525,102 +745,64 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_seq_bwd_kernel(float* __re
     const unsigned char* xrd = gb + ((long)jt * JT + w * PW) * 1024 + lane * 16;        // tiles for me, from producers w*PW ..
     unsigned char* xwr = gb + ((long)(w * CT) * JT + jt) * 1024 + lane * 16;            // my tiles for consumers w*CT ..
     const int bi = (tid >> 4) & 15, jj = tid & 15;
-    const int b = bt * 16 + bi, j = jt * 16 + jj;
-    const int bc = b < B ? b : B - 1;
+    const int b = bt * 16 + bi;
     const bool cell = tid < 256;
     float dc_rec = 0.f;
     float da[4] = {0.f, 0.f, 0.f, 0.f};
-    auto tau_of = [&](int st) { return HALO + (dir == 0 ? T - 1 - st : st); };
     struct Ops {
         float gi, gf, gg, go, d_o, cc, cp;
     };
-    auto fetch = [&](int st) {
-        Ops o{};
-        const int tau = tau_of(st), tau_prev = dir == 0 ? tau - 1 : tau + 1;
-        const float* gr = gates + ((long)bc * TP + tau) * (8 * H) + dir * 4 * H + j;
-        const long oo = ((long)bc * TP + tau) * (2 * H) + dir * H + j;
-        o.gi = gr[0];
-        o.gf = gr[H];
-        o.gg = gr[2 * H];
-        o.go = gr[3 * H];
-        o.d_o = d_out[oo];
-        o.cc = csave[oo];
-        o.cp = csave[((long)bc * TP + tau_prev) * (2 * H) + dir * H + j];
-        return o;
-    };
-    Ops cur{}, nxt{};
-    if (cell) cur = fetch(0);
-    float da_p[4] = {0.f, 0.f, 0.f, 0.f};
-    int tau_p = -1;
+    Ops cur{};
     float amx = 0.f;                                  // max |da| this thread has produced (for the consumers' fp16 scaling)
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};             // sum over time of this thread's da: the bias gradient of its (utterance, unit)
-    auto flush_slab = [&]() {
-        if (cell && b < B && tau_p >= 0 && !(diag & 8)) {
-            float* gr = gates + ((long)b * TP + tau_p) * (8 * H) + dir * 4 * H + j;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) gr[g * H] = da_p[g];
-        }
-        tau_p = -1;
-    };
 
-    if (helper) {
-        constexpr int AHEAD = 3;                       // the cell threads fetch step st + 1 during step st
-        const int u = lane & 15, q = lane >> 4;        // lane -> (utterance, 64-byte segment): 4 gate segments, d_out, c
-        const int bu = bt * 16 + u < B ? bt * 16 + u : B - 1;
-        float v0 = 0.f, v1 = 0.f, sink = 0.f;
-        for (int st = 0; st < T; ++st) {
-            sink += v0 + v1;                           // consumes last step's loads: nothing is in flight past this point
-            if (st + AHEAD < T && !(diag & 128)) {
-                const int tau = tau_of(st + AHEAD);
-                v0 = gates[((long)bu * TP + tau) * (8 * H) + dir * 4 * H + q * H + jt * 16];
-                const long oo = ((long)bu * TP + tau) * (2 * H) + dir * H + jt * 16;
-                if (q == 0) v1 = d_out[oo];
-                if (q == 1) v1 = csave[oo];
-            }
-            if (st > 0) {                              // the same barriers as the working waves, in the same order
-                __syncthreads();
-                if (!s_ok) return;
-            }
-            __syncthreads();
-            __syncthreads();
-            __syncthreads();
-        }
-        if (sink == 1.2345e-30f && T < 0) gates[0] = sink;      // never true: keeps the loads alive
-    }
     for (int st = 0; st < T && !helper; ++st) {
-        const int tau = tau_of(st);
-        // next step's operands: requested behind this step's tile loads (see the forward kernel)
-        auto prefetch = [&]() {
-            if (cell && st + 1 < T && !(diag & 4)) nxt = fetch((diag & 64) ? (st & 1) : st + 1);     // 64: always the same two rows (cache-hot)
-        };
         f32x4 part = {0.f, 0.f, 0.f, 0.f};
         if (st > 0) {
-            if (w == 0) {                              // one watcher here: a second one made the backward slower (3.1 -> 3.3 us)
-                const bool ok = (diag & 16) ? true : wait_flags(flags, JT, (unsigned)(st + 1), abortp);
-                if (lane == 0) s_ok = ok ? 1 : 0;
+            if constexpr (!TAG) {
+                if (w == 0) {                          // one watcher here: a second one made the backward slower (3.1 -> 3.3 us)
+                    const bool ok = (diag & 16) ? true : wait_flags(flags, JT, (unsigned)(st + 1), abortp);
+                    if (lane == 0) s_ok = ok ? 1 : 0;
+                }
+                lds_barrier();
+                if (!s_ok) return;
             }
-            __syncthreads();
-            if (!s_ok) return;
             const unsigned char* p = xrd + (st & 1) * half;
             u32x4 r[PW];
-            if (diag & 1) {
+            if ((diag & 1) || ((diag & 256) && (jt % CT) >= CT / 2)) {
 #pragma unroll
                 for (int i = 0; i < PW; ++i) r[i] = u32x4{0u, 0u, 0u, 0u};
+            } else if constexpr (TAG) {
+                // every wave polls ITS OWN tiles (one producer wave each) until all of their dwords carry this step's tag
+                const unsigned tg = tag_of(st);
+                for (unsigned spins = 0;; ++spins) {
+                    if constexpr (PW == 4) load4_sc1(p, r);
+                    else load2_sc1(p, r);
+                    unsigned bad = 0;
+#pragma unroll
+                    for (int i = 0; i < PW; ++i) bad |= (r[i][0] ^ tg) | (r[i][1] ^ tg) | (r[i][2] ^ tg) | (r[i][3] ^ tg);
+                    if (__all(!(bad & 1u)) || (diag & 16) != 0) break;
+                    if (!poll_continue(spins, abortp)) {
+                        if (lane == 0) s_ok = 0;
+                        break;
+                    }
+                }
             } else if constexpr (PW == 4) load4_sc1(p, r);
             else load2_sc1(p, r);
-            prefetch();
-            flush_slab();                               // last step's slab copy: its acks hide behind the cell math and products
 #pragma unroll
             for (int i = 0; i < PW; ++i) {
                 const f32x4 v = __builtin_bit_cast(f32x4, r[i]);
                 part += v;
             }
-        } else {
-            prefetch();
         }
         *reinterpret_cast<f32x4*>(&red[w][li][lq * 4]) = part;
-        __syncthreads();
+        lds_barrier();
+        if (TAG && !s_ok) return;                      // uniform: every thread reads the same LDS word
         if (cell) {
+            {
+                const float* o = ops[st % (OPD + 1)] + bi * 112 + jj;
+                cur = Ops{o[0], o[16], o[32], o[48], o[64], o[80], o[96]};
+            }
             float s = 0.f;
 #pragma unroll
             for (int ww = 0; ww < NW; ++ww) s += red[ww][jj][bi];
@@ -652,10 +834,10 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_seq_bwd_kernel(float* __re
                 const int la = ((g & 1) * 2 + (jj >> 3)) * 16 + bi;
                 a_lds[g >> 1][0][la][jj & 7] = (unsigned short)h;
                 a_lds[g >> 1][1][la][jj & 7] = (unsigned short)l;
+                da_st[g][bi][jj] = da[g];              // for the memory wave: slab copy for the weight-gradient GEMMs
             }
-            cur = nxt;
         }
-        __syncthreads();
+        lds_barrier();
         if (st + 1 < T && !(diag & 2)) {                  // partial dh(t-1) of my gate units for every hidden unit
             f16x8 a[2][2];
 #pragma unroll
@@ -670,19 +852,24 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lstm_seq_bwd_kernel(float* __re
                 acc = mfma3(a[0], bw[0][ct], acc);
                 acc = mfma3(a[1], bw[1][ct], acc);
                 acc *= us;
+                if constexpr (TAG) {
+                    const unsigned tg = tag_of(st + 1);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[c] = __uint_as_float((__float_as_uint(acc[c]) & ~1u) | tg);
+                }
+                if ((diag & 256) && ct >= CT / 2) continue;                   // timing only: half of the exchange traffic
                 if (local) store16_plain(q + (long)ct * JT * 1024, acc);     // hand-off payload, group on one XCD: the shared L2 has it
                 else store16_sc1(q + (long)ct * JT * 1024, acc);              // group spans XCDs: write-through
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) publish(flags + jt, (unsigned)(st + 2));
-        // the slab copy for the weight-gradient GEMMs is held back until the next step's tiles have arrived (see forward)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) da_p[g] = da[g];
-        tau_p = tau;
+        // tagged: nothing to publish, and no closing barrier either -- red[] is next written behind this step's second barrier,
+        // a_lds / row_unscale behind the next step's first one, which no wave reaches before it has finished its products here
+        if constexpr (!TAG) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+            if (tid == 0) publish(flags + jt, (unsigned)(st + 2));
+        }
     }
-    flush_slab();
     if (amax && cell) {                               // one atomic per wave: positive floats order like their bit patterns
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o));
@@ -725,8 +912,8 @@ static long resident_limit(int H) {
         int per_cu = 0;
         hipError_t e = hipGetDeviceProperties(&prop, dev);
         if (e == hipSuccess)
-            e = H == 512 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<512, 8>, 576, 0)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<256, 8>, 576, 0);
+            e = H == 512 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<512, 8, false>, 640, 0)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<256, 8, false>, 640, 0);
         c = e == hipSuccess ? (long)prop.multiProcessorCount * per_cu : -1;
         if (c == 0) c = -1;
     }
@@ -744,10 +931,10 @@ long lstm_seq_xbytes(int B, int H, bool backward) {
     return backward ? 2 * (2 * nbt * JT * JT * 1024) : 2 * (2 * nbt * 2 * (H / 32) * 1024);
 }
 
-static int seq_prio_arg() { return (g_seq_prio & 0xFFFF) | ((g_seq_spin_log2 & 31) << 16); }
+static int seq_prio_arg(bool time_major) { return (g_seq_prio & 0xFFFF) | ((g_seq_spin_log2 & 31) << 16) | (time_major ? 1 << 21 : 0) | ((g_seq_wlead & 31) << 22); }
 
 hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, float* out, float* csave,
-                        unsigned* sync, unsigned* sticky, int B, int T, int H, bool zero_state, hipStream_t s) {
+                        unsigned* sync, unsigned* sticky, int B, int T, int H, bool zero_state, bool time_major, hipStream_t s) {
     const int nbt = (B + 15) / 16;
     if (!lstm_seq_supported(B, H)) return hipErrorInvalidValue;
     if (zero_state) {
@@ -756,23 +943,38 @@ hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, vo
         if (e != hipSuccess) return e;
     }
     unsigned char* xb = static_cast<unsigned char*>(xbuf);
-    if (H == 512) hipLaunchKernelGGL((lstm_seq_fwd_kernel<512, 8>), dim3(2 * nbt * 32), dim3(512), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, B, T, nbt, seq_prio_arg());
-    else          hipLaunchKernelGGL((lstm_seq_fwd_kernel<256, 4>), dim3(2 * nbt * 16), dim3(256), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, B, T, nbt, seq_prio_arg());
+    const int pa = seq_prio_arg(time_major);
+    // Measured (tools/kbench.py seqtag, us per step flags -> tagged): groups that sit on one XCD each (B = 64: 8 groups under the
+    // round-robin placement) 2.47 -> 2.03; groups that span XCDs, whose polls and write-through payload cross the fabric,
+    // 3.10 -> 3.23 (B = 16) and 3.00 -> 3.47 (B = 48).  The backward gains either way (3.13 -> 2.98, 3.40 -> 2.49, 4.13 -> 3.25).
+    const bool tag = (g_seq_tag & 1) && (2 * nbt) % 8 == 0;
+    if (H == 512 && tag) hipLaunchKernelGGL((lstm_seq_fwd_kernel<512, 8, true>), dim3(2 * nbt * 32), dim3(640), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, B, T, nbt, pa);
+    else if (H == 512)         hipLaunchKernelGGL((lstm_seq_fwd_kernel<512, 8, false>), dim3(2 * nbt * 32), dim3(640), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, B, T, nbt, pa);
+    else if (tag)              hipLaunchKernelGGL((lstm_seq_fwd_kernel<256, 4, true>), dim3(2 * nbt * 16), dim3(384), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, B, T, nbt, pa);
+    else                       hipLaunchKernelGGL((lstm_seq_fwd_kernel<256, 4, false>), dim3(2 * nbt * 16), dim3(384), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, B, T, nbt, pa);
     return hipGetLastError();
 }
 
 hipError_t lstm_seq_bwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, const float* d_out,
                         const float* csave, unsigned* sync, unsigned* sticky, float* amax, float* gbias_f, float* gbias_b, int B, int T,
-                        int H, bool zero_state, hipStream_t s) {
+                        int H, bool zero_state, bool time_major, hipStream_t s) {
     const int nbt = (B + 15) / 16;
     if (!lstm_seq_supported(B, H)) return hipErrorInvalidValue;
     if (zero_state) {
-        hipError_t e = hipMemsetAsync(sync, 0, LSTM_SEQ_SYNC_WORDS * sizeof(unsigned), s);      // the exchange tiles need no initial state
+        hipError_t e = hipMemsetAsync(sync, 0, LSTM_SEQ_SYNC_WORDS * sizeof(unsigned), s);
+        // flag protocol: the exchange tiles need no initial state; tagged payload: every tag must start at 0
+        if (e == hipSuccess && (g_seq_tag & 2)) e = hipMemsetAsync(xbuf, 0, lstm_seq_xbytes(B, H, true), s);
         if (e != hipSuccess) return e;
     }
     unsigned char* xb = static_cast<unsigned char*>(xbuf);
-    if (H == 512) hipLaunchKernelGGL((lstm_seq_bwd_kernel<512, 8>), dim3(2 * nbt * 32), dim3(576), 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, reinterpret_cast<unsigned*>(amax), gbias_f, gbias_b, B, T, nbt, seq_prio_arg());
-    else          hipLaunchKernelGGL((lstm_seq_bwd_kernel<256, 8>), dim3(2 * nbt * 16), dim3(576), 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, reinterpret_cast<unsigned*>(amax), gbias_f, gbias_b, B, T, nbt, seq_prio_arg());
+    unsigned* am = reinterpret_cast<unsigned*>(amax);
+    const dim3 grid(2 * nbt * (H / 16)), block(640);
+    const int pa = seq_prio_arg(time_major);
+    const bool tag = g_seq_tag & 2;
+    if (H == 512 && tag) hipLaunchKernelGGL((lstm_seq_bwd_kernel<512, 8, true>), grid, block, 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, am, gbias_f, gbias_b, B, T, nbt, pa);
+    else if (H == 512)         hipLaunchKernelGGL((lstm_seq_bwd_kernel<512, 8, false>), grid, block, 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, am, gbias_f, gbias_b, B, T, nbt, pa);
+    else if (tag)              hipLaunchKernelGGL((lstm_seq_bwd_kernel<256, 8, true>), grid, block, 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, am, gbias_f, gbias_b, B, T, nbt, pa);
+    else                       hipLaunchKernelGGL((lstm_seq_bwd_kernel<256, 8, false>), grid, block, 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, am, gbias_f, gbias_b, B, T, nbt, pa);
     return hipGetLastError();
 }
 

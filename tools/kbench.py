@@ -275,9 +275,9 @@ def bench_seq(B=64, T=128, H=512):
         f'dgates max diff {float((res[0][1] - res[1][1]).abs().max()):.2e}')
     tune('persist', 1)
     # where a backward step's time goes: seq_prio bit 0 = s_setprio, bits 1.. = ablations (wrong results)
-    for dg, what in [(0, 'full'), (1, 'no exchange loads'), (2, 'no products / tile stores'), (4, 'no operand fetch'), (8, 'no slab stores'),
-                     (16, 'no wait'), (128, 'idle helper wave (results right)'), (31, 'nothing but the barriers + cell math'), (32, 'tile stores without sc1'), (64, 'operand fetch from two hot rows'), (96, 'plain tile stores + hot operand rows'), (36, 'plain tile stores + no operand fetch'),
-                     (44, 'plain tile stores, no fetch, no slab stores')]:
+    for dg, what in [(0, 'full'), (1, 'no exchange loads (no polling)'), (4, 'no operand fetch'), (8, 'no slab stores'), (16, 'no wait (one poll load)'),
+                     (64, 'no warm-up reads'), (12, 'no operand fetch, no slab stores'), (13, 'no polling, no fetch, no slab stores'), (256, 'half of the exchange traffic (half of the consumers do not wait)'),
+                     (268, 'half traffic, no fetch, no slab stores')]:
         tune('seq_prio', 1 | (dg << 1))
         tb = timeit(bwd)[0] - timeit(copy_only)[0]
         say(f'   bwd ablation [{what:40s}]: {tb / T:.2f} us/step')
@@ -292,11 +292,57 @@ def bench_seq(B=64, T=128, H=512):
     tune('seq_prio', 1)
 
 
+def bench_seqtag(B=64, T=128, H=512):
+    """flag hand-off vs tagged payload, interleaved rounds in one process; results compared with each other"""
+    dev = 'cuda'
+    g = torch.Generator(device='cpu').manual_seed(0)
+    xproj = (torch.randn(B, T, 2, 4 * H, generator=g) * 0.5).to(dev)
+    whh = (torch.rand(2, 4 * H, H, generator=g) * 2 - 1).to(dev) / H ** 0.5
+    d_out = (torch.randn(B, T, 2 * H, generator=g) * 0.1).to(dev)
+    scratch = torch.zeros(max(8 * H * H + 16 * B * H + 2 * B * H + 1024, 2 * ((B + 15) // 16) * (H // 16) ** 2 * 1024 + 4096), device=dev)
+    gates = torch.zeros(B, T + 4, 8 * H, device=dev)
+    gates[:, 2:2 + T] = xproj.reshape(B, T, 8 * H)
+    xp_keep = gates.clone()
+    out = torch.zeros(B, T + 4, 2 * H, device=dev)
+    cs = torch.zeros(B, T + 4, 2 * H, device=dev)
+    dpad = torch.zeros(B, T + 4, 2 * H, device=dev)
+    dpad[:, 2:2 + T] = d_out
+    res = {}
+
+    def fwd():
+        gates.copy_(xp_keep)
+        _capi.check(lib.ss_op_lstm_fwd(P(gates), P(whh[0]), P(whh[1]), P(out), P(cs), P(scratch), scratch.numel(), B, T, H, S()))
+
+    def copy_only():
+        gates.copy_(xp_keep)
+    for rnd in range(3):
+        for tg in (0, 3):
+            tune('seq_tag', tg)
+            tf = timeit(fwd, iters=9)[0] - timeit(copy_only, iters=9)[0]
+            ga_keep = gates.clone()
+            o_keep = out.clone()
+
+            def bwd():
+                gates.copy_(ga_keep)
+                _capi.check(lib.ss_op_lstm_bwd(P(gates), P(whh[0]), P(whh[1]), P(dpad), P(cs), P(scratch), scratch.numel(), B, T, H, S()))
+            tb = timeit(bwd, iters=9)[0] - timeit(copy_only, iters=9)[0]
+            bwd()
+            res[tg] = (o_keep, gates.clone())
+            say(f'lstm layer H{H} B{B} T{T} seq_tag{tg}: fwd {tf:.0f} us ({tf / T:.2f}/step)  bwd {tb:.0f} us ({tb / T:.2f}/step; tagged includes a 16 MB memset)')
+    tune('seq_tag', 3)
+    say(f'   tagged vs flags: out max diff {float((res[0][0] - res[3][0]).abs().max()):.2e}, '
+        f'dgates max diff {float((res[0][1] - res[3][1]).abs().max()):.2e} (max |dgates| {float(res[0][1].abs().max()):.2e})')
+
+
 if __name__ == '__main__':
     want = sys.argv[1:] or ['lstm', 'gemm', 'step']
     say('====', ' '.join(want), torch.cuda.get_device_name(0))
     if 'lstm' in want:
         bench_lstm()
+    if 'seqtag' in want:
+        bench_seqtag()
+        bench_seqtag(B=16, T=64)
+        bench_seqtag(B=48, T=192)
     if 'seq' in want:
         bench_seq()
     if 'modes' in want:

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Does a GEMM run UNDER a persistent recurrence?  One decoder BLSTM layer (B=64, T=128, H=512) on stream A, an independent fp16x2 GEMM
+(decoder projection / dW shapes) on stream B launched right behind it; HIP events give each kernel's span and the pair's wall time.
+Writes gpurun_out/overlap_probe.txt.   Usage: python tools/overlap_probe.py"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from speechsplit_amd import _capi                     # noqa: E402
+from speechsplit_amd import engine as E               # noqa: E402
+
+OUT = os.path.join(ROOT, 'gpurun_out')
+os.makedirs(OUT, exist_ok=True)
+LOG = open(os.path.join(OUT, 'overlap_probe.txt'), 'a')
+lib = _capi.lib()
+
+
+def say(*a):
+    s = ' '.join(str(x) for x in a)
+    print(s, flush=True)
+    LOG.write(s + '\n')
+    LOG.flush()
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def main():
+    dev = 'cuda'
+    B, T, H = 64, 128, 512
+    g = torch.Generator(device='cpu').manual_seed(0)
+    xproj = (torch.randn(B, T, 2, 4 * H, generator=g) * 0.5).to(dev)
+    whh = (torch.rand(2, 4 * H, H, generator=g) * 2 - 1).to(dev) / H ** 0.5
+    scratch = torch.zeros(max(8 * H * H + 16 * B * H + 2 * B * H + 1024, ((B + 15) // 16) * (H // 16) ** 2 * 1024 + 4096), device=dev)
+    gates = torch.zeros(B, T + 4, 8 * H, device=dev)
+    gates[:, 2:2 + T] = xproj.reshape(B, T, 8 * H)
+    out = torch.zeros(B, T + 4, 2 * H, device=dev)
+    cs = torch.zeros(B, T + 4, 2 * H, device=dev)
+    dpad = torch.zeros(B, T + 4, 2 * H, device=dev)
+    dpad[:, 2:2 + T] = (torch.randn(B, T, 2 * H, generator=g) * 0.1).to(dev)
+    sa = torch.cuda.Stream()
+    sbs = [torch.cuda.Stream() for _ in range(4)]
+    # pick a B stream on another hardware queue: try a few and keep the one whose overlap is best (the engine's probe does this properly)
+    shapes = [('proj NT 8192x4096x1024', 8192, 4096, 1024, False, False, 1), ('dW_ih TN 2048x1024x8192 ks4', 2048, 1024, 8192, True, True, 4),
+              ('dX NT-tr 8192x1024x4096', 8192, 1024, 4096, False, True, 1)]
+
+    def rec(kind):
+        if kind == 'fwd':
+            _capi.check(lib.ss_op_lstm_fwd(P(gates), P(whh[0]), P(whh[1]), P(out), P(cs), P(scratch), scratch.numel(), B, T, H, C.c_void_p(sa.cuda_stream)))
+        else:
+            _capi.check(lib.ss_op_lstm_bwd(P(gates), P(whh[0]), P(whh[1]), P(dpad), P(cs), P(scratch), scratch.numel(), B, T, H, C.c_void_p(sa.cuda_stream)))
+
+    def ev():
+        return torch.cuda.Event(enable_timing=True)
+
+    for kind in ('fwd', 'bwd'):
+        for name, M, N, K, ta, tb, ks in shapes:
+            A = torch.randn((K, M) if ta else (M, K), device=dev)
+            Bm = torch.randn((K, N) if tb else (N, K), device=dev)
+            c = torch.zeros(M, N, device=dev)
+
+            def gemm(reps, sb):
+                with torch.cuda.stream(sb):
+                    for _ in range(reps):
+                        E.gemm(A, Bm, None, ta, tb, ks, out=c, f16x2=True)
+            for reps in (1, 2, 3):
+              best = None
+              for sb in sbs:
+                rows = []
+                for it in range(6):
+                    torch.cuda.synchronize()
+                    # alone
+                    a0, a1 = ev(), ev()
+                    a0.record(sa); rec(kind); a1.record(sa)
+                    torch.cuda.synchronize()
+                    g0, g1 = ev(), ev()
+                    g0.record(sb); gemm(reps, sb); g1.record(sb)
+                    torch.cuda.synchronize()
+                    # together: recurrence first, the GEMMs right behind it on the other stream
+                    w0, r1, q0, q1 = ev(), ev(), ev(), ev()
+                    w0.record(sa)
+                    sb.wait_event(w0)
+                    rec(kind); r1.record(sa)
+                    q0.record(sb); gemm(reps, sb); q1.record(sb)
+                    torch.cuda.synchronize()
+                    rows.append((a0.elapsed_time(a1) * 1e3, g0.elapsed_time(g1) * 1e3, w0.elapsed_time(r1) * 1e3, w0.elapsed_time(q1) * 1e3))
+                rows = rows[2:]
+                med = [sorted(r[i] for r in rows)[len(rows) // 2] for i in range(4)]
+                if best is None or max(med[2], med[3]) < max(best[2], best[3]):
+                    best = med
+              med = best
+              say(f'{kind} recurrence + {reps} x {name}: alone rec {med[0]:.0f} us, gemm {med[1]:.0f} us | together: rec ends {med[2]:.0f} us, all done {med[3]:.0f} us '
+                  f'(serial {med[0] + med[1]:.0f}, saved {med[0] + med[1] - max(med[2], med[3]):.0f})')
+
+
+if __name__ == '__main__':
+    say('====', torch.cuda.get_device_name(0))
+    main()
