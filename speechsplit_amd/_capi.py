@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SS_DIAG_LIB=1 (tools/ only): the -DSS_DIAG build with the wrong-result timing experiments compiled in
-LIB_PATH = os.path.join(_HERE, 'lib', 'libspeechsplit_hip_diag.so' if os.environ.get('SS_DIAG_LIB') == '1' else 'libspeechsplit_hip.so')
+LIB_PATH = os.environ.get('SS_LIB_PATH') or os.path.join(_HERE, 'lib', 'libspeechsplit_hip_diag.so' if os.environ.get('SS_DIAG_LIB') == '1' else 'libspeechsplit_hip.so')
 
 HP_FIELDS = ('freq', 'dim_neck', 'freq_2', 'dim_neck_2', 'freq_3', 'dim_neck_3', 'dim_enc', 'dim_enc_2', 'dim_enc_3',
              'dim_freq', 'dim_spk_emb', 'dim_f0', 'chs_grp', 'min_len_seg', 'max_len_seg', 'max_len_seq', 'max_len_pad')

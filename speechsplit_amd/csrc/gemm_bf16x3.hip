@@ -17,6 +17,8 @@ namespace ss {
 
 extern int g_gemm_want;
 int g_gemm_tr = 2;       // transposing LDS reads for reduction-major operands of 128-wide tiles: 1 wherever possible, 2 not for TN, 0 never
+int g_gemm_ws = 0;        // 128 x 128 fp16 x 2 tiles: 1 = the wave-specialised (512-thread) form where it measured faster in isolation, 2 = always,
+                          // 0 = never (default: in the training step, where two convolutions share the chip anyway, 1 measured 0.02 ms slower)
 int g_gemm_mode = 1;      // 0: exact-fp32 MFMA kernel (gemm_f32.hip), 1: bf16x3 kernel whenever operands are 16-byte aligned
 
 namespace {
@@ -61,12 +63,15 @@ __device__ __forceinline__ float pow2_scale(float m) {
     se = se < 1 ? 1 : (se > 187 ? 187 : se);
     return __uint_as_float((unsigned)se << 23);
 }
+// Four instructions per PAIR of values: the mixed-precision fma scales, subtracts the fp16 piece it reads straight out of the
+// packed register, rounds once and writes the chosen half of the destination (hipcc's own code for the plain C++ form: seven).
+// The split sits on the same issue port as the MFMAs -- 4 cycles per vector instruction, 8 of its 32 per MFMA -- so with 128 x 128
+// tiles every instruction saved per value is ~3 % of the k-loop.
 __device__ __forceinline__ void split2_f16(float x0, float x1, float scale, unsigned& h, unsigned& l) {
-    const float y0 = x0 * scale, y1 = x1 * scale;
-    const f16x2 hh = {(_Float16)y0, (_Float16)y1};
-    const f16x2 ll = {(_Float16)(y0 - (float)hh[0]), (_Float16)(y1 - (float)hh[1])};
-    h = __builtin_bit_cast(unsigned, hh);
-    l = __builtin_bit_cast(unsigned, ll);
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(scale));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(scale));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(scale), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(scale), "v"(h));
 }
 
 // two fp32 values -> packed bf16 pair, round to nearest even (element 0 in the low half)
@@ -101,18 +106,25 @@ __device__ __forceinline__ u32x4 tr_frag(const unsigned char* plane, int o_lo, i
     return u32x4{l2[0], l2[1], h2[0], h2[1]};
 }
 
-template <int BM, int BN, bool TA, bool TB, int NPL, bool PROBE = false, bool TR = false>
-__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
+// WS (wave-specialised, 512 threads): waves 0-3 only multiply, waves 4-7 only stage -- global loads two k-tiles ahead, the split
+// and the LDS stores of tile kt+1 while the multipliers work on tile kt out of the other of two LDS buffers; ONE LDS-only barrier
+// per k-tile.  A multiplier wave and a staging wave share each SIMD: the split's VALU work issues in the shadow of the MFMAs
+// instead of in front of them (in the 256-thread form every wave does both, one after the other, and a k-tile's loads have one
+// MFMA phase -- ~0.4 us -- to arrive).
+template <int BM, int BN, bool TA, bool TB, int NPL, bool PROBE = false, bool TR = false, bool WS = false>
+__global__ __launch_bounds__(WS ? 512 : 256) void gemm_bf16x3_kernel(const GemmDesc d) {
     constexpr bool TRA = TR && TA && BM == 128, TRB = TR && TB && BN == 128;
     constexpr int MI = BM / 64, NI = BN / 64;
     constexpr int PA = BM * 64, PB = BN * 64;                 // bytes per plane
-    __shared__ __attribute__((aligned(16))) unsigned char As[NPL * PA];
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[NPL * PB];
+    constexpr int NBUF = WS ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) unsigned char As[NBUF * NPL * PA];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[NBUF * NPL * PB];
     // a slot = 4 consecutive k of one row of the tile.  K-contiguous operand: one float4 (8 slots per row, lanes along k);
     // reduction-major operand: four dword loads down the source rows, lanes along the tile rows (coalesced)
     constexpr int NA = BM * BK / 4 / 256, NB = BN * BK / 4 / 256;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool stager = WS && threadIdx.x >= 256;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     {
@@ -222,18 +234,19 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
         return s;
     };
     Slot ra[NA], rb[NB];
-    auto gload = [&](int k0, bool full) {
+    auto gload_to = [&](Slot (&qa)[NA], Slot (&qb)[NB], int k0, bool full) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int f = tid + i * 256;
-            ra[i] = fetch(d.A, TA, TRA, pa[i], wa[i], oka[i], TRA ? k0 + f / 32 : (TA ? k0 + 4 * (f / BM) : k0 + (f % 8) * 4), full);
+            qa[i] = fetch(d.A, TA, TRA, pa[i], wa[i], oka[i], TRA ? k0 + f / 32 : (TA ? k0 + 4 * (f / BM) : k0 + (f % 8) * 4), full);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int f = tid + i * 256;
-            rb[i] = fetch(d.B, TB, TRB, pb[i], wb[i], okb[i], TRB ? k0 + f / 32 : (TB ? k0 + 4 * (f / BN) : k0 + (f % 8) * 4), full);
+            qb[i] = fetch(d.B, TB, TRB, pb[i], wb[i], okb[i], TRB ? k0 + f / 32 : (TB ? k0 + 4 * (f / BN) : k0 + (f % 8) * 4), full);
         }
     };
+    auto gload = [&](int k0, bool full) { gload_to(ra, rb, k0, full); };
     // split the prefetched fp32 values and write the three bf16 planes
     auto sstore_one = [&](unsigned char* S, int P, bool T, bool TRX, int BX, int f, const Slot& s, float scale) {
         const int row = T ? f % BX : f / 8;
@@ -258,12 +271,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
         *reinterpret_cast<u32x2*>(S + P + o) = u32x2{m0_, m1};
         *reinterpret_cast<u32x2*>(S + 2 * P + o) = u32x2{l0, l1};
     };
-    auto sstore = [&]() {
+    auto sstore_from = [&](const Slot (&qa)[NA], const Slot (&qb)[NB], int buf) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) sstore_one(As, PA, TA, TRA, BM, tid + i * 256, ra[i], sc_a);
+        for (int i = 0; i < NA; ++i) sstore_one(As + buf * NPL * PA, PA, TA, TRA, BM, tid + i * 256, qa[i], sc_a);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) sstore_one(Bs, PB, TB, TRB, BN, tid + i * 256, rb[i], sc_b);
+        for (int i = 0; i < NB; ++i) sstore_one(Bs + buf * NPL * PB, PB, TB, TRB, BN, tid + i * 256, qb[i], sc_b);
     };
+    auto sstore = [&]() { sstore_from(ra, rb, 0); };
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -280,19 +294,10 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
     const int ta_lo = lds_off_t(kg * 8 + tq, wm * (BM / 2) + (lane & 16) + 4 * tpp), ta_hi = lds_off_t(kg * 8 + 4 + tq, wm * (BM / 2) + (lane & 16) + 4 * tpp);
     const int tb_lo = lds_off_t(kg * 8 + tq, wn * (BN / 2) + (lane & 16) + 4 * tpp), tb_hi = lds_off_t(kg * 8 + 4 + tq, wn * (BN / 2) + (lane & 16) + 4 * tpp);
     const int nfull = (kend - kbeg) / BK;           // k-tiles that need no bounds checks
-    if (nk > 0) gload(kbeg, false);
-    unsigned long long ph[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (PROBE) t0 = __builtin_readcyclecounter();
-        if (!GDIAG(d, 64)) sstore();               // tile kt: registers -> bf16 planes   (diag 64 / 128 / 256: timing ablations)
-        if (PROBE) { t1 = __builtin_readcyclecounter(); ph[0] += t1 - t0; t0 = t1; }
-        if (!GDIAG(d, 32)) __syncthreads();        // diag 32 (timing only, wrong results): no barriers in the k-loop
-        if (PROBE) { t1 = __builtin_readcyclecounter(); ph[1] += t1 - t0; t0 = t1; }
-        // tile kt+1 in flight during the MFMAs
-        if (GDIAG(d, 128)) {
-        } else if (kt + 1 < nfull) gload(kbeg + (kt + 1) * BK, true);
-        else if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK, false);
-        if (PROBE) { t1 = __builtin_readcyclecounter(); ph[2] += t1 - t0; t0 = t1; }
+    // one k-tile's products out of LDS buffer `buf`
+    auto multiply = [&](int buf) {
+        const unsigned char* Ab_ = As + buf * NPL * PA;
+        const unsigned char* Bb_ = Bs + buf * NPL * PB;
 #pragma unroll
         for (int ks16 = 0; ks16 < BK / 16; ++ks16) {
             bf16x8 a[NPL][MI], b[NPL][NI];
@@ -303,8 +308,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
                 const int o = lds_off(row, ks16 * 16 + kg * 8) * fskip;
 #pragma unroll
                 for (int p = 0; p < NPL; ++p) {
-                    if constexpr (TRA) a[p][mi] = __builtin_bit_cast(bf16x8, tr_frag(As + p * PA + ks16 * 4096, ta_lo ^ (mi * 64), ta_hi ^ (mi * 64)));
-                    else a[p][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + p * PA + o));
+                    if constexpr (TRA) a[p][mi] = __builtin_bit_cast(bf16x8, tr_frag(Ab_ + p * PA + ks16 * 4096, ta_lo ^ (mi * 64), ta_hi ^ (mi * 64)));
+                    else a[p][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Ab_ + p * PA + o));
                 }
             }
 #pragma unroll
@@ -313,8 +318,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
                 const int o = lds_off(row, ks16 * 16 + kg * 8) * fskip;
 #pragma unroll
                 for (int p = 0; p < NPL; ++p) {
-                    if constexpr (TRB) b[p][ni] = __builtin_bit_cast(bf16x8, tr_frag(Bs + p * PB + ks16 * 4096, tb_lo ^ (ni * 64), tb_hi ^ (ni * 64)));
-                    else b[p][ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bs + p * PB + o));
+                    if constexpr (TRB) b[p][ni] = __builtin_bit_cast(bf16x8, tr_frag(Bb_ + p * PB + ks16 * 4096, tb_lo ^ (ni * 64), tb_hi ^ (ni * 64)));
+                    else b[p][ni] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bb_ + p * PB + o));
                 }
             }
 #pragma unroll
@@ -342,9 +347,56 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmDesc d) {
                     acc[mi][ni] = c;
                 }
         }
+    };
+    unsigned long long ph[5] = {0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
+    if constexpr (WS) {
+        // Tile kt lives in buffer kt & 1.  Stagers keep two register sets in flight: at k-tile kt they store tile kt+1 (requested
+        // two k-tiles ago) and request tile kt+3 into the registers that frees.  The barrier that ends k-tile kt tells the
+        // multipliers that tile kt+1 is in LDS and the stagers that buffer kt & 1 may be overwritten.
+        auto full_at = [&](int t) { return t < nfull; };
+        if (stager) {
+            Slot sa[NA], sb[NB];                       // second register set (ra / rb is the first)
+            if (nk > 0) gload_to(ra, rb, kbeg, full_at(0));
+            if (nk > 1) gload_to(sa, sb, kbeg + BK, full_at(1));
+            if (nk > 0) sstore_from(ra, rb, 0);
+            if (nk > 2) gload_to(ra, rb, kbeg + 2 * BK, full_at(2));
+            lds_barrier();
+            for (int kt = 0; kt < nk; kt += 2) {
+                if (kt + 1 < nk) sstore_from(sa, sb, 1);                                   // tile kt+1
+                if (kt + 3 < nk) gload_to(sa, sb, kbeg + (kt + 3) * BK, full_at(kt + 3));
+                lds_barrier();
+                if (kt + 1 >= nk) break;
+                if (kt + 2 < nk) sstore_from(ra, rb, 0);                                   // tile kt+2
+                if (kt + 4 < nk) gload_to(ra, rb, kbeg + (kt + 4) * BK, full_at(kt + 4));
+                lds_barrier();
+            }
+            return;
+        }
+        lds_barrier();
+        for (int kt = 0; kt < nk; ++kt) {
+            multiply(kt & 1);
+            lds_barrier();
+        }
+    } else {
+    if (nk > 0) gload(kbeg, false);
+    // (A separate loop over the whole k-tiles only -- no bounds logic in it -- was measured too, A/B in one process against this
+    // form: the training step was 0.18 ms SLOWER with it, with either split.  One loop it stays.)
+    for (int kt = 0; kt < nk; ++kt) {
+        if (PROBE) t0 = __builtin_readcyclecounter();
+        if (!GDIAG(d, 64)) sstore();               // tile kt: registers -> bf16 planes   (diag 64 / 128 / 256: timing ablations)
+        if (PROBE) { t1 = __builtin_readcyclecounter(); ph[0] += t1 - t0; t0 = t1; }
+        if (!GDIAG(d, 32)) __syncthreads();        // diag 32 (timing only, wrong results): no barriers in the k-loop
+        if (PROBE) { t1 = __builtin_readcyclecounter(); ph[1] += t1 - t0; t0 = t1; }
+        // tile kt+1 in flight during the MFMAs
+        if (GDIAG(d, 128)) {
+        } else if (kt + 1 < nfull) gload(kbeg + (kt + 1) * BK, true);
+        else if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK, false);
+        if (PROBE) { t1 = __builtin_readcyclecounter(); ph[2] += t1 - t0; t0 = t1; }
+        multiply(0);
         if (PROBE) { t1 = __builtin_readcyclecounter(); ph[3] += t1 - t0; t0 = t1; }
         if (!GDIAG(d, 32)) __syncthreads();        // all fragment reads done before the planes are overwritten
         if (PROBE) { t1 = __builtin_readcyclecounter(); ph[4] += t1 - t0; }
+    }
     }
     if (PROBE && lane == 0 && blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z) < 64) {
         for (int i = 0; i < 5; ++i) atomicAdd(&g_gemm_phase[wave][i], ph[i]);
@@ -388,10 +440,28 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t s) {
                       (op.seglen == 0 || (op.seglen % 4 == 0 && op.segstride % 4 == 0)));
     };
     constexpr bool CAN_TR = (TA || TB) && (!TA || BM == 128) && (!TB || BN == 128);
+    // Measured (tools/kbench.py gws, us 256-thread -> wave-specialised): a grid that leaves one workgroup per CU gains -- encoder
+    // convolution 8192 x 512 x 2560 (256 tiles) 116 -> 104 -- because its staging waves are a second set of waves to hide latency
+    // behind; grids of two and more workgroups per CU do not (projection 280 -> 276, input gradient 245 -> 254), and a
+    // reduction-major pair of operands loses (dW 158 -> 230: four staging waves issue 32 dword loads per k-tile each).
+    constexpr bool CAN_WS = BM == 128 && BN == 128;
+    const bool ws = g_gemm_ws == 2 || (g_gemm_ws == 1 && !(TA && TB) && (long)grid.x * grid.y * grid.z <= 320);
     if constexpr (CAN_TR) {
         if (g_gemm_tr && (g_gemm_tr == 1 || !(TA && TB)) && !(d.flags & GEMM_BF16) && quad_ok(d.A, TA, d.M) && quad_ok(d.B, TB, d.N)) {
+            if constexpr (CAN_WS) {
+                if ((d.flags & GEMM_F16X2) && ws && !d.diag) {
+                    hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB, 2, false, true, true>), grid, dim3(512), 0, s, d);
+                    return hipGetLastError();
+                }
+            }
             if (d.flags & GEMM_F16X2) hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB, 2, false, true>), grid, dim3(256), 0, s, d);
             else hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB, 3, false, true>), grid, dim3(256), 0, s, d);
+            return hipGetLastError();
+        }
+    }
+    if constexpr (CAN_WS) {
+        if ((d.flags & GEMM_F16X2) && !(d.flags & GEMM_BF16) && ws && !d.diag) {
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, TA, TB, 2, false, false, true>), grid, dim3(512), 0, s, d);
             return hipGetLastError();
         }
     }

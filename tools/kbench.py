@@ -190,6 +190,50 @@ def bench_gemm_diag():
                 say(f'gemm {name} [{"fp16 x 2 (3 MFMA)" if f16 else "bf16 x 3 (6 MFMA)":20s}]: {t:8.1f} us  {2.0 * M * N * K / t / 1e6:6.1f} TF  err {err:.1e}')
 
 
+def bench_gemm_ablate():
+    """where a k-tile's time goes in the fp16 x 2 in-loop-split kernel (timing only: most modes give wrong results)"""
+    dev = 'cuda'
+    shapes = [('proj   NT 8192x4096x1024', 8192, 4096, 1024, False, False, 1), ('dX  NT-tr 8192x1024x4096', 8192, 1024, 4096, False, True, 1),
+              ('dW_ih  TN 2048x1024x8192 ks4', 2048, 1024, 8192, True, True, 4), ('conv   NT 8192x512x2560', 8192, 512, 2560, False, False, 1)]
+    modes = [(0, 'full'), (4, 'every k-tile re-reads tile 0 (no memory latency)'), (128, 'no global loads'), (64, 'no split / LDS store'), (32, 'no barriers'),
+             (256, 'fragment reads all to one address'), (192, 'no split, no loads'), (224, 'no split, no loads, no barriers'), (8, 'plain tile order (no XCD / L2 grouping)')]
+    for name, M, N, K, ta, tb, ks in shapes:
+        A = torch.randn((K, M) if ta else (M, K), device=dev)
+        Bm = torch.randn((K, N) if tb else (N, K), device=dev)
+        c = torch.zeros(M, N, device=dev)
+        for dg, what in modes:
+            tune('gemm_diag', dg)
+            t, tmin = timeit(lambda: E.gemm(A, Bm, None, ta, tb, ks, out=c, f16x2=True), iters=7)
+            say(f'gemm {name} [{what:50s}]: {t:8.1f} us  {2.0 * M * N * K / t / 1e6:6.1f} TF')
+    tune('gemm_diag', 0)
+
+
+def bench_gemm_ws():
+    """256-thread kernel vs the wave-specialised 512-thread form (fp16 x 2, 128 x 128 tiles), each checked against fp64"""
+    dev = 'cuda'
+    shapes = [('proj   NT 8192x4096x1024', 8192, 4096, 1024, False, False, 1), ('dX  NT-tr 8192x1024x4096', 8192, 1024, 4096, False, True, 1),
+              ('dW_ih  TN 2048x1024x8192 ks4', 2048, 1024, 8192, True, True, 4), ('dW_hh  TN 2048x512x8192 ks8', 2048, 512, 8192, True, True, 8),
+              ('conv   NT 8192x512x2560', 8192, 512, 2560, False, False, 1), ('convdW TN 512x2560x8192 ks6', 512, 2560, 8192, True, True, 6),
+              ('odd    NT 1000x520x1000', 1000, 520, 1000, False, False, 1), ('odd    TN 300x260x4100 ks3', 300, 260, 4100, True, True, 3),
+              ('one k-tile NT 256x256x32', 256, 256, 32, False, False, 1), ('three k-tiles NT 256x256x96', 256, 256, 96, False, False, 1)]
+    for name, M, N, K, ta, tb, ks in shapes:
+        A = torch.randn((K, M) if ta else (M, K), device=dev)
+        Bm = torch.randn((K, N) if tb else (N, K), device=dev)
+        c = torch.zeros(M, N, device=dev)
+        ref = ((A.t() if ta else A).double() @ (Bm if tb else Bm.t()).double())
+        for rnd in range(2):
+            for ws in (0, 2):
+                tune('gemm_ws', ws)
+                tune('gemm_want', 1)
+                c.zero_()
+                E.gemm(A, Bm, None, ta, tb, ks, out=c, f16x2=True)
+                err = float((c.double() - ref).abs().max() / ref.abs().max())
+                t, tmin = timeit(lambda: E.gemm(A, Bm, None, ta, tb, ks, out=c, f16x2=True), iters=7)
+                say(f'gemm {name} [{"wave-specialised" if ws else "256 threads     "}]: {t:8.1f} us  {2.0 * M * N * K / t / 1e6:6.1f} TF  err {err:.1e}')
+    tune('gemm_ws', 1)
+    tune('gemm_want', 1024)
+
+
 def bench_step():
     from oracle import weights as W
     from oracle.gen_fixtures import synth_batch
@@ -349,6 +393,10 @@ if __name__ == '__main__':
         bench_lstm_modes()
     if 'gemm' in want:
         bench_gemm()
+    if 'gws' in want:
+        bench_gemm_ws()
+    if 'gabl' in want:
+        bench_gemm_ablate()
     if 'gdiag' in want:
         bench_gemm_diag()
     if 'step' in want:
