@@ -112,7 +112,7 @@ __device__ __forceinline__ u32x4 tr_frag(const unsigned char* plane, int o_lo, i
 // instead of in front of them (in the 256-thread form every wave does both, one after the other, and a k-tile's loads have one
 // MFMA phase -- ~0.4 us -- to arrive).
 template <int BM, int BN, bool TA, bool TB, int NPL, bool PROBE = false, bool TR = false, bool WS = false>
-__global__ __launch_bounds__(WS ? 512 : 256) void gemm_bf16x3_kernel(const GemmDesc d) {
+__global__ __launch_bounds__(WS ? 512 : 256, (NPL == 2 && !WS && !PROBE) ? 3 : 1) void gemm_bf16x3_kernel(const GemmDesc d) {
     constexpr bool TRA = TR && TA && BM == 128, TRB = TR && TB && BN == 128;
     constexpr int MI = BM / 64, NI = BN / 64;
     constexpr int PA = BM * 64, PB = BN * 64;                 // bytes per plane
