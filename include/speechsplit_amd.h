@@ -191,7 +191,7 @@ int ss_op_gemm(const float* a_dev, long lda, const float* b_dev, long ldb, float
  * single-launch kernel, H in {64,128,256,512} one launch per time step and needs scratch of at least
  * 8*H*H + 4*ceil16(B)*H floats (forward) / 8*H*H + 16*ceil16(B)*H + 2*B*H floats (backward).  H in {256,512} with
  * 2*ceil(B/16)*(H/16) <= 256 runs as ONE persistent launch (the engine's schedule) when, for the backward, scratch also
- * holds its exchange tiles and flags: 4*ceil(B/16)*(H/16)^2*1024 + 8192 bytes. */
+ * holds its exchange tiles and flags: 4*ceil(B/16)*(H/16)^2*1024 + 8192 bytes (the hook zeroes them: the tiles carry step tags). */
 int ss_op_lstm_fwd(float* gates_dev, const float* whh_f_dev, const float* whh_b_dev, float* out_dev, float* csave_dev,
                    float* scratch_dev, long scratch_floats, int B, int T, int H, void* stream);
 /* BPTT of the same: d_out [B,T+4,2H]; gates is replaced by the pre-activation gradients. */
@@ -220,7 +220,11 @@ int ss_debug_relu_mask(ss_engine* e, const char* block, float* mask_dev, void* s
  * "gemm_want" >= 1, "overlap" 0|1, "graph" 0|1, "persist" 0|1, "split" 0|1, "gemm_mode" 0 (fp32 MFMA) | 1 (split arithmetic on
  * the 16-bit pipe), "fwd_f16x2" / "bwd_f16x2" 0|1 (fp16 x 2 instead of bf16 x 3 for the forward / the scaled gradient
  * contractions), "seq_spin_log2" 0..24 (log2 of the persistent kernels' bounded wait; 0 makes it expire at once -- how the
- * tests exercise the abort path), "deterministic" 0|1.  The timing experiments that produce WRONG results ("lstm_mode",
+ * tests exercise the abort path), "deterministic" 0|1, "seq_tag" 0|1 (forward persistent recurrence: step tag in the hand-off
+ * payload where every group sits on one XCD | always the flag line), "seq_wlead" 0..31 (backward persistent recurrence: steps
+ * between a warm-up read and the operand request it serves, 0 = the kernel's default), "gemm_ws" 0|1|2 (wave-specialised form of
+ * the 128 x 128 fp16 x 2 GEMM: never | where it measured faster in isolation | always), "op_time_major" 0|1 (ss_op_lstm_fwd / _bwd
+ * read their slabs as [T+4,B,C]; persistent kernels only -- a layout experiment).  The timing experiments that produce WRONG results ("lstm_mode",
  * "gemm_diag", "seq_prio" > 1) are compiled out of this library; `make -C speechsplit_amd/csrc diag` builds
  * libspeechsplit_hip_diag.so with them for tools/ (never loaded by the package unless SS_DIAG_LIB=1 is set). */
 int ss_tune(const char* key, int value);

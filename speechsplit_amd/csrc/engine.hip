@@ -1271,8 +1271,8 @@ int backward_decoder(ss_engine* e, hipStream_t s, bool late = false) {
     if (par) CHK(fork_join(e, s, b2));
     if (e->ld.big()) {
         if (g_persist && lstm_seq_supported(e->curB, e->ld.H)) {
-            // the group counters of every layer and, for the tagged hand-off, their exchange tiles
-            HIPCHK(hipMemsetAsync(e->ld.zb, 0, (g_seq_tag & 2) ? e->ld.zb_bytes : e->ld.L * 4L * LSTM_SEQ_SYNC_WORDS, b2));
+            // the group counters of every layer and their exchange tiles (tags start at 0)
+            HIPCHK(hipMemsetAsync(e->ld.zb, 0, e->ld.zb_bytes, b2));
         } else {
             for (int l = 0; l < e->ld.L; ++l)
                 HIPCHK(lstm_pack_w(e->P + e->ld.pd[l * 2].whh, e->P + e->ld.pd[l * 2 + 1].whh, e->ld.wfrag[l], e->ld.H, 1, b2));
@@ -1281,7 +1281,6 @@ int backward_decoder(ss_engine* e, hipStream_t s, bool late = false) {
     // head.  Only its input gradient is on the critical path; when the decoder's weight gradients are deferred to the side
     // stream (lstm_bwd), the head's weight / bias gradients go with them instead of running in front of the first recurrence.
     const long HD = 2L * e->ld.H;
-    const float* h3 = e->ld.out[e->ld.L - 1];
     const bool defer_head = !g_graph && e->ld.big() && g_persist && lstm_seq_supported(B, e->ld.H) && e->side && g_overlap && g_defer_dw;
     late = late && defer_head;
     e->dec_w_pending = late;
@@ -2012,7 +2011,7 @@ int ss_tune(const char* key, int value) {
 #else
     else if (k == "seq_prio" && (value == 0 || value == 1)) g_seq_prio = value;
 #endif
-    else if (k == "seq_tag" && value >= 0 && value <= 3) g_seq_tag = value;
+    else if (k == "seq_tag" && (value == 0 || value == 1)) g_seq_tag = value;
     else if (k == "op_time_major" && (value == 0 || value == 1)) g_op_time_major = value;
     else if (k == "seq_wlead" && value >= 0 && value < 32) g_seq_wlead = value;
     else if (k == "gemm_ws" && value >= 0 && value <= 2) g_gemm_ws = value;

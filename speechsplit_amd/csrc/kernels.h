@@ -140,9 +140,10 @@ hipError_t lstm_step_bwd(float* gates, const float* wfragT, const float* gf_cur,
 
 // ---------------------------------------------------------------- lstm_seq.hip  (persistent: one launch per layer)
 // gates / out / csave / d_out as above; whh_* are the parameter tensors themselves ([4H][H] row-major): each workgroup
-// splits its slice into bf16 pieces once and keeps it in registers.  xbuf = lstm_seq_xbytes() bytes of exchange buffer
-// (forward: h(t) as fp16 pieces in MFMA fragment order; backward: partial-dh tiles), sync = LSTM_SEQ_SYNC_WORDS unsigned words
-// (completion flags, XCD masks, abort word at [0]); both must be all zero at launch: zero_state = false means the caller has zeroed them itself.
+// splits its slice into fp16 x 2 pieces once and keeps it in registers.  xbuf = lstm_seq_xbytes() bytes of exchange buffer
+// (forward: h(t) as fp16 pieces in MFMA fragment order; backward: partial-dh tiles, whose dwords carry their step's tag in bit 0),
+// sync = LSTM_SEQ_SYNC_WORDS unsigned words (completion flags, XCD masks, abort word at [0]); both must be all zero at launch:
+// zero_state = false means the caller has zeroed them itself.  time_major: the slabs are [T+4][B][C] instead of [B][T+4][C].
 constexpr int LSTM_SEQ_SYNC_WORDS = 2048;   // [0] abort, [1..) XCD masks per group, [64 + 32*group + member] completion flags
 bool lstm_seq_supported(int B, int H);
 long lstm_seq_xbytes(int B, int H, bool backward);

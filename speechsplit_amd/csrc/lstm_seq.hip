@@ -2,46 +2,56 @@
 //
 // Why: with one launch per step (lstm_step.hip) a step costs ~7-8 us of which ~1.7 us is fp32 MFMA work; the rest is
 // the launch/drain floor (~3.5 us) and re-streaming the workgroup's 128 KB slice of W_hh from L2 every step.  Here
-// each workgroup keeps its W_hh slice in REGISTERS for the whole sequence -- as the three bf16 pieces of the exact split
-// x = h + m + l (gemm_bf16x3.hip), 96 VGPRs per lane -- and multiplies on the bf16 pipe with six
-// v_mfma_f32_16x16x32_bf16 per product (fp32-grade result, 0.75 us instead of 1.9 us of matrix-pipe time per step).
+// each workgroup keeps its W_hh slice in REGISTERS for the whole sequence -- as the two fp16 pieces of the fp16 x 2 split
+// (gemm_bf16x3.hip), 64 VGPRs per lane -- and multiplies with three v_mfma_f32_16x16x32_f16 per product.
 //
 // Forward: the workgroup (dir, btile, jtile) needs, at step t, h(t-1) of its 16 utterances from the JT workgroups with
-// the same (dir, btile) -- nothing else.  Producers store h as bf16 pieces in A-fragment order, so consumers load whole
+// the same (dir, btile) -- nothing else.  Producers store h as fp16 pieces in A-fragment order, so consumers load whole
 // fragments and nobody re-splits.  Backward: every workgroup multiplies its OWN 64 gate units of da(t+1) (straight from
 // LDS) into a partial dh for all H hidden units and hands 16x16 fp32 tiles to their owners, who add up JT tiles
 // (see lstm_seq_bwd_kernel).  Either way there is no grid-wide barrier, only 2*ceil(B/16) independent groups of
-// JT = H/16 workgroups, each with one monotonic arrival counter.  The 1-D block id is laid out so that a group is
-// blockIdx % ngroups: with B = 64 that is 8 groups = the 8 XCDs under the observed round-robin placement.
+// JT = H/16 workgroups.  The 1-D block id is laid out so that a group is blockIdx % ngroups: with B = 64 that is
+// 8 groups = the 8 XCDs under the observed round-robin placement.
 //
-// Hand-off protocol (CDNA guide Guideline 16 / MI355X_MICROARCH "Valid forms", counter row), placement-independent:
-//   producer: payload stores -> every storing wave s_waitcnt vmcnt(0) -> workgroup barrier -> one lane stores the step number
-//             into the workgroup's own flag word (relaxed, agent scope; 32 flags of a group share one 128-byte line)
-//   consumer: one wave polls the flag line (one load, lane = member) -> workgroup barrier -> every payload load is an sc1 load
-// Flags instead of a shared arrival counter because same-address atomics serialise in the L2 (measured: 4 -> 8 adds per
-// workgroup and step tripled the step time), a store to an own word and a one-line poll do not.
+// Hand-off, two forms (both placement-independent, both bounded):
+//   tagged payload (backward always; forward when every group sits on one XCD): every payload dword carries its step's tag in
+//       bit 0 and the consumer polls the payload itself -- one L2 trip per step, no ordering between dwords needed ("Tagged
+//       payload" below);
+//   flag line (forward otherwise; CDNA guide Guideline 16 / MI355X_MICROARCH "Valid forms", counter row):
+//       producer: payload stores -> every storing wave s_waitcnt vmcnt(0) -> workgroup barrier -> one lane stores the step number
+//                 into the workgroup's own flag word (relaxed, agent scope; 32 flags of a group share one 128-byte line)
+//       consumer: one wave polls the flag line (one load, lane = member) -> workgroup barrier -> every payload load is an sc1 load
+//       Flags instead of a shared arrival counter because same-address atomics serialise in the L2 (measured: 4 -> 8 adds per
+//       workgroup and step tripled the step time), a store to an own word and a one-line poll do not.
 // Payload stores are write-through (sc1) in general.  Round 0 of every launch has each member publish the XCD it runs on
 // (s_getreg XCC_ID) in a group mask: if the whole group shares one XCD -- hence one L2 -- ordinary stores suffice, and
 // that is worth 1.8 us per backward step (8 MB of sc1 traffic per step otherwise).  Measured, never assumed: a group that
 // spans XCDs (B = 16, 48, ...) takes the sc1 path and stays correct (tools/seq_debug.py).
 //
-// Residency: the grid (ngroups * JT <= 256 workgroups of 512 threads) fits the 256 CUs at one workgroup per CU; other
+// Memory waves: two extra waves per workgroup own all slab traffic.  One brings the cell threads' operands of the coming steps
+// into a ring in LDS by LDS-DMA (no registers, so the request depth is a plain s_waitcnt constant), the other writes the cell
+// threads' results, left in LDS, to the slabs.  The waves on the hand-off path have nothing in flight but payload and polls,
+// and the step barriers are LDS-only (s_waitcnt lgkmcnt(0) + s_barrier: __syncthreads() would also wait for every outstanding
+// global access of the wave, ~1 us a trip).
+//
+// Residency: the grid (ngroups * JT <= 256 workgroups of 640 threads) fits the 256 CUs at one workgroup per CU; other
 // kernels sharing the chip can only delay it (they never wait on it).  Every spin is bounded: on expiry the
 // workgroup raises a global abort word that all pollers watch, and the kernel drains (ss_check() reports it).
 //
 // Inline-asm rules learnt the hard way (both were silent corruptions): (1) an asm load must be waited for inside the same
 // statement, or hipcc re-uses / copies its destination register while the load is in flight; (2) an asm instruction that
 // reads an MFMA result needs its own wait states (store16_*), hipcc inserts them only for consumers it can see.
-// Measured and dropped: "warm-up" loads of the next steps' operands by the idle waves (-0.4 us/step on one layer in
-// isolation with hot operands, +0.1 ms on the whole training step).
+// Also learnt: hipcc's wait-count bookkeeping gives up at loop edges when loads and stores (or loads under control flow) are in
+// flight together -- it then waits for everything -- so a wave that is meant to keep requests in flight across iterations issues
+// only LDS-DMA loads and counts them itself.
 #include "common.h"
 #include "kernels.h"
 
 namespace ss {
 
 int g_seq_prio = 1;    // 1: persistent recurrence waves run at s_setprio 3
-int g_seq_tag = 3;     // the hand-off payload carries its own step tag (no flag round trip, see "Tagged payload" below) instead of a flag line
-                       // per group: bit 0 forward, bit 1 backward
+int g_seq_tag = 1;     // forward recurrence: the hand-off payload carries its own step tag (no flag round trip, see "Tagged payload" below) where
+                       // every group sits on one XCD; 0: always the flag line per group.  (The backward is always tagged.)
 int g_seq_wlead = 0;   // backward kernel: steps between a warm-up read and the operand request it serves (0: the kernel's default)
 int g_seq_spin_log2 = 18;   // bounded wait of the group hand-off: 2^18 polls ~ tens of ms.  ss_tune("seq_spin_log2", 4) makes the
                             // first wait of a launch expire, which is how the tests exercise the abort path on hardware
@@ -87,7 +97,7 @@ __device__ __forceinline__ void publish(unsigned* flag, unsigned v) {
     __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Tagged payload (TAG kernels).  The flag protocol costs three dependent L2 trips per step: payload stores acknowledged ->
+// Tagged payload.  The flag protocol costs three dependent L2 trips per step: payload stores acknowledged ->
 // flag store -> a poll that sees it -> payload loads.  Here every payload DWORD carries the tag of its step in bit 0, so the
 // consumer polls the payload itself and needs no ordering between dwords at all: one trip.  A ping-pong half is reused every
 // second step; its tag alternates per use and starts at 1, so the buffers must be ZERO when a launch starts (the engine keeps
@@ -576,7 +586,7 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_fwd_kernel(float* __re
 // Tiles are stored write-through (sc1) unless round 0 found the whole group on one XCD (group_locality): then ordinary
 // stores are used, which is what makes this formulation pay (8 MB of sc1 traffic per step costs ~1.8 us of every step).
 // sync: as in the forward kernel.
-template <int H, int NW, bool TAG>
+template <int H, int NW>
 __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __restrict__ gates, const float* __restrict__ whh_f,
                                                                const float* __restrict__ whh_b, unsigned char* __restrict__ xb,
                                                                const float* __restrict__ d_out, const float* __restrict__ csave,
@@ -629,7 +639,7 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
     if (s_ok < 0) return;
     const bool local = s_ok == 1 || (diag & 32);
     __syncthreads();                                   // s_ok is reused by the step loop
-    if (TAG && tid == 0) s_ok = 1;                     // tagged: cleared by a wave whose poll gave up; first read behind step 0's barriers
+    if (tid == 0) s_ok = 1;                            // cleared by a wave whose poll gave up; first read behind step 0's barriers
 
     auto tau_of = [&](int st) { return HALO + (dir == 0 ? T - 1 - st : st); };
     const bool tm = (prio >> 21) & 1;                  // slabs time-major [T+4, B, C] instead of batch-major [B, T+4, C]
@@ -637,18 +647,9 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
     if (helper) {
         // the working waves' barriers of one step, in the same order; false: the launch is being abandoned
         auto barriers_to_products = [&](int st) -> bool {
-            if constexpr (TAG) {
-                lds_barrier();
-                if (!lds_peek(&s_ok)) return false;
-                lds_barrier();
-            } else {
-                if (st > 0) {
-                    lds_barrier();
-                    if (!lds_peek(&s_ok)) return false;
-                }
-                lds_barrier();
-                lds_barrier();
-            }
+            lds_barrier();
+            if (!lds_peek(&s_ok)) return false;
+            lds_barrier();
             return true;
         };
         if (loader) {
@@ -702,7 +703,6 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
                     ok = false;
                     break;
                 }
-                if constexpr (!TAG) lds_barrier();
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing may land in this LDS after the workgroup has gone
             if (!ok) return;
@@ -718,7 +718,6 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
                         if (bt * 16 + u < B) *reinterpret_cast<f32x4*>(gates + row_of(bt * 16 + u, tau) * (8 * H) + dir * 4 * H + g * H + jt * 16 + 4 * q) = v;
                     }
                 }
-                if constexpr (!TAG) lds_barrier();
             }
         }
     }
@@ -759,20 +758,12 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
     for (int st = 0; st < T && !helper; ++st) {
         f32x4 part = {0.f, 0.f, 0.f, 0.f};
         if (st > 0) {
-            if constexpr (!TAG) {
-                if (w == 0) {                          // one watcher here: a second one made the backward slower (3.1 -> 3.3 us)
-                    const bool ok = (diag & 16) ? true : wait_flags(flags, JT, (unsigned)(st + 1), abortp);
-                    if (lane == 0) s_ok = ok ? 1 : 0;
-                }
-                lds_barrier();
-                if (!s_ok) return;
-            }
             const unsigned char* p = xrd + (st & 1) * half;
             u32x4 r[PW];
-            if ((diag & 1) || ((diag & 256) && (jt % CT) >= CT / 2)) {
+            if (diag & 1) {
 #pragma unroll
                 for (int i = 0; i < PW; ++i) r[i] = u32x4{0u, 0u, 0u, 0u};
-            } else if constexpr (TAG) {
+            } else {
                 // every wave polls ITS OWN tiles (one producer wave each) until all of their dwords carry this step's tag
                 const unsigned tg = tag_of(st);
                 for (unsigned spins = 0;; ++spins) {
@@ -787,8 +778,7 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
                         break;
                     }
                 }
-            } else if constexpr (PW == 4) load4_sc1(p, r);
-            else load2_sc1(p, r);
+            }
 #pragma unroll
             for (int i = 0; i < PW; ++i) {
                 const f32x4 v = __builtin_bit_cast(f32x4, r[i]);
@@ -797,7 +787,7 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
         }
         *reinterpret_cast<f32x4*>(&red[w][li][lq * 4]) = part;
         lds_barrier();
-        if (TAG && !s_ok) return;                      // uniform: every thread reads the same LDS word
+        if (!s_ok) return;                             // uniform: every thread reads the same LDS word
         if (cell) {
             {
                 const float* o = ops[st % (OPD + 1)] + bi * 112 + jj;
@@ -852,23 +842,15 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
                 acc = mfma3(a[0], bw[0][ct], acc);
                 acc = mfma3(a[1], bw[1][ct], acc);
                 acc *= us;
-                if constexpr (TAG) {
-                    const unsigned tg = tag_of(st + 1);
+                const unsigned tg = tag_of(st + 1);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[c] = __uint_as_float((__float_as_uint(acc[c]) & ~1u) | tg);
-                }
-                if ((diag & 256) && ct >= CT / 2) continue;                   // timing only: half of the exchange traffic
+                for (int c = 0; c < 4; ++c) acc[c] = __uint_as_float((__float_as_uint(acc[c]) & ~1u) | tg);
                 if (local) store16_plain(q + (long)ct * JT * 1024, acc);     // hand-off payload, group on one XCD: the shared L2 has it
                 else store16_sc1(q + (long)ct * JT * 1024, acc);              // group spans XCDs: write-through
             }
         }
-        // tagged: nothing to publish, and no closing barrier either -- red[] is next written behind this step's second barrier,
-        // a_lds / row_unscale behind the next step's first one, which no wave reaches before it has finished its products here
-        if constexpr (!TAG) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            lds_barrier();
-            if (tid == 0) publish(flags + jt, (unsigned)(st + 2));
-        }
+        // nothing to publish, and no closing barrier either -- red[] is next written behind this step's second barrier, a_lds /
+        // row_unscale behind the next step's first one, which no wave reaches before it has finished its products here
     }
     if (amax && cell) {                               // one atomic per wave: positive floats order like their bit patterns
 #pragma unroll
@@ -912,8 +894,8 @@ static long resident_limit(int H) {
         int per_cu = 0;
         hipError_t e = hipGetDeviceProperties(&prop, dev);
         if (e == hipSuccess)
-            e = H == 512 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<512, 8, false>, 640, 0)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<256, 8, false>, 640, 0);
+            e = H == 512 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<512, 8>, 640, 0)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<256, 8>, 640, 0);
         c = e == hipSuccess ? (long)prop.multiProcessorCount * per_cu : -1;
         if (c == 0) c = -1;
     }
@@ -947,7 +929,7 @@ hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, vo
     // Measured (tools/kbench.py seqtag, us per step flags -> tagged): groups that sit on one XCD each (B = 64: 8 groups under the
     // round-robin placement) 2.47 -> 2.03; groups that span XCDs, whose polls and write-through payload cross the fabric,
     // 3.10 -> 3.23 (B = 16) and 3.00 -> 3.47 (B = 48).  The backward gains either way (3.13 -> 2.98, 3.40 -> 2.49, 4.13 -> 3.25).
-    const bool tag = (g_seq_tag & 1) && (2 * nbt) % 8 == 0;
+    const bool tag = g_seq_tag && (2 * nbt) % 8 == 0;
     if (H == 512 && tag) hipLaunchKernelGGL((lstm_seq_fwd_kernel<512, 8, true>), dim3(2 * nbt * 32), dim3(640), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, B, T, nbt, pa);
     else if (H == 512)         hipLaunchKernelGGL((lstm_seq_fwd_kernel<512, 8, false>), dim3(2 * nbt * 32), dim3(640), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, B, T, nbt, pa);
     else if (tag)              hipLaunchKernelGGL((lstm_seq_fwd_kernel<256, 4, true>), dim3(2 * nbt * 16), dim3(384), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, B, T, nbt, pa);
@@ -962,19 +944,15 @@ hipError_t lstm_seq_bwd(float* gates, const float* whh_f, const float* whh_b, vo
     if (!lstm_seq_supported(B, H)) return hipErrorInvalidValue;
     if (zero_state) {
         hipError_t e = hipMemsetAsync(sync, 0, LSTM_SEQ_SYNC_WORDS * sizeof(unsigned), s);
-        // flag protocol: the exchange tiles need no initial state; tagged payload: every tag must start at 0
-        if (e == hipSuccess && (g_seq_tag & 2)) e = hipMemsetAsync(xbuf, 0, lstm_seq_xbytes(B, H, true), s);
+        if (e == hipSuccess) e = hipMemsetAsync(xbuf, 0, lstm_seq_xbytes(B, H, true), s);       // every tag starts at 0
         if (e != hipSuccess) return e;
     }
     unsigned char* xb = static_cast<unsigned char*>(xbuf);
     unsigned* am = reinterpret_cast<unsigned*>(amax);
     const dim3 grid(2 * nbt * (H / 16)), block(640);
     const int pa = seq_prio_arg(time_major);
-    const bool tag = g_seq_tag & 2;
-    if (H == 512 && tag) hipLaunchKernelGGL((lstm_seq_bwd_kernel<512, 8, true>), grid, block, 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, am, gbias_f, gbias_b, B, T, nbt, pa);
-    else if (H == 512)         hipLaunchKernelGGL((lstm_seq_bwd_kernel<512, 8, false>), grid, block, 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, am, gbias_f, gbias_b, B, T, nbt, pa);
-    else if (tag)              hipLaunchKernelGGL((lstm_seq_bwd_kernel<256, 8, true>), grid, block, 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, am, gbias_f, gbias_b, B, T, nbt, pa);
-    else                       hipLaunchKernelGGL((lstm_seq_bwd_kernel<256, 8, false>), grid, block, 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, am, gbias_f, gbias_b, B, T, nbt, pa);
+    if (H == 512) hipLaunchKernelGGL((lstm_seq_bwd_kernel<512, 8>), grid, block, 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, am, gbias_f, gbias_b, B, T, nbt, pa);
+    else          hipLaunchKernelGGL((lstm_seq_bwd_kernel<256, 8>), grid, block, 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, am, gbias_f, gbias_b, B, T, nbt, pa);
     return hipGetLastError();
 }
 

@@ -22,7 +22,10 @@ python3 tools/step_breakdown.py $(ls $O/prof/*/*kernel_trace.csv) > $O/step_brea
 python3 tools/step_timeline.py $(ls $O/prof/*/*kernel_trace.csv) > $O/step_timeline.txt
 head -12 $O/step_breakdown.txt
 SS_DIAG_LIB=1 timeout -k 10 120 python3 tools/kbench.py seq 2>&1 | grep -v amdgpu.ids > $O/kbench_seq_ablation.txt || true
+SS_DIAG_LIB=1 timeout -k 10 120 python3 tools/kbench.py seqtag 2>&1 | grep -v amdgpu.ids > $O/kbench_seq_handoff.txt || true
+SS_DIAG_LIB=1 timeout -k 10 120 python3 tools/kbench.py gws gabl 2>&1 | grep -v amdgpu.ids > $O/kbench_gemm_forms.txt || true
+timeout -k 10 200 python3 tools/seq_stride_probe.py layouts 2>&1 | grep -v amdgpu.ids > $O/seq_operand_temperature.txt || true
 timeout -k 10 200 python3 tools/f16x2_error.py 2>&1 | grep -v amdgpu.ids > $O/f16x2_error.txt || true
-cp $O/bench_kernel_stats.csv $O/step_breakdown.txt $O/kbench_seq_ablation.txt $O/f16x2_error.txt $O/bench_n1.json profiles/$R/ 2>/dev/null || true
+cp $O/bench_kernel_stats.csv $O/step_breakdown.txt $O/kbench_seq_ablation.txt $O/kbench_seq_handoff.txt $O/kbench_gemm_forms.txt $O/seq_operand_temperature.txt $O/f16x2_error.txt $O/bench_n1.json profiles/$R/ 2>/dev/null || true
 cp $O/step_timeline.txt profiles/$R/step_timeline.txt
 rm -rf $O/prof/*/*.db
