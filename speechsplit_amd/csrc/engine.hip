@@ -31,6 +31,8 @@ int g_conv_want = 256;    // experiment: workgroup target of the conv GEMMs' til
 int g_defer_dw = 1;    // 1: the decoder's weight-gradient GEMMs start after its last input gradient (see lstm_bwd)
 int g_side_prio = 0;   // 1: create the side stream with the lowest priority (read at ss_bind).  Measured: 2.3x SLOWER
                        //    (35 ms vs 14.8 ms per step): the low-priority queue starves behind 768 tiny step launches.
+int g_prewarm = 2;         // streaming pre-read of a decoder layer's operand slabs on a side stream beside its persistent recurrence: bit 1 forward
+                           // (step -0.08 ms), bit 0 backward (no gain in the step, off; neither one recurrence ahead: +0.08 ms)
 int g_op_time_major = 0;   // experiment: ss_op_lstm_fwd / _bwd take time-major slabs [T+4, B, C] (persistent kernels only)
 int g_persist = 1;     // 1: decoder recurrences run as ONE persistent launch per layer (lstm_seq.hip) when the batch fits
 int g_split = 0;       // 1: decoder recurrences run as two batch-half chains on two streams (GEMMs of one half fill the
@@ -845,10 +847,17 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
             }
         }
         if (persist) {   // start state zeroed by lstm_prep
+            // the input projections the GEMM has just written are read once more, in whole lines, beside the recurrence (lstm_seq.hip)
+            const bool pw = (g_prewarm & 2) && e->side3 && g_overlap && !g_graph;
+            if (pw) {
+                CHK(fork_join(e, s, e->side3));
+                HIPCHK(slab_prewarm(lb.gates[l], 8 * H, nullptr, nullptr, 2 * H, e->amax, B, T, false, e->side3));
+            }
             const int pi = prof_begin(e, SS_PROF_REC_FWD, s, 2.0 * 2 * B * T * 4.0 * H * H);
             HIPCHK(lstm_seq_fwd(lb.gates[l], e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.hf_l(l), lb.out[l], lb.csave[l],
                                 lb.sync_f(l), e->sticky, B, T, H, false, false, s));
             prof_end(e, pi, s);
+            if (pw) CHK(fork_join(e, e->side3, s));
             continue;
         }
         for (int st = 0; st < T; ++st)
@@ -1011,11 +1020,19 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
             }
             // persistent: start state zeroed by backward_decoder
             if (persist) {
+                // activated gates and cell states of the forward pass are long gone from the caches: one streaming read beside the
+                // recurrence puts them into the memory-side cache ahead of its 64-byte requests (lstm_seq.hip, slab_prewarm_kernel)
+                const bool pw = (g_prewarm & 1) && e->side3 && g_overlap && !g_graph;
+                if (pw) {
+                    CHK(fork_join(e, s, e->side3));
+                    HIPCHK(slab_prewarm(dG, 8 * H, lb.csave[l], dcur, 2 * H, e->amax, B, T, false, e->side3));
+                }
                 const int pi = prof_begin(e, SS_PROF_REC_BWD, s, 2.0 * 2 * B * T * 4.0 * H * H);
                 HIPCHK(lstm_seq_bwd(dG, e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.px_l(l), dcur, lb.csave[l], lb.sync_b(l),
                                     e->sticky, am, bias_in_kernel ? e->G + lb.pd[l * 2].bih : nullptr,
                                     bias_in_kernel ? e->G + lb.pd[l * 2 + 1].bih : nullptr, B, T, H, false, false, s));
                 prof_end(e, pi, s);
+                if (pw) CHK(fork_join(e, e->side3, s));
             }
             for (int st = 0; st < T && !persist; ++st)
                 for (int c = 0; c < nch; ++c) {
@@ -2014,6 +2031,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "seq_tag" && (value == 0 || value == 1)) g_seq_tag = value;
     else if (k == "op_time_major" && (value == 0 || value == 1)) g_op_time_major = value;
     else if (k == "seq_wlead" && value >= 0 && value < 32) g_seq_wlead = value;
+    else if (k == "prewarm" && value >= 0 && value <= 3) g_prewarm = value;
     else if (k == "gemm_ws" && value >= 0 && value <= 2) g_gemm_ws = value;
     else if (k == "seq_spin_log2" && value >= 0 && value <= 24) g_seq_spin_log2 = value;
     else if (k == "overlap" && (value == 0 || value == 1)) g_overlap = value;

@@ -158,4 +158,8 @@ hipError_t lstm_seq_bwd(float* gates, const float* whh_f, const float* whh_b, vo
                         const float* csave, unsigned* sync, unsigned* sticky, float* amax, float* gbias_f, float* gbias_b, int B, int T,
                         int H, bool zero_state, bool time_major, hipStream_t s);
 
+// streaming pre-read (results unused) of the slabs a persistent recurrence is about to consume: wide [rows][cw] (gates) and one or two
+// narrow ones [rows][cn] (cell states; output gradient), both ends of the sequence first.  Meant for a side stream, beside the recurrence.
+hipError_t slab_prewarm(const float* wide, int cw, const float* n0, const float* n1, int cn, float* sink, int B, int T, bool time_major, hipStream_t s);
+
 }  // namespace ss
