@@ -594,6 +594,38 @@ def test_bf16_configs_data_parallel_linearity(E, case):
     _shard_linearity(E, kind, B, T, len_lo, 2, wseed=0 if kind == 'G3' else 4, precision='bf16', tol=1e-3)
 
 
+@pytest.mark.parametrize('case', [(64, 128, 512, 1), (50, 37, 512, 1), (16, 8, 512, 1), (33, 5, 256, 1), (64, 3, 256, 1), (7, 1, 256, 1), (64, 40, 512, 0)],
+                         ids=['b64_t128_h512_tagged_both', 'b50_t37_h512_partial_tile', 'b16_t8_h512_one_group_pair', 'b33_t5_h256', 'b64_t3_h256',
+                              'b7_t1_h256_single_step', 'b64_t40_h512_flag_forward'])
+def test_persistent_blstm_layer_against_torch(E, case):
+    """One decoder-sized BLSTM layer through the persistent recurrence kernels (tagged hand-off, memory waves, LDS-DMA operand ring:
+    sequences shorter than the ring, odd lengths, a batch tile that is not full, groups on one XCD and across XCDs, and the forward's
+    flag-line form) against torch.nn.LSTM in float64: output, input gradient and every weight / bias gradient."""
+    B, T, H, tag = case
+    E.tune('seq_tag', tag)
+    try:
+        In = 96
+        g = torch.Generator().manual_seed(100 + B + T)
+        ref = torch.nn.LSTM(In, H, 1, batch_first=True, bidirectional=True).double()
+        x = torch.randn(B, T, In, generator=g, dtype=torch.float64)
+        d_out = torch.randn(B, T, 2 * H, generator=g, dtype=torch.float64) * 0.1
+        xr = x.clone().requires_grad_(True)
+        y_ref, _ = ref(xr)
+        y_ref.backward(d_out)
+        f = lambda n: getattr(ref, n).detach().float().cuda()
+        y, dx, grads = E.blstm_layer(x.float().cuda(), (f('weight_ih_l0'), f('weight_ih_l0_reverse')), (f('weight_hh_l0'), f('weight_hh_l0_reverse')),
+                                     (f('bias_ih_l0'), f('bias_ih_l0_reverse')), (f('bias_hh_l0'), f('bias_hh_l0_reverse')), d_out.float().cuda())
+        assert rel(y, y_ref.detach()) < TOL
+        assert rel(dx, xr.grad) < TOL
+        for d, sfx in enumerate(('', '_reverse')):
+            gw_ih, gw_hh, gb = grads[d]
+            assert rel(gw_ih, getattr(ref, 'weight_ih_l0' + sfx).grad) < TOL, sfx
+            assert rel(gw_hh, getattr(ref, 'weight_hh_l0' + sfx).grad) < TOL, sfx
+            assert rel(gb, getattr(ref, 'bias_ih_l0' + sfx).grad) < TOL, sfx
+    finally:
+        E.tune('seq_tag', 1)
+
+
 def test_batch_beyond_one_workgroup_per_cu(E):
     """128 utterances per GPU do not fit the persistent recurrence (one workgroup per CU): the decoder falls back to one
     launch per time step.  Its gradients must equal the mean over two 64-utterance shards, which run the persistent kernels."""
