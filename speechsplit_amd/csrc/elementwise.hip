@@ -227,6 +227,29 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
     if (rl == 0 && c < C) atomicAdd(out + c, (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
 }
 
+// both directions' bias gradients of one BLSTM layer in one launch: column c of the [R][2 x C] gradient slab goes to (b_ih, b_hh) of
+// direction c / C (the two biases of a direction have the same gradient)
+__global__ __launch_bounds__(256) void colsum_bias_kernel(const float* __restrict__ in, long ld, int R, int C, int rows_per_chunk,
+                                                          float* __restrict__ bih0, float* __restrict__ bhh0, float* __restrict__ bih1,
+                                                          float* __restrict__ bhh1) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int r0 = blockIdx.y * rows_per_chunk;
+    int r1 = r0 + rows_per_chunk;
+    if (r1 > R) r1 = R;
+    float s = 0.f;
+    if (c < 2 * C)
+        for (int r = r0 + rl; r < r1; r += 4) s += in[(long)r * ld + c];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < 2 * C) {
+        const float t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        atomicAdd((c < C ? bih0 : bih1) + (c < C ? c : c - C), t);
+        atomicAdd((c < C ? bhh0 : bhh1) + (c < C ? c : c - C), t);
+    }
+}
+
 __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, long s_ld, long s_bs,
                                                         float* __restrict__ dst, long d_ld, long d_bs, int T, int C) {
     const int b = blockIdx.y;
@@ -531,6 +554,16 @@ hipError_t colsum_acc(const float* in, long ld, int R, int C, float* out, hipStr
     if (chunks < 1) chunks = 1;
     const int rpc = cdiv(R, chunks);
     hipLaunchKernelGGL(colsum_kernel, dim3(cblocks, cdiv(R, rpc)), dim3(256), 0, s, in, ld, R, C, rpc, out);
+    return hipGetLastError();
+}
+
+hipError_t colsum_bias(const float* in, long ld, int R, int C, float* bih0, float* bhh0, float* bih1, float* bhh1, hipStream_t s) {
+    const int cblocks = cdiv(2 * C, 64);
+    int chunks = g_deterministic ? 1 : cdiv(1024, cblocks);
+    if (chunks > cdiv(R, 16)) chunks = cdiv(R, 16);
+    if (chunks < 1) chunks = 1;
+    const int rpc = cdiv(R, chunks);
+    hipLaunchKernelGGL(colsum_bias_kernel, dim3(cblocks, cdiv(R, rpc)), dim3(256), 0, s, in, ld, R, C, rpc, bih0, bhh0, bih1, bhh1);
     return hipGetLastError();
 }
 

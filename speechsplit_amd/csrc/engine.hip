@@ -31,6 +31,8 @@ int g_conv_want = 256;    // experiment: workgroup target of the conv GEMMs' til
 int g_defer_dw = 1;    // 1: the decoder's weight-gradient GEMMs start after its last input gradient (see lstm_bwd)
 int g_side_prio = 0;   // 1: create the side stream with the lowest priority (read at ss_bind).  Measured: 2.3x SLOWER
                        //    (35 ms vs 14.8 ms per step): the low-priority queue starves behind 768 tiny step launches.
+int g_batch_dirs = 1;      // BLSTM weight gradients: both directions of a layer in one launch per matrix (batch = 2) + one bias kernel:
+                           // 1 = the encoder BLSTMs (36 -> 14 launches), 2 = the decoder too (measured: step +0.18 ms), 0 = never
 int g_prewarm = 2;         // streaming pre-read of a decoder layer's operand slabs on a side stream beside its persistent recurrence: bit 1 forward
                            // (step -0.08 ms), bit 0 backward (no gain in the step, off; neither one recurrence ahead: +0.08 ms)
 int g_op_time_major = 0;   // experiment: ss_op_lstm_fwd / _bwd take time-major slabs [T+4, B, C] (persistent kernels only)
@@ -909,6 +911,42 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
     const long TP = T + 2 * HALO, R = (long)B * TP;
     const int In = lb.in_of(l);
     float* dG = lb.gates[l];
+    const LstmDir &p0 = lb.pd[l * 2], &p1 = lb.pd[l * 2 + 1];
+    // Both directions in ONE launch each (batch = 2) when their parameters sit at one stride in the arena (PyTorch's order: they do).
+    // dW_hh: h_prev is `out` one row earlier (forward) / later (reverse), so the forward direction reads dG one row later instead.
+    if ((g_batch_dirs == 2 || (g_batch_dirs == 1 && !lb.big())) && p1.wih - p0.wih == p1.whh - p0.whh && p1.wih > p0.wih) {
+        const long pstride = p1.wih - p0.wih;
+        GemmDesc a{};
+        a.A = {dG, 8L * H, 4L * H, 0, 0};
+        a.B = {xi.p, xi.ld, 0, 0, 0};
+        a.C = e->G + p0.wih;
+        a.ldc = In;
+        a.cstride = pstride;
+        a.M = 4 * H;
+        a.N = In;
+        a.K = (int)R;
+        a.batch = 2;
+        a.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM | (am ? GEMM_F16X2 : 0);
+        a.amax_a = am;                              // gradient slab: measured scale; the layer input is O(1)
+        a.ksplit = pick_ksplit(a.M, a.N, a.K);
+        PGEMM_ON(lb.big() ? SS_PROF_DEC_DW : SS_PROF_ENC_LSTM, a, ws);
+        GemmDesc h{};
+        h.A = {dG + 8L * H, 8L * H, 4L * H - 8L * H, 0, 0};                    // forward: rows 1 .., reverse: rows 0 .. of its own columns
+        h.B = {lb.out[l], 2L * H, 2L * H + H, 0, 0};                           // forward: rows 0 .. of h_f, reverse: rows 1 .. of h_b
+        h.C = e->G + p0.whh;
+        h.ldc = H;
+        h.cstride = pstride;
+        h.M = 4 * H;
+        h.N = H;
+        h.K = (int)(R - 1);
+        h.batch = 2;
+        h.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM | (am ? GEMM_F16X2 : 0);
+        h.amax_a = am;
+        h.ksplit = pick_ksplit(h.M, h.N, h.K);
+        PGEMM_ON(lb.big() ? SS_PROF_DEC_DW : SS_PROF_ENC_LSTM, h, ws);
+        if (!bias_done) HIPCHK(colsum_bias(dG, 8L * H, (int)R, 4 * H, e->G + p0.bih, e->G + p0.bhh, e->G + p1.bih, e->G + p1.bhh, ws));
+        return 0;
+    }
     for (int dir = 0; dir < 2; ++dir) {
         const LstmDir& pd = lb.pd[l * 2 + dir];
         const float* dGd = dG + dir * 4L * H;
@@ -2032,6 +2070,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "op_time_major" && (value == 0 || value == 1)) g_op_time_major = value;
     else if (k == "seq_wlead" && value >= 0 && value < 32) g_seq_wlead = value;
     else if (k == "prewarm" && value >= 0 && value <= 3) g_prewarm = value;
+    else if (k == "batch_dirs" && value >= 0 && value <= 2) g_batch_dirs = value;
     else if (k == "gemm_ws" && value >= 0 && value <= 2) g_gemm_ws = value;
     else if (k == "seq_spin_log2" && value >= 0 && value <= 24) g_seq_spin_log2 = value;
     else if (k == "overlap" && (value == 0 || value == 1)) g_overlap = value;

@@ -48,6 +48,8 @@ hipError_t gn_relu_mask(const float* x, long x_ld, long x_bs, const float* gamma
                         float* mask, int B, int T, int C, hipStream_t s);
 // out[c] += sum_r in[r*ld + c]   (atomic accumulate)
 hipError_t colsum_acc(const float* in, long ld, int R, int C, float* out, hipStream_t s);
+// column sums of a BLSTM layer's [R][2 x C] gradient slab added to (b_ih, b_hh) of both directions
+hipError_t colsum_bias(const float* in, long ld, int R, int C, float* bih0, float* bhh0, float* bih1, float* bhh1, hipStream_t s);
 hipError_t copy_rows(const float* src, long s_ld, long s_bs, float* dst, long d_ld, long d_bs, int B, int T, int C,
                      hipStream_t s);
 // batch assembly from a device-resident corpus: see collate_kernel (crop rows, clip mel to [0,1], pad mel with 0 / F0 with -1e10)

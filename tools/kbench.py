@@ -234,6 +234,44 @@ def bench_gemm_ws():
     tune('gemm_want', 1024)
 
 
+def bench_gemm_tiles():
+    """tile choice per decoder shape: gemm_want forces 128 x 128 (1), 128 x 64 or 64 x 64 by asking for more workgroups"""
+    dev = 'cuda'
+    shapes = [('proj   NT 8192x4096x1024', 8192, 4096, 1024, False, False, 1), ('dX  NT-tr 8192x1024x4096', 8192, 1024, 4096, False, True, 1),
+              ('dW_ih  TN 2048x1024x8192 ks4', 2048, 1024, 8192, True, True, 4), ('dW_ih  TN 2048x1024x8192 ks2', 2048, 1024, 8192, True, True, 2),
+              ('dW_ih  TN 2048x1024x8192 ks8', 2048, 1024, 8192, True, True, 8), ('dW_hh  TN 2048x512x8192 ks8', 2048, 512, 8192, True, True, 8),
+              ('dW_hh  TN 2048x512x8192 ks4', 2048, 512, 8192, True, True, 4), ('conv   NT 8192x512x2560', 8192, 512, 2560, False, False, 1)]
+    for name, M, N, K, ta, tb, ks in shapes:
+        A = torch.randn((K, M) if ta else (M, K), device=dev)
+        Bm = torch.randn((K, N) if tb else (N, K), device=dev)
+        c = torch.zeros(M, N, device=dev)
+        t128 = (M // 128) * (N // 128) * ks
+        for want, what in ((1, '128 x 128'), (t128 + 1, '128 x 64'), (2 * t128 + 1, '64 x 64')):
+            tune('gemm_want', want)
+            t, tmin = timeit(lambda: E.gemm(A, Bm, None, ta, tb, ks, out=c, f16x2=True), iters=7)
+            say(f'gemm {name} [{what:9s} tiles, {t128 * (1 if want == 1 else (2 if want == t128 + 1 else 4)):5d} workgroups]: {t:8.1f} us  {2.0 * M * N * K / t / 1e6:6.1f} TF')
+    tune('gemm_want', 1024)
+
+
+def bench_gemm_skinny():
+    """the decoder's layer-0 input gradient: 8448 x 164 x 4096 (narrow N), split-K and tile variants"""
+    dev = 'cuda'
+    M, N, K = 8448, 164, 4096
+    A = torch.randn(M, K, device=dev)
+    Bm = torch.randn(K, N, device=dev)
+    c = torch.zeros(M, N, device=dev)
+    ref = A.double() @ Bm.double()
+    for ks in (1, 2, 4, 8):
+        for want in (1, 300, 600, 1200, 5000):
+            tune('gemm_want', want)
+            c.zero_()
+            E.gemm(A, Bm, None, False, True, ks, out=c, f16x2=True)
+            err = float((c.double() - ref).abs().max() / ref.abs().max())
+            t, tmin = timeit(lambda: E.gemm(A, Bm, None, False, True, ks, out=c, f16x2=True), iters=7)
+            say(f'gemm dX0 NT 8448x164x4096 ks{ks} want{want:5d}: {t:8.1f} us  {2.0 * M * N * K / t / 1e6:6.1f} TF  err {err:.1e}')
+    tune('gemm_want', 1024)
+
+
 def bench_step():
     from oracle import weights as W
     from oracle.gen_fixtures import synth_batch
@@ -392,6 +430,10 @@ if __name__ == '__main__':
         bench_lstm_modes()
     if 'gemm' in want:
         bench_gemm()
+    if 'gskinny' in want:
+        bench_gemm_skinny()
+    if 'gtiles' in want:
+        bench_gemm_tiles()
     if 'gws' in want:
         bench_gemm_ws()
     if 'gabl' in want:

@@ -58,6 +58,10 @@ def main():
     def ev():
         return torch.cuda.Event(enable_timing=True)
 
+    want = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    if want:
+        _capi.check(lib.ss_tune(b'gemm_want', want))
+        say(f'gemm_want {want} (more workgroups wanted -> smaller tiles, fewer registers per wave)')
     for kind in ('fwd', 'bwd'):
         for name, M, N, K, ta, tb, ks in shapes:
             A = torch.randn((K, M) if ta else (M, K), device=dev)
