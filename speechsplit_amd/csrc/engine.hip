@@ -31,6 +31,7 @@ int g_conv_want = 256;    // experiment: workgroup target of the conv GEMMs' til
 int g_defer_dw = 1;    // 1: the decoder's weight-gradient GEMMs start after its last input gradient (see lstm_bwd)
 int g_side_prio = 0;   // 1: create the side stream with the lowest priority (read at ss_bind).  Measured: 2.3x SLOWER
                        //    (35 ms vs 14.8 ms per step): the low-priority queue starves behind 768 tiny step launches.
+int g_branch_low = 0;      // experiment: the probed branch streams are created with the lowest priority (read at ss_bind); measured 5.78 vs 5.80 ms, off
 int g_batch_dirs = 1;      // BLSTM weight gradients: both directions of a layer in one launch per matrix (batch = 2) + one bias kernel:
                            // 1 = the encoder BLSTMs (36 -> 14 launches), 2 = the decoder too (measured: step +0.18 ms), 0 = never
 int g_prewarm = 2;         // streaming pre-read of a decoder layer's operand slabs on a side stream beside its persistent recurrence: bit 1 forward
@@ -609,8 +610,10 @@ int pick_streams(ss_engine* e, hipStream_t main) {
     hipStream_t pool[POOL] = {};
     hipEvent_t ev[3] = {};
     for (auto& x : ev) HIPCHK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+    int least = 0, greatest = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
     for (auto& st : pool) {
-        HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, g_branch_low ? least : 0));
         hipLaunchKernelGGL(queue_probe_nop_kernel, dim3(1), dim3(1), 0, st);      // first use of a stream sets its queue up: not inside a measurement
     }
     hipLaunchKernelGGL(queue_probe_nop_kernel, dim3(1), dim3(1), 0, main);
@@ -2071,6 +2074,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "seq_wlead" && value >= 0 && value < 32) g_seq_wlead = value;
     else if (k == "prewarm" && value >= 0 && value <= 3) g_prewarm = value;
     else if (k == "batch_dirs" && value >= 0 && value <= 2) g_batch_dirs = value;
+    else if (k == "branch_low" && (value == 0 || value == 1)) g_branch_low = value;
     else if (k == "gemm_ws" && value >= 0 && value <= 2) g_gemm_ws = value;
     else if (k == "seq_spin_log2" && value >= 0 && value <= 24) g_seq_spin_log2 = value;
     else if (k == "overlap" && (value == 0 || value == 1)) g_overlap = value;
