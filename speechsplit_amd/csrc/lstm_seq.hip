@@ -836,17 +836,22 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
                 for (int pc = 0; pc < 2; ++pc) a[ks][pc] = *reinterpret_cast<const f16x8*>(&a_lds[ks][pc][lane][0]);
             const f32x4 us = *reinterpret_cast<const f32x4*>(&row_unscale[lq * 4]);      // accumulator rows 4*lq + r
             unsigned char* q = xwr + ((st + 1) & 1) * half;
+            const unsigned tg = tag_of(st + 1);
+            // two column tiles at a time: their two product chains interleave (a dependent 16x16x32 MFMA waits for its predecessor),
+            // and the first pair's stores drain under the second pair's products
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                acc = mfma3(a[0], bw[0][ct], acc);
-                acc = mfma3(a[1], bw[1][ct], acc);
-                acc *= us;
-                const unsigned tg = tag_of(st + 1);
+            for (int c0 = 0; c0 < CT; c0 += 2) {
+                f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                mfma3_each<2>(a[0], [&](int i, int pc) -> const f16x8& { return bw[0][c0 + i][pc]; }, acc);
+                mfma3_each<2>(a[1], [&](int i, int pc) -> const f16x8& { return bw[1][c0 + i][pc]; }, acc);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] = __uint_as_float((__float_as_uint(acc[c]) & ~1u) | tg);
-                if (local) store16_plain(q + (long)ct * JT * 1024, acc);     // hand-off payload, group on one XCD: the shared L2 has it
-                else store16_sc1(q + (long)ct * JT * 1024, acc);              // group spans XCDs: write-through
+                for (int i = 0; i < 2; ++i) {
+                    f32x4 v = acc[i] * us;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = __uint_as_float((__float_as_uint(v[c]) & ~1u) | tg);
+                    if (local) store16_plain(q + (long)(c0 + i) * JT * 1024, v);     // hand-off payload, group on one XCD: the shared L2 has it
+                    else store16_sc1(q + (long)(c0 + i) * JT * 1024, v);              // group spans XCDs: write-through
+                }
             }
         }
         // nothing to publish, and no closing barrier either -- red[] is next written behind this step's second barrier, a_lds /
