@@ -16,7 +16,8 @@
 namespace ss {
 
 extern int g_gemm_want;
-int g_gemm_tr = 2;       // transposing LDS reads for reduction-major operands of 128-wide tiles: 1 wherever possible, 2 not for TN, 0 never
+int g_gemm_tr = 1;       // transposing LDS reads for reduction-major operands of 128-wide tiles: 1 wherever possible, 2 not for TN, 0 never
+                         // (round 2: 1 -- since the kernels are held to three waves per SIMD the TN weight gradients gain too, step -0.08 ms)
 int g_gemm_ws = 0;        // 128 x 128 fp16 x 2 tiles: 1 = the wave-specialised (512-thread) form where it measured faster in isolation, 2 = always,
                           // 0 = never (default: in the training step, where two convolutions share the chip anyway, 1 measured 0.02 ms slower)
 int g_gemm_mode = 1;      // 0: exact-fp32 MFMA kernel (gemm_f32.hip), 1: bf16x3 kernel whenever operands are 16-byte aligned

@@ -455,17 +455,17 @@ def _full_gradients(E, B, T, wseed, bseed, want_safe):
         assert rel(gv[n], p.grad) < tol[n], (n, tol[n])
 
 
-@pytest.mark.parametrize('knob', ['small_lds', 'defer_dw', 'dx_batched', 'gemm_tr=1', 'gemm_tr=0'])
+@pytest.mark.parametrize('knob', ['small_lds', 'defer_dw', 'dx_batched', 'gemm_tr=2', 'gemm_tr=0'])
 def test_schedule_knobs_do_not_change_gradients(E, knob):
     """The LDS-staged small recurrences vs. the streaming fallback, the deferred vs. co-scheduled decoder weight
     gradients, the per-utterance vs. whole-slab input-gradient GEMMs and the two LDS images of reduction-major GEMM
-    operands (transposing reads everywhere / nowhere; default: not for TN) are alternative schedules of the same arithmetic: the oracle parity of the variant that is off by default must hold as well."""
+    operands (transposing reads not for TN / nowhere; default: everywhere) are alternative schedules of the same arithmetic: the oracle parity of the variant that is off by default must hold as well."""
     name, _, val = knob.partition('=')
     E.tune(name, int(val or 0))
     try:
         _full_gradients(E, 4, 128, 9, 61, False)
     finally:
-        E.tune(name, 2 if name in ('dx_batched', 'gemm_tr') else 1)
+        E.tune(name, 2 if name == 'dx_batched' else 1)
 
 
 def test_g6_train_step(E):
