@@ -391,6 +391,45 @@ __global__ __launch_bounds__(256) void build_dec_in_kernel(CodeSrcPack p, const 
     }
 }
 
+// The decoder input repeats in blocks of f frames (every code is up-sampled by the same f, the speaker row is constant): its COMPACT
+// form has one row per block, xc [B][T / f][ld].  grid = (T / f, B), block 256
+__global__ __launch_bounds__(256) void build_dec_in_compact_kernel(CodeSrcPack p, const float* __restrict__ emb, int emb_dim,
+                                                                   int emb_col, float* __restrict__ xc, int ld, int T, int f) {
+    const int blk = blockIdx.x, b = blockIdx.y;
+    const int TP = T + 2 * HALO;
+    float* row = xc + ((long)b * (T / f) + blk) * ld;
+    for (int c = threadIdx.x; c < ld; c += 256) {
+        float v = 0.f;
+        if (c >= emb_col && c < emb_col + emb_dim) {
+            v = emb[(long)b * emb_dim + c - emb_col];
+        } else {
+            for (int i = 0; i < p.n; ++i) {
+                const int H = p.s[i].H, col = p.s[i].col;
+                if (c >= col && c < col + 2 * H) {
+                    const int cc = c - col;
+                    const int ts = cc < H ? blk * f + f - 1 : blk * f;      // as build_dec_in_kernel
+                    v = p.s[i].o[((long)b * TP + ts + HALO) * (2 * H) + cc];
+                }
+            }
+        }
+        row[c] = v;
+    }
+}
+
+// gradient of the same: d_xc [B][T / f][ld] already holds the sum over each block's frames.  grid = (T, B)
+__global__ __launch_bounds__(128) void dec_in_grad_compact_kernel(CodeSrcPack p, const float* __restrict__ d_xc, int ld, int T, int f) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    const int TP = T + 2 * HALO;
+    for (int i = 0; i < p.n; ++i) {
+        const int H = p.s[i].H, col = p.s[i].col;
+        float* drow = p.s[i].d_o + ((long)b * TP + t + HALO) * (2 * H);
+        for (int cc = threadIdx.x; cc < 2 * H; cc += 128) {
+            const bool sampled = cc < H ? (t % f == f - 1) : (t % f == 0);
+            drow[cc] = sampled ? d_xc[((long)b * (T / f) + t / f) * ld + col + cc] : 0.f;
+        }
+    }
+}
+
 // grid = (T, B): writes the full gradient slab of every encoder BLSTM output (zeros where the code is not sampled)
 __global__ __launch_bounds__(128) void dec_in_grad_kernel(CodeSrcPack p, const float* __restrict__ d_dec_in, int ld, int T) {
     const int t = blockIdx.x, b = blockIdx.y;
@@ -621,6 +660,25 @@ hipError_t build_dec_in(const CodeSrc* src, int nsrc, const float* emb, int emb_
     p.n = nsrc;
     for (int i = 0; i < nsrc; ++i) p.s[i] = src[i];
     hipLaunchKernelGGL(build_dec_in_kernel, dim3(T, B), dim3(256), 0, s, p, emb, emb_dim, emb_col, dec_in, ld, T);
+    return hipGetLastError();
+}
+
+hipError_t build_dec_in_compact(const CodeSrc* src, int nsrc, const float* emb, int emb_dim, int emb_col, float* xc, int ld, int B, int T,
+                                int f, hipStream_t s) {
+    if (nsrc > 4 || f < 1 || T % f) return hipErrorInvalidValue;
+    CodeSrcPack p{};
+    p.n = nsrc;
+    for (int i = 0; i < nsrc; ++i) p.s[i] = src[i];
+    hipLaunchKernelGGL(build_dec_in_compact_kernel, dim3(T / f, B), dim3(256), 0, s, p, emb, emb_dim, emb_col, xc, ld, T, f);
+    return hipGetLastError();
+}
+
+hipError_t dec_in_grad_compact(const CodeSrc* src, int nsrc, const float* d_xc, int ld, int B, int T, int f, hipStream_t s) {
+    if (nsrc > 4 || f < 1 || T % f) return hipErrorInvalidValue;
+    CodeSrcPack p{};
+    p.n = nsrc;
+    for (int i = 0; i < nsrc; ++i) p.s[i] = src[i];
+    hipLaunchKernelGGL(dec_in_grad_compact_kernel, dim3(T, B), dim3(128), 0, s, p, d_xc, ld, T, f);
     return hipGetLastError();
 }
 

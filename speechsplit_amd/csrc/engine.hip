@@ -32,6 +32,7 @@ int g_defer_dw = 1;    // 1: the decoder's weight-gradient GEMMs start after its
 int g_side_prio = 0;   // 1: create the side stream with the lowest priority (read at ss_bind).  Measured: 2.3x SLOWER
                        //    (35 ms vs 14.8 ms per step): the low-priority queue starves behind 768 tiny step launches.
 int g_branch_low = 0;      // experiment: the probed branch streams are created with the lowest priority (read at ss_bind); measured 5.78 vs 5.80 ms, off
+int g_compact0 = 1;        // decoder layer 0: input projections, input gradient and W_ih gradient once per block of repeated input frames
 int g_batch_dirs = 1;      // BLSTM weight gradients: both directions of a layer in one launch per matrix (batch = 2) + one bias kernel:
                            // 1 = the encoder BLSTMs (36 -> 14 launches), 2 = the decoder too (measured: step +0.18 ms), 0 = never
 int g_prewarm = 2;         // streaming pre-read of a decoder layer's operand slabs on a side stream beside its persistent recurrence: bit 1 forward
@@ -120,6 +121,11 @@ struct LstmBlk {
     // backward exchange tiles, one set per layer: the tagged hand-off (lstm_seq.hip) needs them zero at launch
     void* px_l(int l) const { return zb + 4L * LSTM_SEQ_SYNC_WORDS * L + gf_bytes * l; }
     float* dmid[2] = {nullptr, nullptr};   // gradient slabs of inner layer outputs [B,TP,2H]
+    // Layer 0's input repeats in blocks of xf frames (decoder: every code is up-sampled by the same factor, the speaker row is constant;
+    // xf = 0: not so / not used): compact input xc [B*T/xf][In], its projections xp0 [.][8H], block sums of the pre-activation gradients
+    // dgs [.][8H] and the input gradient d_xc [.][In], one row per block
+    int xf = 0;
+    float *xc = nullptr, *xp0 = nullptr, *dgs = nullptr, *d_xc = nullptr;
     bool big() const { return H > 32; }
     int in_of(int l) const { return l == 0 ? In : 2 * H; }
 };
@@ -431,6 +437,18 @@ long ss_engine::carve(int B, int T, bool assign) {
     d_ot = slab("enc2.d_ot", 2L * lt.H);
     dec_in = slab("dec.in", dec_in_dim);
     d_dec_in = slab("dec.d_in", dec_in_dim);
+    {
+        const int F = hp.freq_2;
+        const bool same = hp.freq_3 == F && (kind != SS_GENERATOR_3 || hp.freq == F);
+        ld.xf = (same && F > 1 && T % F == 0 && ld.big()) ? F : 0;       // structurally possible; ss_tune("compact0") decides per step
+        if (ld.xf) {
+            const long R8 = (long)B * (T / F);
+            ld.xc = (float*)take(R8 * dec_in_dim * 4);
+            ld.xp0 = (float*)take(R8 * 8 * ld.H * 4);
+            ld.dgs = (float*)take(R8 * 8 * ld.H * 4);
+            ld.d_xc = (float*)take(R8 * dec_in_dim * 4);
+        }
+    }
     d_top = slab("dec.d_top", 2L * ld.H);
     out_slab = slab("out", head_out);
     d_out_slab = slab("d_out", head_out);
@@ -828,9 +846,23 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
     for (int l = 0; l < lb.L; ++l) {
         const int In = lb.in_of(l);
         Slab xi = l == 0 ? x : Slab{lb.out[l - 1], 2L * H};
+        const bool compact = l == 0 && lb.xf && persist && x.p == lb.xc;       // the input repeats in blocks of xf frames: one projection row per block
         for (int c = 0; c < nch; ++c) {
             const long r0 = (long)ch[c].b0 * TP;
-            {   // both directions in one GEMM against the stacked W_ih / summed biases of lstm_prep (N = 8H)
+            if (compact) {
+                GemmDesc d{};
+                d.A = {lb.xc, In, 0, 0, 0};
+                d.B = {lb.wcat[l], In, 0, 0, 0};
+                d.C = lb.xp0;
+                d.ldc = 8L * H;
+                d.bias = lb.bsum + (long)l * 8 * H;
+                d.M = B * (T / lb.xf);
+                d.N = 8 * H;
+                d.K = In;
+                d.batch = 1;
+                d.ksplit = 1;
+                PGEMM_FWD_ON(SS_PROF_DEC_PROJ0, d, ch[c].st);
+            } else {   // both directions in one GEMM against the stacked W_ih / summed biases of lstm_prep (N = 8H)
                 GemmDesc d{};
                 d.A = {xi.p + (r0 + HALO) * xi.ld, xi.ld, TP * xi.ld, 0, 0};
                 d.B = {lb.wcat[l], In, 0, 0, 0};
@@ -853,14 +885,14 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
         }
         if (persist) {   // start state zeroed by lstm_prep
             // the input projections the GEMM has just written are read once more, in whole lines, beside the recurrence (lstm_seq.hip)
-            const bool pw = (g_prewarm & 2) && e->side3 && g_overlap && !g_graph;
+            const bool pw = (g_prewarm & 2) && e->side3 && g_overlap && !g_graph && !compact;
             if (pw) {
                 CHK(fork_join(e, s, e->side3));
                 HIPCHK(slab_prewarm(lb.gates[l], 8 * H, nullptr, nullptr, 2 * H, e->amax, B, T, false, e->side3));
             }
             const int pi = prof_begin(e, SS_PROF_REC_FWD, s, 2.0 * 2 * B * T * 4.0 * H * H);
             HIPCHK(lstm_seq_fwd(lb.gates[l], e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.hf_l(l), lb.out[l], lb.csave[l],
-                                lb.sync_f(l), e->sticky, B, T, H, false, false, s));
+                                lb.sync_f(l), e->sticky, compact ? lb.xp0 : nullptr, compact ? lb.xf : 0, B, T, H, false, false, s));
             prof_end(e, pi, s);
             if (pw) CHK(fork_join(e, e->side3, s));
             continue;
@@ -877,6 +909,9 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
     if (nch == 2) CHK(fork_join(e, ch[1].st, s));
     return 0;
 }
+
+// the decoder's layer 0 runs on the compact (one row per block of repeated frames) form of its input
+static bool dec_compact(const ss_engine* e) { return g_compact0 && e->ld.xf > 0 && e->ld.big() && g_persist && lstm_seq_supported(e->curB, e->ld.H); }
 
 int lstm_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
     if (lb.big()) return lstm_big_fwd(e, lb, x, s);
@@ -915,9 +950,10 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
     const int In = lb.in_of(l);
     float* dG = lb.gates[l];
     const LstmDir &p0 = lb.pd[l * 2], &p1 = lb.pd[l * 2 + 1];
+    const bool compact = l == 0 && lb.xf && xi.p == lb.xc;     // dW_ih from the block sums and one input row per block (K / xf)
     // Both directions in ONE launch each (batch = 2) when their parameters sit at one stride in the arena (PyTorch's order: they do).
     // dW_hh: h_prev is `out` one row earlier (forward) / later (reverse), so the forward direction reads dG one row later instead.
-    if ((g_batch_dirs == 2 || (g_batch_dirs == 1 && !lb.big())) && p1.wih - p0.wih == p1.whh - p0.whh && p1.wih > p0.wih) {
+    if (!compact && (g_batch_dirs == 2 || (g_batch_dirs == 1 && !lb.big())) && p1.wih - p0.wih == p1.whh - p0.whh && p1.wih > p0.wih) {
         const long pstride = p1.wih - p0.wih;
         GemmDesc a{};
         a.A = {dG, 8L * H, 4L * H, 0, 0};
@@ -955,13 +991,13 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
         const float* dGd = dG + dir * 4L * H;
         // dW_ih[n][k] = sum_r dG[r][n] * X[r][k]
         GemmDesc a{};
-        a.A = {dGd, 8L * H, 0, 0, 0};
+        a.A = {compact ? lb.dgs + dir * 4L * H : dGd, 8L * H, 0, 0, 0};
         a.B = {xi.p, xi.ld, 0, 0, 0};
         a.C = e->G + pd.wih;
         a.ldc = In;
         a.M = 4 * H;
         a.N = In;
-        a.K = (int)R;
+        a.K = compact ? B * (T / lb.xf) : (int)R;
         a.batch = 1;
         a.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM | (am ? GEMM_F16X2 : 0);
         a.amax_a = am;                              // gradient slab: measured scale; the layer input is O(1)
@@ -991,6 +1027,26 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
 
 // input gradient of one layer for the slab rows [r0, r0 + nr):  dX = dG . W_ih  (both directions accumulate)
 int lstm_input_grad(ss_engine* e, LstmBlk& lb, int l, Slab dxi, long r0, long nr, const float* am, hipStream_t st) {
+    if (l == 0 && lb.xf && dxi.p == lb.d_xc) {
+        // compact: d_xc[block] = (sum of dG over the block's frames) . W_ih, one row per block of repeated input frames
+        const int H = lb.H, In = lb.in_of(0);
+        const long R8 = (long)e->curB * (e->curT / lb.xf);
+        GemmDesc g{};
+        g.A = {lb.dgs, 8L * H, 0, 0, 0};
+        g.B = {lb.wcat[0], In, 0, 0, 0};
+        g.C = lb.d_xc;
+        g.ldc = In;
+        g.M = (int)R8;
+        g.N = In;
+        g.K = 8 * H;
+        g.batch = 1;
+        g.flags = GEMM_TB | GEMM_ACCUM | (am ? GEMM_F16X2 : 0);
+        g.amax_a = am;                              // the block sums are at most xf times the slab's maximum: inside the scale's headroom (256x)
+        g.ksplit = 8;
+        HIPCHK(hipMemsetAsync(g.C, 0, R8 * In * 4, st));
+        PGEMM_ON(SS_PROF_DEC_DX, g, st);
+        return 0;
+    }
     // dX[r][k] = sum over both directions' 8H gate units of dG[r][n] * W_ih[n][k]: ONE GEMM against the stacked weights
     // (lstm_prep).  A narrow input (the decoder's 164 columns) is cut along the reduction so the launch still fills the chip.
     const int H = lb.H, In = lb.in_of(l), T = e->curT;
@@ -1071,7 +1127,8 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
                 const int pi = prof_begin(e, SS_PROF_REC_BWD, s, 2.0 * 2 * B * T * 4.0 * H * H);
                 HIPCHK(lstm_seq_bwd(dG, e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.px_l(l), dcur, lb.csave[l], lb.sync_b(l),
                                     e->sticky, am, bias_in_kernel ? e->G + lb.pd[l * 2].bih : nullptr,
-                                    bias_in_kernel ? e->G + lb.pd[l * 2 + 1].bih : nullptr, B, T, H, false, false, s));
+                                    bias_in_kernel ? e->G + lb.pd[l * 2 + 1].bih : nullptr, (l == 0 && lb.xf && dx.p == lb.d_xc) ? lb.dgs : nullptr,
+                                    (l == 0 && lb.xf && dx.p == lb.d_xc) ? lb.xf : 0, B, T, H, false, false, s));
                 prof_end(e, pi, s);
                 if (pw) CHK(fork_join(e, e->side3, s));
             }
@@ -1260,14 +1317,19 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
         src[n++] = {e->l1.out[1], e->d_o1, h.dim_neck, h.freq, 0};
         src[n++] = {e->lt.out[0], e->d_ot, h.dim_neck_2, h.freq_2, 2 * h.dim_neck};
         src[n++] = {e->l2.out[0], e->d_o2, h.dim_neck_3, h.freq_3, 2 * h.dim_neck + 2 * h.dim_neck_2};
-        HIPCHK(build_dec_in(src, n, e->emb, h.dim_spk_emb, 2 * h.dim_neck + 2 * h.dim_neck_2 + 2 * h.dim_neck_3, e->dec_in,
-                            e->dec_in_dim, B, T, s));
+        if (dec_compact(e))
+            HIPCHK(build_dec_in_compact(src, n, e->emb, h.dim_spk_emb, 2 * h.dim_neck + 2 * h.dim_neck_2 + 2 * h.dim_neck_3, e->ld.xc,
+                                        e->dec_in_dim, B, T, e->ld.xf, s));
+        else
+            HIPCHK(build_dec_in(src, n, e->emb, h.dim_spk_emb, 2 * h.dim_neck + 2 * h.dim_neck_2 + 2 * h.dim_neck_3, e->dec_in,
+                                e->dec_in_dim, B, T, s));
     } else {
         src[n++] = {e->lt.out[0], e->d_ot, h.dim_neck_2, h.freq_2, 0};
         src[n++] = {e->l2.out[0], e->d_o2, h.dim_neck_3, h.freq_3, 2 * h.dim_neck_2};
-        HIPCHK(build_dec_in(src, n, nullptr, 0, e->dec_in_dim, e->dec_in, e->dec_in_dim, B, T, s));
+        if (dec_compact(e)) HIPCHK(build_dec_in_compact(src, n, nullptr, 0, e->dec_in_dim, e->ld.xc, e->dec_in_dim, B, T, e->ld.xf, s));
+        else HIPCHK(build_dec_in(src, n, nullptr, 0, e->dec_in_dim, e->dec_in, e->dec_in_dim, B, T, s));
     }
-    CHK(lstm_fwd(e, e->ld, Slab{e->dec_in, e->dec_in_dim}, s));
+    CHK(lstm_fwd(e, e->ld, dec_compact(e) ? Slab{e->ld.xc, e->dec_in_dim} : Slab{e->dec_in, e->dec_in_dim}, s));
     // LinearNorm head (model.py:253 / 277)
     const long HD = 2L * e->ld.H;
     GemmDesc d{};
@@ -1358,7 +1420,8 @@ int backward_decoder(ss_engine* e, hipStream_t s, bool late = false) {
         PGEMM_ON(SS_PROF_HEAD, g, s);
     }
     if (par) CHK(fork_join(e, b2, s));
-    CHK(lstm_bwd(e, e->ld, e->d_top, Slab{e->dec_in, e->dec_in_dim}, Slab{e->d_dec_in, e->dec_in_dim}, s, nullptr, late));
+    if (dec_compact(e)) CHK(lstm_bwd(e, e->ld, e->d_top, Slab{e->ld.xc, e->dec_in_dim}, Slab{e->ld.d_xc, e->dec_in_dim}, s, nullptr, late));
+    else CHK(lstm_bwd(e, e->ld, e->d_top, Slab{e->dec_in, e->dec_in_dim}, Slab{e->d_dec_in, e->dec_in_dim}, s, nullptr, late));
     if (late) HIPCHK(hipEventRecord(e->ev_join[1], s));          // the chain is through: what the side stream's batch waits for
     else if (defer_head) CHK(head_weight_grads(e, e->side));      // behind the decoder's weight gradients, ordered after the chain by lstm_bwd's fork
                                                             // (measured: on the third branch stream instead 6.395 vs 6.365 ms)
@@ -1387,7 +1450,8 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
         src[n++] = {e->lt.out[0], e->d_ot, h.dim_neck_2, h.freq_2, 0};
         src[n++] = {e->l2.out[0], e->d_o2, h.dim_neck_3, h.freq_3, 2 * h.dim_neck_2};
     }
-    HIPCHK(dec_in_grad(src, n, e->d_dec_in, e->dec_in_dim, B, T, s));
+    if (dec_compact(e)) HIPCHK(dec_in_grad_compact(src, n, e->ld.d_xc, e->dec_in_dim, B, T, e->ld.xf, s));
+    else HIPCHK(dec_in_grad(src, n, e->d_dec_in, e->dec_in_dim, B, T, s));
     const int off2 = g3 ? h.dim_enc : 0;
     // Three independent branches below the decoder input: lstm_1 (on `s`), lstm_2 (`b2`; writes the other columns of d_xf)
     // and Encoder_t (`b3`; joins at the end).  Their weight-gradient GEMMs share the side stream.
@@ -1443,7 +1507,7 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
     // ---- everything that only has to be finished by the end of the step
     if (e->dec_w_pending) {                        // backward_decoder(late): decoder + head weight gradients, behind the decoder chain
         HIPCHK(hipStreamWaitEvent(e->side, e->ev_join[1], 0));
-        CHK(lstm_late_weights(e, e->ld, Slab{e->dec_in, e->dec_in_dim}, e->side));
+        CHK(lstm_late_weights(e, e->ld, dec_compact(e) ? Slab{e->ld.xc, e->dec_in_dim} : Slab{e->dec_in, e->dec_in_dim}, e->side));
         CHK(head_weight_grads(e, e->side));
         e->side_used = true;
         e->dec_w_pending = false;
@@ -2074,6 +2138,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "seq_wlead" && value >= 0 && value < 32) g_seq_wlead = value;
     else if (k == "prewarm" && value >= 0 && value <= 3) g_prewarm = value;
     else if (k == "batch_dirs" && value >= 0 && value <= 2) g_batch_dirs = value;
+    else if (k == "compact0" && (value == 0 || value == 1)) g_compact0 = value;
     else if (k == "branch_low" && (value == 0 || value == 1)) g_branch_low = value;
     else if (k == "gemm_ws" && value >= 0 && value <= 2) g_gemm_ws = value;
     else if (k == "seq_spin_log2" && value >= 0 && value <= 24) g_seq_spin_log2 = value;
@@ -2118,7 +2183,7 @@ int ss_op_lstm_fwd(float* gates, const float* whh_f, const float* whh_b, float* 
         float* hf = scratch + wn;
         if (g_persist && lstm_seq_supported(B, H) && wn * 4 >= lstm_seq_xbytes(B, H, false)) {
             // exchange buffer in the (unused) packed-weight area, counters behind it
-            HIPCHK(lstm_seq_fwd(gates, whh_f, whh_b, scratch, out, csave, (unsigned*)hf, nullptr, B, T, H, true, g_op_time_major != 0, s));
+            HIPCHK(lstm_seq_fwd(gates, whh_f, whh_b, scratch, out, csave, (unsigned*)hf, nullptr, nullptr, 0, B, T, H, true, g_op_time_major != 0, s));
             return 0;
         }
         HIPCHK(lstm_pack_w(whh_f, whh_b, scratch, H, 0, s));
@@ -2141,7 +2206,7 @@ int ss_op_lstm_bwd(float* gates, const float* whh_f, const float* whh_b, const f
         float* dc = gf + 2 * half;
         const long xbytes = lstm_seq_xbytes(B, H, true);
         if (g_persist && lstm_seq_supported(B, H) && scratch_floats * 4 >= xbytes + 4L * LSTM_SEQ_SYNC_WORDS) {     // [exchange tiles][flags]
-            HIPCHK(lstm_seq_bwd(gates, whh_f, whh_b, scratch, d_out, csave, (unsigned*)((char*)scratch + xbytes), nullptr, nullptr, nullptr, nullptr, B, T,
+            HIPCHK(lstm_seq_bwd(gates, whh_f, whh_b, scratch, d_out, csave, (unsigned*)((char*)scratch + xbytes), nullptr, nullptr, nullptr, nullptr, nullptr, 0, B, T,
                                 H, true, g_op_time_major != 0, s));
             return 0;
         }

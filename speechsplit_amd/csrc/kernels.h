@@ -84,6 +84,11 @@ struct CodeSrc {          // one encoder BLSTM output feeding the decoder input 
 hipError_t build_dec_in(const CodeSrc* src, int nsrc, const float* emb, int emb_dim, int emb_col, float* dec_in, int ld,
                         int B, int T, hipStream_t s);
 hipError_t dec_in_grad(const CodeSrc* src, int nsrc, const float* d_dec_in, int ld, int B, int T, hipStream_t s);
+// compact forms for a decoder input that repeats in blocks of f frames (all codes up-sampled by the same f): one row per block,
+// xc / d_xc [B][T/f][ld]; d_xc holds the gradient already summed over each block's frames
+hipError_t build_dec_in_compact(const CodeSrc* src, int nsrc, const float* emb, int emb_dim, int emb_col, float* xc, int ld, int B, int T,
+                                int f, hipStream_t s);
+hipError_t dec_in_grad_compact(const CodeSrc* src, int nsrc, const float* d_xc, int ld, int B, int T, int f, hipStream_t s);
 
 // loss = mean((tgt - out)^2) over B*T*C real elements (solver.py:166); d_out = 2 (out - tgt) / N * scale
 hipError_t mse_loss(const float* out, long o_ld, long o_bs, const float* tgt, long t_ld, long t_bs, float* d_out,
@@ -149,16 +154,19 @@ hipError_t lstm_step_bwd(float* gates, const float* wfragT, const float* gf_cur,
 constexpr int LSTM_SEQ_SYNC_WORDS = 2048;   // [0] abort, [1..) XCD masks per group, [64 + 32*group + member] completion flags
 bool lstm_seq_supported(int B, int H);
 long lstm_seq_xbytes(int B, int H, bool backward);
+// xc / xf (fwd), dgs / xf (bwd), nullable: a layer whose input repeats in blocks of xf frames -- input projections given once per block
+// [B][T/xf][8H]; pre-activation gradients additionally written summed per block [B][T/xf][8H]
 // sticky (nullable): engine-wide word, host-visible, that a launch ORs 1 into when its bounded wait expires (never cleared by a step)
 hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, float* out, float* csave,
-                        unsigned* sync, unsigned* sticky, int B, int T, int H, bool zero_state, bool time_major, hipStream_t s);
+                        unsigned* sync, unsigned* sticky, const float* xc, int xf, int B, int T, int H, bool zero_state, bool time_major,
+                        hipStream_t s);
 // amax (nullable): device word that receives max |pre-activation gradient| written (atomic max of the float's bit pattern;
 // zero it first) -- the scale the fp16 x 2 GEMMs that consume the gradient slab need
 // gbias_f / gbias_b (nullable): [2][4H] gradient accumulators of (b_ih, b_hh) of the forward / reverse direction; the kernel
 // adds the sum over utterances and time of the pre-activation gradients to both halves (f32 atomics)
 hipError_t lstm_seq_bwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, const float* d_out,
-                        const float* csave, unsigned* sync, unsigned* sticky, float* amax, float* gbias_f, float* gbias_b, int B, int T,
-                        int H, bool zero_state, bool time_major, hipStream_t s);
+                        const float* csave, unsigned* sync, unsigned* sticky, float* amax, float* gbias_f, float* gbias_b, float* dgs, int xf,
+                        int B, int T, int H, bool zero_state, bool time_major, hipStream_t s);
 
 // streaming pre-read (results unused) of the slabs a persistent recurrence is about to consume: wide [rows][cw] (gates) and one or two
 // narrow ones [rows][cn] (cell states; output gradient), both ends of the sequence first.  Meant for a side stream, beside the recurrence.

@@ -350,8 +350,10 @@ template <int H, int NW, bool TAG>
 __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_fwd_kernel(float* __restrict__ gates, const float* __restrict__ whh_f,
                                                                const float* __restrict__ whh_b, unsigned char* __restrict__ xb,
                                                                float* __restrict__ out, float* __restrict__ csave,
-                                                               unsigned* __restrict__ sync, unsigned* __restrict__ sticky, int B, int T,
-                                                               int nbt, int prio) {
+                                                               unsigned* __restrict__ sync, unsigned* __restrict__ sticky,
+                                                               const float* __restrict__ xc, int xf, int B, int T, int nbt, int prio) {
+    // xc (nullable): the input projections in COMPACT form [B][T / xf][8H] -- the layer's input repeats in blocks of xf frames (the
+    // decoder's up-sampled codes, model.py:301-309), so they were computed once per block; `gates` is then only written
     constexpr int JT = H / 16, KC = H / 32, KS = H / NW / 32;       // KS k-steps of 32 per wave
     static_assert(KS == 2, "the persistent forward kernel is written for 64 reduction elements per wave");
     // per-wave partial sums, [unit column][utterance row], rows padded to 20 floats: a lane writes its four accumulator rows
@@ -423,7 +425,8 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_fwd_kernel(float* __re
                 for (int i = 0; i < 4; ++i) {
                     const int idx = lane + 64 * i, u = idx >> 4, g = (idx & 15) >> 2, q = idx & 3;
                     const int bu = bt * 16 + u < B ? bt * 16 + u : B - 1;
-                    __builtin_amdgcn_global_load_lds((const void*)(gates + row_of(bu, tau) * (8 * H) + dir * 4 * H + g * H + jt * 16 + 4 * q), (lds_t)(slot + 256 * i), 16, 0, 0);
+                    const float* rowp = xc ? xc + ((long)bu * (T / xf) + (tau - HALO) / xf) * (8 * H) : gates + row_of(bu, tau) * (8 * H);
+                    __builtin_amdgcn_global_load_lds((const void*)(rowp + dir * 4 * H + g * H + jt * 16 + 4 * q), (lds_t)(slot + 256 * i), 16, 0, 0);
                 }
             };
             if (!(diag & 4)) {
@@ -592,7 +595,10 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
                                                                const float* __restrict__ d_out, const float* __restrict__ csave,
                                                                unsigned* __restrict__ sync, unsigned* __restrict__ sticky,
                                                                unsigned* __restrict__ amax, float* __restrict__ gbias_f,
-                                                               float* __restrict__ gbias_b, int B, int T, int nbt, int prio) {
+                                                               float* __restrict__ gbias_b, float* __restrict__ dgs, int xf, int B, int T,
+                                                               int nbt, int prio) {
+    // dgs (nullable): the layer's input repeats in blocks of xf frames (see the forward kernel), so its input / weight gradients only
+    // need da SUMMED over each block: the storing wave adds the steps of a block up and writes [B][T / xf][8H] (time order, no atomics)
     constexpr int JT = H / 16, CT = JT / NW, PW = JT / NW;      // column tiles (= consumers) / producers handled per wave
     static_assert(CT == 4 || CT == 2, "the persistent backward kernel is written for 2 or 4 column tiles per wave");
     __shared__ __attribute__((aligned(16))) float red[NW][16][20];      // [unit column][utterance row, padded], see the forward kernel
@@ -707,15 +713,25 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing may land in this LDS after the workgroup has gone
             if (!ok) return;
         } else {
+            f32x4 bsm[4] = {};
             for (int st = 0; st < T; ++st) {
                 if (!barriers_to_products(st)) return;
                 if (!(diag & 8)) {
-                    const int tau = tau_of(st);
+                    const int tau = tau_of(st), t = tau - HALO;
+                    const bool close = dgs && (dir == 0 ? t % xf == 0 : t % xf == xf - 1);      // this step completes its block (dir 0 walks down)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int idx = lane + 64 * i, g = idx >> 6, u = (idx & 63) >> 2, q = idx & 3;
                         const f32x4 v = *reinterpret_cast<const f32x4*>(&da_st[g][u][4 * q]);
-                        if (bt * 16 + u < B) *reinterpret_cast<f32x4*>(gates + row_of(bt * 16 + u, tau) * (8 * H) + dir * 4 * H + g * H + jt * 16 + 4 * q) = v;
+                        if (bt * 16 + u >= B) continue;
+                        *reinterpret_cast<f32x4*>(gates + row_of(bt * 16 + u, tau) * (8 * H) + dir * 4 * H + g * H + jt * 16 + 4 * q) = v;
+                        if (dgs) {
+                            bsm[i] += v;
+                            if (close) {
+                                *reinterpret_cast<f32x4*>(dgs + ((long)(bt * 16 + u) * (T / xf) + t / xf) * (8 * H) + dir * 4 * H + g * H + jt * 16 + 4 * q) = bsm[i];
+                                bsm[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            }
+                        }
                     }
                 }
             }
@@ -959,7 +975,9 @@ long lstm_seq_xbytes(int B, int H, bool backward) {
 static int seq_prio_arg(bool time_major) { return (g_seq_prio & 0xFFFF) | ((g_seq_spin_log2 & 31) << 16) | (time_major ? 1 << 21 : 0) | ((g_seq_wlead & 31) << 22); }
 
 hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, float* out, float* csave,
-                        unsigned* sync, unsigned* sticky, int B, int T, int H, bool zero_state, bool time_major, hipStream_t s) {
+                        unsigned* sync, unsigned* sticky, const float* xc, int xf, int B, int T, int H, bool zero_state, bool time_major,
+                        hipStream_t s) {
+    if (xc && (xf < 1 || T % xf)) return hipErrorInvalidValue;
     const int nbt = (B + 15) / 16;
     if (!lstm_seq_supported(B, H)) return hipErrorInvalidValue;
     if (zero_state) {
@@ -973,16 +991,17 @@ hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, vo
     // round-robin placement) 2.47 -> 2.03; groups that span XCDs, whose polls and write-through payload cross the fabric,
     // 3.10 -> 3.23 (B = 16) and 3.00 -> 3.47 (B = 48).  The backward gains either way (3.13 -> 2.98, 3.40 -> 2.49, 4.13 -> 3.25).
     const bool tag = g_seq_tag && (2 * nbt) % 8 == 0;
-    if (H == 512 && tag) hipLaunchKernelGGL((lstm_seq_fwd_kernel<512, 8, true>), dim3(2 * nbt * 32), dim3(640), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, B, T, nbt, pa);
-    else if (H == 512)         hipLaunchKernelGGL((lstm_seq_fwd_kernel<512, 8, false>), dim3(2 * nbt * 32), dim3(640), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, B, T, nbt, pa);
-    else if (tag)              hipLaunchKernelGGL((lstm_seq_fwd_kernel<256, 4, true>), dim3(2 * nbt * 16), dim3(384), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, B, T, nbt, pa);
-    else                       hipLaunchKernelGGL((lstm_seq_fwd_kernel<256, 4, false>), dim3(2 * nbt * 16), dim3(384), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, B, T, nbt, pa);
+    if (H == 512 && tag) hipLaunchKernelGGL((lstm_seq_fwd_kernel<512, 8, true>), dim3(2 * nbt * 32), dim3(640), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, xc, xf, B, T, nbt, pa);
+    else if (H == 512)         hipLaunchKernelGGL((lstm_seq_fwd_kernel<512, 8, false>), dim3(2 * nbt * 32), dim3(640), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, xc, xf, B, T, nbt, pa);
+    else if (tag)              hipLaunchKernelGGL((lstm_seq_fwd_kernel<256, 4, true>), dim3(2 * nbt * 16), dim3(384), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, xc, xf, B, T, nbt, pa);
+    else                       hipLaunchKernelGGL((lstm_seq_fwd_kernel<256, 4, false>), dim3(2 * nbt * 16), dim3(384), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, xc, xf, B, T, nbt, pa);
     return hipGetLastError();
 }
 
 hipError_t lstm_seq_bwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, const float* d_out,
-                        const float* csave, unsigned* sync, unsigned* sticky, float* amax, float* gbias_f, float* gbias_b, int B, int T,
-                        int H, bool zero_state, bool time_major, hipStream_t s) {
+                        const float* csave, unsigned* sync, unsigned* sticky, float* amax, float* gbias_f, float* gbias_b, float* dgs, int xf,
+                        int B, int T, int H, bool zero_state, bool time_major, hipStream_t s) {
+    if (dgs && (xf < 1 || T % xf)) return hipErrorInvalidValue;
     const int nbt = (B + 15) / 16;
     if (!lstm_seq_supported(B, H)) return hipErrorInvalidValue;
     if (zero_state) {
@@ -994,8 +1013,8 @@ hipError_t lstm_seq_bwd(float* gates, const float* whh_f, const float* whh_b, vo
     unsigned* am = reinterpret_cast<unsigned*>(amax);
     const dim3 grid(2 * nbt * (H / 16)), block(640);
     const int pa = seq_prio_arg(time_major);
-    if (H == 512) hipLaunchKernelGGL((lstm_seq_bwd_kernel<512, 8>), grid, block, 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, am, gbias_f, gbias_b, B, T, nbt, pa);
-    else          hipLaunchKernelGGL((lstm_seq_bwd_kernel<256, 8>), grid, block, 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, am, gbias_f, gbias_b, B, T, nbt, pa);
+    if (H == 512) hipLaunchKernelGGL((lstm_seq_bwd_kernel<512, 8>), grid, block, 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, am, gbias_f, gbias_b, dgs, xf, B, T, nbt, pa);
+    else          hipLaunchKernelGGL((lstm_seq_bwd_kernel<256, 8>), grid, block, 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, am, gbias_f, gbias_b, dgs, xf, B, T, nbt, pa);
     return hipGetLastError();
 }
 
