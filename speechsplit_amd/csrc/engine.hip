@@ -32,6 +32,7 @@ int g_defer_dw = 1;    // 1: the decoder's weight-gradient GEMMs start after its
 int g_side_prio = 0;   // 1: create the side stream with the lowest priority (read at ss_bind).  Measured: 2.3x SLOWER
                        //    (35 ms vs 14.8 ms per step): the low-priority queue starves behind 768 tiny step launches.
 int g_branch_low = 0;      // experiment: the probed branch streams are created with the lowest priority (read at ss_bind); measured 5.78 vs 5.80 ms, off
+int g_trunk_indep = 1;     // Encoder_7 forward: content and pitch conv stacks run as two INDEPENDENT chains (they share only the resampling plans)
 int g_compact0 = 1;        // decoder layer 0: input projections, input gradient and W_ih gradient once per block of repeated input frames
 int g_batch_dirs = 1;      // BLSTM weight gradients: both directions of a layer in one launch per matrix (batch = 2) + one bias kernel:
                            // 1 = the encoder BLSTMs (36 -> 14 launches), 2 = the decoder too (measured: step +0.18 ms), 0 = never
@@ -1227,6 +1228,21 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
                          hh.dim_freq, b2));
         if (e->late_emb) HIPCHK(hipMemcpyAsync(e->emb, e->late_emb, (long)B * hh.dim_spk_emb * 4, hipMemcpyDeviceToDevice, b2));
     }
+    // Encoder_7's content (512 ch) and pitch (256 ch) stacks only share the random-resampling PLAN of each layer (model.py:199-206: one
+    // warp applied to the concatenation), and the plans depend on the draws alone.  With g_trunk_indep the plans are computed first thing
+    // on the branch stream and the two stacks run as independent chains on `s` and `b1` -- conv, GroupNorm, gather of their OWN columns --
+    // down to their BLSTMs, instead of meeting before every gather.
+    const bool indep = g3 && par && g_conv_par && g_trunk_indep && !g_graph;
+    hipEvent_t plans = nullptr;
+    if (indep && training) {
+        for (int i = 0; i < 3; ++i)
+            HIPCHK(interp_plan(e->plan[draw0 + i], scales + (long)(draw0 + i) * B * S7, len_seg + (long)(draw0 + i) * B * S7, nullptr,
+                               e->hp.max_len_pad, B, b2));
+        plans = e->ev[e->ev_next];
+        e->ev_next = (e->ev_next + 1) & 15;
+        HIPCHK(hipEventRecord(plans, b2));
+    }
+    if (indep) CHK(fork_join(e, s, b1));
     for (int i = 1; i < 3; ++i) {
         if (g3) CHK(conv_pack_all(e, e->c1[i], b2));
         CHK(conv_pack_all(e, e->c2[i], b2));
@@ -1272,7 +1288,24 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
             // the WAIT was issued, not only up to the recorded event (measured: the trunk stalled ~250 us behind the tiny
             // launches below).  So: first trunk layer, the wait for the re-layouts, and only then the rest of b2's work.
             if (packed) HIPCHK(hipStreamWaitEvent(s, packed, 0));
+            if (packed && indep) HIPCHK(hipStreamWaitEvent(b1, packed, 0));
             if (!prio_fwd) CHK(branch_work());
+        }
+        if (indep) {
+            Slab x1 = i == 0 ? Slab{e->in_mel, e->hp.dim_freq} : Slab{e->xf[i - 1], CE};
+            Slab x2 = i == 0 ? Slab{e->in_f0, e->f0p} : Slab{e->xf[i - 1] + off2, CE};
+            CHK(conv_block_fwd(e, e->c2[i], x2, Slab{y + off2, CE}, b1));
+            CHK(conv_block_fwd(e, e->c1[i], x1, Slab{y, CE}, s));
+            if (training) {
+                InterpPlan& pl = e->plan[draw0 + i];
+                if (i == 0) {
+                    HIPCHK(hipStreamWaitEvent(b1, plans, 0));
+                    HIPCHK(hipStreamWaitEvent(s, plans, 0));
+                }
+                HIPCHK(interp_gather(pl, e->act + HALO * CE + off2, CE, TP * CE, e->xf[i] + HALO * CE + off2, CE, TP * CE, CE - off2, B, b1));
+                HIPCHK(interp_gather(pl, e->act + HALO * CE, CE, TP * CE, e->xf[i] + HALO * CE, CE, TP * CE, off2, B, s));
+            }
+            continue;
         }
         // The content (512 ch) and pitch (256 ch) blocks of a layer are independent: with g_conv_par the pitch block and the layer's
         // resampling plan run on the first branch stream beside the content block.
@@ -1304,7 +1337,8 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
     if (prio_fwd) CHK(branch_work());
     if (par) {
         CHK(fork_join(e, b2, s));                  // bias sums of every block are ready (and Encoder_t is done)
-        CHK(fork_join(e, s, b1));
+        if (indep) CHK(fork_join(e, b2, b1));      // the pitch chain does not wait for the content chain
+        else CHK(fork_join(e, s, b1));
     }
     CHK(lstm_fwd(e, e->l2, Slab{e->xf[2] + off2, CE}, b1));
     if (g3) CHK(lstm_fwd(e, e->l1, Slab{e->xf[2], CE}, s));
@@ -2139,6 +2173,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "prewarm" && value >= 0 && value <= 3) g_prewarm = value;
     else if (k == "batch_dirs" && value >= 0 && value <= 2) g_batch_dirs = value;
     else if (k == "compact0" && (value == 0 || value == 1)) g_compact0 = value;
+    else if (k == "trunk_indep" && (value == 0 || value == 1)) g_trunk_indep = value;
     else if (k == "branch_low" && (value == 0 || value == 1)) g_branch_low = value;
     else if (k == "gemm_ws" && value >= 0 && value <= 2) g_gemm_ws = value;
     else if (k == "seq_spin_log2" && value >= 0 && value <= 24) g_seq_spin_log2 = value;
