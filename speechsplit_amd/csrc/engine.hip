@@ -125,7 +125,7 @@ struct LstmBlk {
     // Layer 0's input repeats in blocks of xf frames (decoder: every code is up-sampled by the same factor, the speaker row is constant;
     // xf = 0: not so / not used): compact input xc [B*T/xf][In], its projections xp0 [.][8H], block sums of the pre-activation gradients
     // dgs [.][8H] and the input gradient d_xc [.][In], one row per block
-    int xf = 0;
+    int xf = 0, xcols = 0;                 // xcols: leading input columns whose gradient is needed (0: all)
     float *xc = nullptr, *xp0 = nullptr, *dgs = nullptr, *d_xc = nullptr;
     bool big() const { return H > 32; }
     int in_of(int l) const { return l == 0 ? In : 2 * H; }
@@ -442,6 +442,7 @@ long ss_engine::carve(int B, int T, bool assign) {
         const int F = hp.freq_2;
         const bool same = hp.freq_3 == F && (kind != SS_GENERATOR_3 || hp.freq == F);
         ld.xf = (same && F > 1 && T % F == 0 && ld.big()) ? F : 0;       // structurally possible; ss_tune("compact0") decides per step
+        ld.xcols = kind == SS_GENERATOR_3 ? dec_in_dim - hp.dim_spk_emb : 0;
         if (ld.xf) {
             const long R8 = (long)B * (T / F);
             ld.xc = (float*)take(R8 * dec_in_dim * 4);
@@ -1038,7 +1039,7 @@ int lstm_input_grad(ss_engine* e, LstmBlk& lb, int l, Slab dxi, long r0, long nr
         g.C = lb.d_xc;
         g.ldc = In;
         g.M = (int)R8;
-        g.N = In;
+        g.N = lb.xcols > 0 ? lb.xcols : In;        // the speaker columns (last in the row, model.py:308-309) are an input: nobody reads their gradient
         g.K = 8 * H;
         g.batch = 1;
         g.flags = GEMM_TB | GEMM_ACCUM | (am ? GEMM_F16X2 : 0);
