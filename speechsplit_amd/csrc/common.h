@@ -26,6 +26,8 @@ enum GemmFlags {
     GEMM_ACCUM = 4,     // C += result (plain read-modify-write; atomics when ksplit > 1)
     GEMM_F16X2 = 16,    // fp32-grade for O(1)-ranged operands: fp16 x 2 split with a fixed power-of-two scale, 3 MFMAs per k-step
     GEMM_BF16 = 8,      // reduced precision: operands rounded to bf16 (nearest-even), ONE bf16 MFMA per k-step, fp32 accumulate
+    GEMM_A_PRE = 32,    // set by the launcher only: the A / B pointer is the operand's PRE-SPLIT image (GemmDesc::a_pre / b_pre)
+    GEMM_B_PRE = 64,
 };
 
 struct GemmDesc {
@@ -46,6 +48,13 @@ struct GemmDesc {
     // scales the operand by the power of two that brings this maximum into [128, 256).  Null: the fixed scale for O(1) data.
     const float* amax_a;
     const float* amax_b;
+    // Optional pre-split images of an operand (GEMM_F16X2 with the FIXED scale only, i.e. amax_* null): the same matrix geometry (ld,
+    // strides, 4 bytes per element), but every aligned group of four elements along the contiguous axis holds the packed fp16 pieces
+    // (h0h1, h2h3, l0l1, l2l3) of 16 x the values instead of four floats -- written once by whoever produces the operand
+    // (split_image in elementwise.hip, the forward recurrence's storing wave).  The launcher uses an image when the kernel form it picks
+    // loads that operand in whole groups (K-contiguous, or the transposing-read image); otherwise it falls back to the fp32 operand.
+    const float* a_pre;
+    const float* b_pre;
 };
 
 // C[b][m][n] (+)= sum_k A(m,k) * B(n,k) (+ bias[n]);  fp32 in, fp32 MFMA accumulate (exact fp32 fma chain)
@@ -95,6 +104,22 @@ __device__ __forceinline__ float pow2_scale_of(float m) {
 // global memory is fire-and-forget (or is waited for explicitly where a hand-off needs it).
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// Four consecutive values -> their group of the pre-split operand image (GemmDesc::a_pre / b_pre): packed fp16 pieces of 16 x the
+// values, (h0 h1, h2 h3, l0 l1, l2 l3), h = fp16(16 v) to nearest, l = fp16(16 v - h) -- exactly what the GEMM's in-loop split produces
+// with its fixed scale.
+__device__ __forceinline__ uint4 ss_split_group(float v0, float v1, float v2, float v3) {
+    const float s = 16.0f;
+    uint4 r;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(r.x) : "v"(v0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(r.x) : "v"(v1), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(r.y) : "v"(v2), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(r.y) : "v"(v3), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r.z) : "v"(v0), "v"(s), "v"(r.x));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(r.z) : "v"(v1), "v"(s), "v"(r.x));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r.w) : "v"(v2), "v"(s), "v"(r.y));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(r.w) : "v"(v3), "v"(s), "v"(r.y));
+    return r;
 }
 __device__ __forceinline__ float ss_sigmoid(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __expf(-x));        // v_rcp_f32 (1 ulp); the IEEE division sequence is ~10 dependent instructions

@@ -286,22 +286,31 @@ __global__ __launch_bounds__(256) void collate_kernel(const float* __restrict__ 
 }
 
 __global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict__ w, int Co, int Ci, int Cp,
-                                                        float* __restrict__ wf, float* __restrict__ wb) {
-    // wf[co][k][cp] ; wb[ci][k][co] = w[co][ci][4-k]
-    const long nf = (long)Co * 5 * Cp;
-    const long nb = (long)Ci * 5 * Co;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < nf + nb; i += (long)gridDim.x * 256) {
-        if (i < nf) {
+                                                        float* __restrict__ wf, float* __restrict__ wb, float* __restrict__ wf_img,
+                                                        float* __restrict__ wb_img) {
+    // wf[co][k][cp] ; wb[ci][k][co] = w[co][ci][4-k].  Cp and Co are multiples of 4: a thread writes one group of four (and its image)
+    const long nf = (long)Co * 5 * Cp / 4;
+    const long nb = (long)Ci * 5 * Co / 4;
+    for (long gi = blockIdx.x * 256L + threadIdx.x; gi < nf + nb; gi += (long)gridDim.x * 256) {
+        float v[4];
+        if (gi < nf) {
+            const long i = gi * 4;
             const int cp = (int)(i % Cp);
             const int k = (int)((i / Cp) % 5);
             const int co = (int)(i / (5L * Cp));
-            wf[i] = cp < Ci ? w[((long)co * Ci + cp) * 5 + k] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = cp + j < Ci ? w[((long)co * Ci + cp + j) * 5 + k] : 0.f;
+            reinterpret_cast<float4*>(wf)[gi] = make_float4(v[0], v[1], v[2], v[3]);
+            if (wf_img) reinterpret_cast<uint4*>(wf_img)[gi] = ss_split_group(v[0], v[1], v[2], v[3]);
         } else if (wb) {
-            const long q = i - nf;
+            const long q = (gi - nf) * 4;
             const int co = (int)(q % Co);
             const int k = (int)((q / Co) % 5);
             const int ci = (int)(q / (5L * Co));
-            wb[q] = w[((long)co * Ci + ci) * 5 + (4 - k)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = w[((long)(co + j) * Ci + ci) * 5 + (4 - k)];
+            reinterpret_cast<float4*>(wb)[gi - nf] = make_float4(v[0], v[1], v[2], v[3]);
+            if (wb_img) reinterpret_cast<uint4*>(wb_img)[gi - nf] = ss_split_group(v[0], v[1], v[2], v[3]);
         }
     }
 }
@@ -353,6 +362,7 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepTable tb) {
                 v.x += w.x, v.y += w.y, v.z += w.z, v.w += w.w;
             }
             d[i] = v;
+            if (t.img) reinterpret_cast<uint4*>(t.img)[i] = ss_split_group(v.x, v.y, v.z, v.w);
         }
     } else {
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < t.n; i += stride) t.dst[i] = t.a[i] + (t.b ? t.b[i] : 0.f);
@@ -622,11 +632,12 @@ hipError_t collate(const float* mel_cat, const float* f0_cat, const float* emb_t
     return hipGetLastError();
 }
 
-hipError_t conv_pack(const float* w, int Co, int Ci, int Cp, float* wf, float* wb, hipStream_t s) {
-    const long n = (long)Co * 5 * Cp + (long)Ci * 5 * Co;
+hipError_t conv_pack(const float* w, int Co, int Ci, int Cp, float* wf, float* wb, float* wf_img, float* wb_img, hipStream_t s) {
+    if (Cp % 4 || Co % 4) return hipErrorInvalidValue;
+    const long n = ((long)Co * 5 * Cp + (long)Ci * 5 * Co) / 4;
     int g = cdiv(n, 256);
     if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(conv_pack_kernel, dim3(g), dim3(256), 0, s, w, Co, Ci, Cp, wf, wb);
+    hipLaunchKernelGGL(conv_pack_kernel, dim3(g), dim3(256), 0, s, w, Co, Ci, Cp, wf, wb, wf_img, wb_img);
     return hipGetLastError();
 }
 

@@ -33,6 +33,7 @@ int g_side_prio = 0;   // 1: create the side stream with the lowest priority (re
                        //    (35 ms vs 14.8 ms per step): the low-priority queue starves behind 768 tiny step launches.
 int g_branch_low = 0;      // experiment: the probed branch streams are created with the lowest priority (read at ss_bind); measured 5.78 vs 5.80 ms, off
 int g_trunk_indep = 1;     // Encoder_7 forward: content and pitch conv stacks run as two INDEPENDENT chains (they share only the resampling plans)
+int g_presplit = 1;        // weights (and, bit 1, the decoder's hidden states) reach the fp16 x 2 GEMMs as pre-split images: 1 weights, 3 both, 0 off
 int g_compact0 = 1;        // decoder layer 0: input projections, input gradient and W_ih gradient once per block of repeated input frames
 int g_batch_dirs = 1;      // BLSTM weight gradients: both directions of a layer in one launch per matrix (batch = 2) + one bias kernel:
                            // 1 = the encoder BLSTMs (36 -> 14 launches), 2 = the decoder too (measured: step +0.18 ms), 0 = never
@@ -91,6 +92,7 @@ struct ParamInfo {
 struct ConvBlk {
     int Ci = 0, Co = 0, Cp = 0;
     long w = 0, b = 0, ga = 0, be = 0;     // arena offsets
+    float *wf_img = nullptr, *wb_img = nullptr;      // pre-split images of wf / wb (GemmDesc::b_pre)
     float *wf = nullptr, *wb = nullptr, *gp = nullptr, *cout = nullptr, *stats = nullptr, *part = nullptr;
     int amax_i = -1;                       // slot in ss_engine::amax
     bool need_dx = false;
@@ -105,6 +107,7 @@ struct LstmBlk {
     std::vector<LstmDir> pd;               // [L*2]
     std::vector<float*> gates, out, csave; // per layer
     float* bsum = nullptr;                 // [L][2][4H]
+    std::vector<float*> wcat_img;          // per layer: pre-split image of wcat (decoder-size blocks only)
     std::vector<float*> wcat;              // per layer: [W_ih forward ; W_ih reverse] stacked, [8H][In] (input-gradient GEMM over both directions)
     std::vector<float*> wfrag;             // per layer: fragment-major W_hh (forward) / W_hh^T (backward), 2*4H*H floats
     float* hf[2] = {nullptr, nullptr};     // per batch-half chain: ping-pong fragment-major h(t),  2 x [2][ceil16(B)][H]
@@ -345,6 +348,8 @@ long ss_engine::carve(int B, int T, bool assign) {
         if (cb.Co == 0) return;
         cb.wf = (float*)take((long)cb.Co * 5 * cb.Cp * 4);
         cb.wb = cb.need_dx ? (float*)take((long)cb.Ci * 5 * cb.Co * 4) : nullptr;
+        cb.wf_img = (float*)take((long)cb.Co * 5 * cb.Cp * 4);
+        cb.wb_img = cb.need_dx ? (float*)take((long)cb.Ci * 5 * cb.Co * 4) : nullptr;
         cb.cout = slab((name + ".conv").c_str(), cb.Co);
         cb.stats = (float*)take((long)B * (cb.Co / 16) * 2 * 4);
         cb.part = (float*)take((long)B * 3 * cb.Co * 4);          // deterministic mode: per-utterance affine / bias gradient sums
@@ -362,6 +367,9 @@ long ss_engine::carve(int B, int T, bool assign) {
         lb.bsum = (float*)take((long)lb.L * 2 * 4 * lb.H * 4);
         lb.wcat.assign(lb.L, nullptr);
         for (int l = 0; l < lb.L; ++l) lb.wcat[l] = (float*)take(8L * lb.H * lb.in_of(l) * 4);
+        lb.wcat_img.assign(lb.L, nullptr);
+        if (lb.big())
+            for (int l = 0; l < lb.L; ++l) lb.wcat_img[l] = (float*)take(8L * lb.H * lb.in_of(l) * 4);
         if (lb.big()) {
             const long B16 = ((B + 15) / 16) * 16;
             lb.wfrag.assign(lb.L, nullptr);
@@ -722,7 +730,7 @@ void flatten_rows(GemmDesc& d, int B, int T) {
 
 // ---- convolution block -------------------------------------------------------------------------------------
 int conv_pack_all(ss_engine* e, ConvBlk& cb, hipStream_t s) {
-    HIPCHK(conv_pack(e->P + cb.w, cb.Co, cb.Ci, cb.Cp, cb.wf, cb.wb, s));
+    HIPCHK(conv_pack(e->P + cb.w, cb.Co, cb.Ci, cb.Cp, cb.wf, cb.wb, cb.wf_img, cb.wb_img, s));
     return 0;
 }
 
@@ -738,6 +746,7 @@ int conv_block_fwd(ss_engine* e, ConvBlk& cb, Slab x, Slab y, hipStream_t s) {
     GemmDesc d{};
     d.A = {x.p, x.ld, TP * x.ld, cb.Cp, x.ld};
     d.B = {cb.wf, 5L * cb.Cp, 0, 0, 0};
+    d.b_pre = (g_presplit & 1) ? cb.wf_img : nullptr;
     d.C = cb.cout + HALO * cb.Co;
     d.ldc = cb.Co;
     d.cstride = TP * cb.Co;
@@ -781,6 +790,7 @@ int conv_block_bwd(ss_engine* e, ConvBlk& cb, Slab dy, Slab x, Slab dx, hipStrea
         GemmDesc g{};
         g.A = {dy.p, dy.ld, TP * dy.ld, cb.Co, dy.ld};
         g.B = {cb.wb, 5L * cb.Co, 0, 0, 0};
+        g.b_pre = (g_presplit & 1) ? cb.wb_img : nullptr;
         g.C = dx.p + HALO * dx.ld;
         g.ldc = dx.ld;
         g.cstride = TP * dx.ld;
@@ -826,7 +836,7 @@ int lstm_prep(ss_engine* e, LstmBlk& lb, PrepTable& tb, hipStream_t s) {
             const long n = 4L * H * lb.in_of(l);
             if (tb.n + 2 > PREP_MAX) return fail("lstm_prep: task table full");
             tb.t[tb.n++] = {e->P + pd.bih, e->P + pd.bhh, lb.bsum + ((long)l * 2 + dir) * 4 * H, 4L * H};       // summed biases
-            tb.t[tb.n++] = {e->P + pd.wih, nullptr, lb.wcat[l] + dir * n, n};                                    // stacked W_ih
+            tb.t[tb.n++] = {e->P + pd.wih, nullptr, lb.wcat[l] + dir * n, n, lb.wcat_img[l] ? lb.wcat_img[l] + dir * n : nullptr};      // stacked W_ih (+ image)
         }
         // fragment-major W_hh for the one-launch-per-step schedule (the persistent kernels read the parameters directly)
         if (lb.big() && !persist) HIPCHK(lstm_pack_w(e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.wfrag[l], H, 0, s));
@@ -855,6 +865,7 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
                 GemmDesc d{};
                 d.A = {lb.xc, In, 0, 0, 0};
                 d.B = {lb.wcat[l], In, 0, 0, 0};
+                d.b_pre = (g_presplit & 1) ? lb.wcat_img[l] : nullptr;
                 d.C = lb.xp0;
                 d.ldc = 8L * H;
                 d.bias = lb.bsum + (long)l * 8 * H;
@@ -868,6 +879,7 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
                 GemmDesc d{};
                 d.A = {xi.p + (r0 + HALO) * xi.ld, xi.ld, TP * xi.ld, 0, 0};
                 d.B = {lb.wcat[l], In, 0, 0, 0};
+                d.b_pre = (g_presplit & 1) ? lb.wcat_img[l] : nullptr;
                 d.C = lb.gates[l] + (r0 + HALO) * 8L * H;
                 d.ldc = 8L * H;
                 d.cstride = TP * 8L * H;
@@ -926,6 +938,7 @@ int lstm_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
             GemmDesc d{};
             d.A = {xi.p + HALO * xi.ld, xi.ld, TP * xi.ld, 0, 0};
             d.B = {lb.wcat[l], In, 0, 0, 0};
+            d.b_pre = (g_presplit & 1) ? lb.wcat_img[l] : nullptr;
             d.C = lb.gates[l] + HALO * 8L * H;
             d.ldc = 8L * H;
             d.cstride = TP * 8L * H;
@@ -1036,6 +1049,7 @@ int lstm_input_grad(ss_engine* e, LstmBlk& lb, int l, Slab dxi, long r0, long nr
         GemmDesc g{};
         g.A = {lb.dgs, 8L * H, 0, 0, 0};
         g.B = {lb.wcat[0], In, 0, 0, 0};
+        g.b_pre = ((g_presplit & 1) && !lb.wcat_img.empty()) ? lb.wcat_img[0] : nullptr;
         g.C = lb.d_xc;
         g.ldc = In;
         g.M = (int)R8;
@@ -1056,6 +1070,7 @@ int lstm_input_grad(ss_engine* e, LstmBlk& lb, int l, Slab dxi, long r0, long nr
     GemmDesc g{};
     g.A = {lb.gates[l] + r0 * 8L * H, 8L * H, 0, 0, 0};
     g.B = {lb.wcat[l], In, 0, 0, 0};
+    g.b_pre = ((g_presplit & 1) && !lb.wcat_img.empty()) ? lb.wcat_img[l] : nullptr;
     g.C = dxi.p + r0 * dxi.ld;
     g.ldc = dxi.ld;
     g.M = (int)nr;
@@ -2163,7 +2178,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "lstm_g" && value >= 0 && value <= 16) g_lstm_g = value;
 #ifdef SS_DIAG
     else if (k == "lstm_mode" && value >= 0 && value <= 4) g_lstm_mode = value;
-    else if (k == "gemm_diag" && value >= 0 && value < 512) g_gemm_diag = value;
+    else if (k == "gemm_diag" && value >= 0 && value < 2048) g_gemm_diag = value;
     else if (k == "seq_prio" && value >= 0 && value < 65536) g_seq_prio = value;
 #else
     else if (k == "seq_prio" && (value == 0 || value == 1)) g_seq_prio = value;
@@ -2174,6 +2189,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "prewarm" && value >= 0 && value <= 3) g_prewarm = value;
     else if (k == "batch_dirs" && value >= 0 && value <= 2) g_batch_dirs = value;
     else if (k == "compact0" && (value == 0 || value == 1)) g_compact0 = value;
+    else if (k == "presplit" && value >= 0 && value <= 3) g_presplit = value;
     else if (k == "trunk_indep" && (value == 0 || value == 1)) g_trunk_indep = value;
     else if (k == "branch_low" && (value == 0 || value == 1)) g_branch_low = value;
     else if (k == "gemm_ws" && value >= 0 && value <= 2) g_gemm_ws = value;

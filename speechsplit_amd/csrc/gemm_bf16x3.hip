@@ -249,7 +249,8 @@ __global__ __launch_bounds__(WS ? 512 : 256, (NPL == 2 && !WS && !PROBE) ? 3 : 1
     };
     auto gload = [&](int k0, bool full) { gload_to(ra, rb, k0, full); };
     // split the prefetched fp32 values and write the three bf16 planes
-    auto sstore_one = [&](unsigned char* S, int P, bool T, bool TRX, int BX, int f, const Slot& s, float scale) {
+    const bool pre_a = NPL == 2 && ((d.flags & GEMM_A_PRE) || GDIAG(d, 1024)), pre_b = NPL == 2 && ((d.flags & GEMM_B_PRE) || GDIAG(d, 512));
+    auto sstore_one = [&](unsigned char* S, int P, bool T, bool TRX, int BX, int f, const Slot& s, float scale, bool pre = false) {
         const int row = T ? f % BX : f / 8;
         const int k = T ? (f / BX) * 4 : (f % 8) * 4;
         const int o = TRX ? lds_off_t(f / 32, 4 * (f % 32)) : lds_off(row, k);
@@ -258,6 +259,12 @@ __global__ __launch_bounds__(WS ? 512 : 256, (NPL == 2 && !WS && !PROBE) ? 3 : 1
             return;
         }
         if (NPL == 2) {
+            if (pre) {      // the operand is already the interleaved image of its two pieces: (h01, h23, l01, l23) per group of four
+                const u32x4 w = __builtin_bit_cast(u32x4, s);
+                *reinterpret_cast<u32x2*>(S + o) = u32x2{w[0], w[1]};
+                *reinterpret_cast<u32x2*>(S + P + o) = u32x2{w[2], w[3]};
+                return;
+            }
             unsigned ha, la, hb, lb;
             split2_f16(s[0], s[1], scale, ha, la);
             split2_f16(s[2], s[3], scale, hb, lb);
@@ -274,9 +281,9 @@ __global__ __launch_bounds__(WS ? 512 : 256, (NPL == 2 && !WS && !PROBE) ? 3 : 1
     };
     auto sstore_from = [&](const Slot (&qa)[NA], const Slot (&qb)[NB], int buf) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) sstore_one(As + buf * NPL * PA, PA, TA, TRA, BM, tid + i * 256, qa[i], sc_a);
+        for (int i = 0; i < NA; ++i) sstore_one(As + buf * NPL * PA, PA, TA, TRA, BM, tid + i * 256, qa[i], sc_a, pre_a);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) sstore_one(Bs + buf * NPL * PB, PB, TB, TRB, BN, tid + i * 256, qb[i], sc_b);
+        for (int i = 0; i < NB; ++i) sstore_one(Bs + buf * NPL * PB, PB, TB, TRB, BN, tid + i * 256, qb[i], sc_b, pre_b);
     };
     auto sstore = [&]() { sstore_from(ra, rb, 0); };
 
@@ -432,7 +439,8 @@ __global__ __launch_bounds__(WS ? 512 : 256, (NPL == 2 && !WS && !PROBE) ? 3 : 1
 }
 
 template <int BM, int BN, bool TA, bool TB>
-hipError_t launch_cfg(const GemmDesc& d, hipStream_t s) {
+hipError_t launch_cfg(const GemmDesc& din, hipStream_t s) {
+    GemmDesc d = din;
     dim3 grid(cdiv(d.N, BN), cdiv(d.M, BM), d.batch * d.ksplit);
     // transposing LDS reads for the reduction-major operands of 128-wide tiles: every 4-column quad must be loadable as one
     // aligned float4 and lie inside one segment
@@ -441,6 +449,24 @@ hipError_t launch_cfg(const GemmDesc& d, hipStream_t s) {
                       (op.seglen == 0 || (op.seglen % 4 == 0 && op.segstride % 4 == 0)));
     };
     constexpr bool CAN_TR = (TA || TB) && (!TA || BM == 128) && (!TB || BN == 128);
+    // Pre-split operand images: usable when this launch multiplies fp16 x 2 with the fixed scale and loads the operand in whole
+    // groups of four along its contiguous axis -- K-contiguous operands with K % 4 == 0 and no K segments shorter than a group, or
+    // reduction-major operands through the transposing-read image (which the code below then has to choose).
+    const bool tr_all = CAN_TR && g_gemm_tr && (g_gemm_tr == 1 || !(TA && TB)) && !(d.flags & GEMM_BF16) && quad_ok(d.A, TA, d.M) && quad_ok(d.B, TB, d.N);
+    const bool f16 = (d.flags & GEMM_F16X2) && !(d.flags & GEMM_BF16) && !d.diag;
+    auto pre_ok = [&](const Operand& op, bool T, const float* img, const float* amax) {
+        if (!img || !f16 || amax || (((size_t)img) & 15)) return false;
+        if (T) return tr_all;
+        return d.K % 4 == 0 && op.ld % 4 == 0 && (op.seglen == 0 || (op.seglen % 4 == 0 && op.segstride % 4 == 0));
+    };
+    if (pre_ok(d.A, TA, d.a_pre, d.amax_a)) {
+        d.A.p = d.a_pre;
+        d.flags |= GEMM_A_PRE;
+    }
+    if (pre_ok(d.B, TB, d.b_pre, d.amax_b)) {
+        d.B.p = d.b_pre;
+        d.flags |= GEMM_B_PRE;
+    }
     // Measured (tools/kbench.py gws, us 256-thread -> wave-specialised): a grid that leaves one workgroup per CU gains -- encoder
     // convolution 8192 x 512 x 2560 (256 tiles) 116 -> 104 -- because its staging waves are a second set of waves to hide latency
     // behind; grids of two and more workgroups per CU do not (projection 280 -> 276, input gradient 245 -> 254), and a

@@ -56,7 +56,8 @@ hipError_t copy_rows(const float* src, long s_ld, long s_bs, float* dst, long d_
 hipError_t collate(const float* mel_cat, const float* f0_cat, const float* emb_tab, const long* row0, const int* len,
                    const int* item, int B, int T, int C, int E, float* mel, float* f0, float* emb, hipStream_t s);
 // conv weight [Co][Ci][5] -> forward pack [Co][5][Cp] (zero-filled for ci >= Ci) and input-grad pack [Ci][5][Co] (taps flipped)
-hipError_t conv_pack(const float* w, int Co, int Ci, int Cp, float* wf, float* wb, hipStream_t s);
+// wf_img / wb_img (nullable): pre-split images of wf / wb (Cp % 4 == 0, Co % 4 == 0)
+hipError_t conv_pack(const float* w, int Co, int Ci, int Cp, float* wf, float* wb, float* wf_img, float* wb_img, hipStream_t s);
 // packed weight grad [Co][5][Cp] -> grad arena [Co][Ci][5] (overwrite)
 hipError_t conv_unpack_grad(const float* gp, int Co, int Ci, int Cp, float* g, hipStream_t s);
 hipError_t transpose2d(const float* in, int R, int C, float* out, hipStream_t s);   // out[c][r] = in[r][c]
@@ -69,6 +70,7 @@ struct PrepTask {
     const float* b;
     float* dst;
     long n;
+    float* img;           // nullable: the pre-split image of dst (GemmDesc::b_pre), written beside it; needs n % 4 == 0 and 16-byte alignment
 };
 struct PrepTable {
     PrepTask t[PREP_MAX];

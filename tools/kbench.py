@@ -196,7 +196,7 @@ def bench_gemm_ablate():
     shapes = [('proj   NT 8192x4096x1024', 8192, 4096, 1024, False, False, 1), ('dX  NT-tr 8192x1024x4096', 8192, 1024, 4096, False, True, 1),
               ('dW_ih  TN 2048x1024x8192 ks4', 2048, 1024, 8192, True, True, 4), ('conv   NT 8192x512x2560', 8192, 512, 2560, False, False, 1)]
     modes = [(0, 'full'), (4, 'every k-tile re-reads tile 0 (no memory latency)'), (128, 'no global loads'), (64, 'no split / LDS store'), (32, 'no barriers'),
-             (256, 'fragment reads all to one address'), (192, 'no split, no loads'), (224, 'no split, no loads, no barriers'), (8, 'plain tile order (no XCD / L2 grouping)')]
+             (256, 'fragment reads all to one address'), (512, 'B operand taken as pre-split (timing only)'), (1536, 'both operands taken as pre-split (timing only)'), (192, 'no split, no loads'), (224, 'no split, no loads, no barriers'), (8, 'plain tile order (no XCD / L2 grouping)')]
     for name, M, N, K, ta, tb, ks in shapes:
         A = torch.randn((K, M) if ta else (M, K), device=dev)
         Bm = torch.randn((K, N) if tb else (N, K), device=dev)
