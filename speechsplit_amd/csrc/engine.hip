@@ -33,7 +33,7 @@ int g_side_prio = 0;   // 1: create the side stream with the lowest priority (re
                        //    (35 ms vs 14.8 ms per step): the low-priority queue starves behind 768 tiny step launches.
 int g_branch_low = 0;      // experiment: the probed branch streams are created with the lowest priority (read at ss_bind); measured 5.78 vs 5.80 ms, off
 int g_trunk_indep = 1;     // Encoder_7 forward: content and pitch conv stacks run as two INDEPENDENT chains (they share only the resampling plans)
-int g_presplit = 1;        // weights (and, bit 1, the decoder's hidden states) reach the fp16 x 2 GEMMs as pre-split images: 1 weights, 3 both, 0 off
+int g_presplit = 3;        // weights (and, bit 1, the decoder's hidden states) reach the fp16 x 2 GEMMs as pre-split images: 1 weights, 3 both, 0 off
 int g_compact0 = 1;        // decoder layer 0: input projections, input gradient and W_ih gradient once per block of repeated input frames
 int g_batch_dirs = 1;      // BLSTM weight gradients: both directions of a layer in one launch per matrix (batch = 2) + one bias kernel:
                            // 1 = the encoder BLSTMs (36 -> 14 launches), 2 = the decoder too (measured: step +0.18 ms), 0 = never
@@ -107,6 +107,7 @@ struct LstmBlk {
     std::vector<LstmDir> pd;               // [L*2]
     std::vector<float*> gates, out, csave; // per layer
     float* bsum = nullptr;                 // [L][2][4H]
+    std::vector<float*> out_img;           // per layer: pre-split image of out (decoder-size blocks on the persistent kernels)
     std::vector<float*> wcat_img;          // per layer: pre-split image of wcat (decoder-size blocks only)
     std::vector<float*> wcat;              // per layer: [W_ih forward ; W_ih reverse] stacked, [8H][In] (input-gradient GEMM over both directions)
     std::vector<float*> wfrag;             // per layer: fragment-major W_hh (forward) / W_hh^T (backward), 2*4H*H floats
@@ -364,6 +365,9 @@ long ss_engine::carve(int B, int T, bool assign) {
             lb.out[l] = slab((name + ".out" + std::to_string(l)).c_str(), 2L * lb.H);
             lb.csave[l] = slab((name + ".c" + std::to_string(l)).c_str(), 2L * lb.H);
         }
+        lb.out_img.assign(lb.L, nullptr);
+        if (lb.big())
+            for (int l = 0; l < lb.L; ++l) lb.out_img[l] = slab(nullptr, 2L * lb.H);       // halo rows stay zero like those of out
         lb.bsum = (float*)take((long)lb.L * 2 * 4 * lb.H * 4);
         lb.wcat.assign(lb.L, nullptr);
         for (int l = 0; l < lb.L; ++l) lb.wcat[l] = (float*)take(8L * lb.H * lb.in_of(l) * 4);
@@ -878,6 +882,7 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
             } else {   // both directions in one GEMM against the stacked W_ih / summed biases of lstm_prep (N = 8H)
                 GemmDesc d{};
                 d.A = {xi.p + (r0 + HALO) * xi.ld, xi.ld, TP * xi.ld, 0, 0};
+                if (l > 0 && persist && (g_presplit & 2)) d.a_pre = lb.out_img[l - 1] + (r0 + HALO) * xi.ld;       // written by the layer below's recurrence
                 d.B = {lb.wcat[l], In, 0, 0, 0};
                 d.b_pre = (g_presplit & 1) ? lb.wcat_img[l] : nullptr;
                 d.C = lb.gates[l] + (r0 + HALO) * 8L * H;
@@ -906,7 +911,8 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
             }
             const int pi = prof_begin(e, SS_PROF_REC_FWD, s, 2.0 * 2 * B * T * 4.0 * H * H);
             HIPCHK(lstm_seq_fwd(lb.gates[l], e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.hf_l(l), lb.out[l], lb.csave[l],
-                                lb.sync_f(l), e->sticky, compact ? lb.xp0 : nullptr, compact ? lb.xf : 0, B, T, H, false, false, s));
+                                lb.sync_f(l), e->sticky, compact ? lb.xp0 : nullptr, compact ? lb.xf : 0, (g_presplit & 2) ? lb.out_img[l] : nullptr, B, T, H,
+                                false, false, s));
             prof_end(e, pi, s);
             if (pw) CHK(fork_join(e, e->side3, s));
             continue;
@@ -966,6 +972,8 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
     float* dG = lb.gates[l];
     const LstmDir &p0 = lb.pd[l * 2], &p1 = lb.pd[l * 2 + 1];
     const bool compact = l == 0 && lb.xf && xi.p == lb.xc;     // dW_ih from the block sums and one input row per block (K / xf)
+    // the hidden-state slabs of a decoder-size block on the persistent kernels also exist as pre-split images (written by the forward)
+    const bool img_ok = (g_presplit & 2) && lb.big() && g_persist && lstm_seq_supported(B, H) && !lb.out_img.empty() && lb.out_img[l];
     // Both directions in ONE launch each (batch = 2) when their parameters sit at one stride in the arena (PyTorch's order: they do).
     // dW_hh: h_prev is `out` one row earlier (forward) / later (reverse), so the forward direction reads dG one row later instead.
     if (!compact && (g_batch_dirs == 2 || (g_batch_dirs == 1 && !lb.big())) && p1.wih - p0.wih == p1.whh - p0.whh && p1.wih > p0.wih) {
@@ -1008,6 +1016,7 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
         GemmDesc a{};
         a.A = {compact ? lb.dgs + dir * 4L * H : dGd, 8L * H, 0, 0, 0};
         a.B = {xi.p, xi.ld, 0, 0, 0};
+        if (img_ok && l > 0) a.b_pre = lb.out_img[l - 1];
         a.C = e->G + pd.wih;
         a.ldc = In;
         a.M = 4 * H;
@@ -1022,6 +1031,7 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
         GemmDesc h{};
         h.A = {dir == 0 ? dGd + 8L * H : dGd, 8L * H, 0, 0, 0};
         h.B = {dir == 0 ? lb.out[l] : lb.out[l] + 2L * H + H, 2L * H, 0, 0, 0};
+        if (img_ok) h.b_pre = dir == 0 ? lb.out_img[l] : lb.out_img[l] + 2L * H + H;
         h.C = e->G + pd.whh;
         h.ldc = H;
         h.M = 4 * H;
@@ -2235,7 +2245,7 @@ int ss_op_lstm_fwd(float* gates, const float* whh_f, const float* whh_b, float* 
         float* hf = scratch + wn;
         if (g_persist && lstm_seq_supported(B, H) && wn * 4 >= lstm_seq_xbytes(B, H, false)) {
             // exchange buffer in the (unused) packed-weight area, counters behind it
-            HIPCHK(lstm_seq_fwd(gates, whh_f, whh_b, scratch, out, csave, (unsigned*)hf, nullptr, nullptr, 0, B, T, H, true, g_op_time_major != 0, s));
+            HIPCHK(lstm_seq_fwd(gates, whh_f, whh_b, scratch, out, csave, (unsigned*)hf, nullptr, nullptr, 0, nullptr, B, T, H, true, g_op_time_major != 0, s));
             return 0;
         }
         HIPCHK(lstm_pack_w(whh_f, whh_b, scratch, H, 0, s));

@@ -156,12 +156,13 @@ hipError_t lstm_step_bwd(float* gates, const float* wfragT, const float* gf_cur,
 constexpr int LSTM_SEQ_SYNC_WORDS = 2048;   // [0] abort, [1..) XCD masks per group, [64 + 32*group + member] completion flags
 bool lstm_seq_supported(int B, int H);
 long lstm_seq_xbytes(int B, int H, bool backward);
+// out_img (fwd, nullable): pre-split image of `out` (GemmDesc::a_pre / b_pre), same shape
 // xc / xf (fwd), dgs / xf (bwd), nullable: a layer whose input repeats in blocks of xf frames -- input projections given once per block
 // [B][T/xf][8H]; pre-activation gradients additionally written summed per block [B][T/xf][8H]
 // sticky (nullable): engine-wide word, host-visible, that a launch ORs 1 into when its bounded wait expires (never cleared by a step)
 hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, float* out, float* csave,
-                        unsigned* sync, unsigned* sticky, const float* xc, int xf, int B, int T, int H, bool zero_state, bool time_major,
-                        hipStream_t s);
+                        unsigned* sync, unsigned* sticky, const float* xc, int xf, float* out_img, int B, int T, int H, bool zero_state,
+                        bool time_major, hipStream_t s);
 // amax (nullable): device word that receives max |pre-activation gradient| written (atomic max of the float's bit pattern;
 // zero it first) -- the scale the fp16 x 2 GEMMs that consume the gradient slab need
 // gbias_f / gbias_b (nullable): [2][4H] gradient accumulators of (b_ih, b_hh) of the forward / reverse direction; the kernel

@@ -351,7 +351,9 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_fwd_kernel(float* __re
                                                                const float* __restrict__ whh_b, unsigned char* __restrict__ xb,
                                                                float* __restrict__ out, float* __restrict__ csave,
                                                                unsigned* __restrict__ sync, unsigned* __restrict__ sticky,
-                                                               const float* __restrict__ xc, int xf, int B, int T, int nbt, int prio) {
+                                                               const float* __restrict__ xc, int xf, float* __restrict__ out_img, int B, int T,
+                                                               int nbt, int prio) {
+    // out_img (nullable): the pre-split image of `out` for the GEMMs that consume it (common.h GemmDesc::a_pre), written beside it
     // xc (nullable): the input projections in COMPACT form [B][T / xf][8H] -- the layer's input repeats in blocks of xf frames (the
     // decoder's up-sampled codes, model.py:301-309), so they were computed once per block; `gates` is then only written
     constexpr int JT = H / 16, KC = H / 32, KS = H / NW / 32;       // KS k-steps of 32 per wave
@@ -457,6 +459,7 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_fwd_kernel(float* __re
                     float* dst = o < 4 ? gates + r * (8 * H) + dir * 4 * H + o * H + jt * 16 + 4 * q
                                        : (o == 4 ? csave : out) + r * (2 * H) + dir * H + jt * 16 + 4 * q;
                     *reinterpret_cast<f32x4*>(dst) = v;
+                    if (o == 5 && out_img) *reinterpret_cast<uint4*>(out_img + r * (2 * H) + dir * H + jt * 16 + 4 * q) = ss_split_group(v[0], v[1], v[2], v[3]);
                 }
             };
             for (int st = 0; st < T; ++st) {
@@ -975,8 +978,8 @@ long lstm_seq_xbytes(int B, int H, bool backward) {
 static int seq_prio_arg(bool time_major) { return (g_seq_prio & 0xFFFF) | ((g_seq_spin_log2 & 31) << 16) | (time_major ? 1 << 21 : 0) | ((g_seq_wlead & 31) << 22); }
 
 hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, float* out, float* csave,
-                        unsigned* sync, unsigned* sticky, const float* xc, int xf, int B, int T, int H, bool zero_state, bool time_major,
-                        hipStream_t s) {
+                        unsigned* sync, unsigned* sticky, const float* xc, int xf, float* out_img, int B, int T, int H, bool zero_state,
+                        bool time_major, hipStream_t s) {
     if (xc && (xf < 1 || T % xf)) return hipErrorInvalidValue;
     const int nbt = (B + 15) / 16;
     if (!lstm_seq_supported(B, H)) return hipErrorInvalidValue;
@@ -991,10 +994,10 @@ hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, vo
     // round-robin placement) 2.47 -> 2.03; groups that span XCDs, whose polls and write-through payload cross the fabric,
     // 3.10 -> 3.23 (B = 16) and 3.00 -> 3.47 (B = 48).  The backward gains either way (3.13 -> 2.98, 3.40 -> 2.49, 4.13 -> 3.25).
     const bool tag = g_seq_tag && (2 * nbt) % 8 == 0;
-    if (H == 512 && tag) hipLaunchKernelGGL((lstm_seq_fwd_kernel<512, 8, true>), dim3(2 * nbt * 32), dim3(640), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, xc, xf, B, T, nbt, pa);
-    else if (H == 512)         hipLaunchKernelGGL((lstm_seq_fwd_kernel<512, 8, false>), dim3(2 * nbt * 32), dim3(640), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, xc, xf, B, T, nbt, pa);
-    else if (tag)              hipLaunchKernelGGL((lstm_seq_fwd_kernel<256, 4, true>), dim3(2 * nbt * 16), dim3(384), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, xc, xf, B, T, nbt, pa);
-    else                       hipLaunchKernelGGL((lstm_seq_fwd_kernel<256, 4, false>), dim3(2 * nbt * 16), dim3(384), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, xc, xf, B, T, nbt, pa);
+    if (H == 512 && tag) hipLaunchKernelGGL((lstm_seq_fwd_kernel<512, 8, true>), dim3(2 * nbt * 32), dim3(640), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, xc, xf, out_img, B, T, nbt, pa);
+    else if (H == 512)         hipLaunchKernelGGL((lstm_seq_fwd_kernel<512, 8, false>), dim3(2 * nbt * 32), dim3(640), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, xc, xf, out_img, B, T, nbt, pa);
+    else if (tag)              hipLaunchKernelGGL((lstm_seq_fwd_kernel<256, 4, true>), dim3(2 * nbt * 16), dim3(384), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, xc, xf, out_img, B, T, nbt, pa);
+    else                       hipLaunchKernelGGL((lstm_seq_fwd_kernel<256, 4, false>), dim3(2 * nbt * 16), dim3(384), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, xc, xf, out_img, B, T, nbt, pa);
     return hipGetLastError();
 }
 
