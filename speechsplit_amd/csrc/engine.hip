@@ -33,7 +33,7 @@ int g_side_prio = 0;   // 1: create the side stream with the lowest priority (re
                        //    (35 ms vs 14.8 ms per step): the low-priority queue starves behind 768 tiny step launches.
 int g_branch_low = 0;      // experiment: the probed branch streams are created with the lowest priority (read at ss_bind); measured 5.78 vs 5.80 ms, off
 int g_trunk_indep = 1;     // Encoder_7 forward: content and pitch conv stacks run as two INDEPENDENT chains (they share only the resampling plans)
-int g_presplit = 3;        // weights (and, bit 1, the decoder's hidden states) reach the fp16 x 2 GEMMs as pre-split images: 1 weights, 3 both, 0 off
+int g_presplit = 7;        // weights (and, bit 1, the decoder's hidden states) reach the fp16 x 2 GEMMs as pre-split images: bit 0 weights, bit 1 the decoder's hidden states, bit 2 the trunk's resampled activations
 int g_compact0 = 1;        // decoder layer 0: input projections, input gradient and W_ih gradient once per block of repeated input frames
 int g_batch_dirs = 1;      // BLSTM weight gradients: both directions of a layer in one launch per matrix (batch = 2) + one bias kernel:
                            // 1 = the encoder BLSTMs (36 -> 14 launches), 2 = the decoder too (measured: step +0.18 ms), 0 = never
@@ -138,6 +138,7 @@ struct LstmBlk {
 struct Slab {   // view of a haloed slab: p points at slab row 0, first channel of interest
     float* p = nullptr;
     long ld = 0;
+    const float* img = nullptr;      // the slab's pre-split image at the same position, if its producer wrote one (GemmDesc::a_pre / b_pre)
 };
 
 }  // namespace
@@ -178,6 +179,8 @@ struct ss_engine {
     float *in_mel = nullptr, *in_f0 = nullptr, *org = nullptr, *emb = nullptr;
     int f0p = 0;                           // padded one-hot width (260)
     float *act = nullptr, *d_act = nullptr, *d_xf = nullptr, *xf[3] = {nullptr, nullptr, nullptr};
+    float* xf_img[3] = {nullptr, nullptr, nullptr};     // pre-split images of xf[0], xf[1] (training forward only: written by the gathers)
+    bool xf_img_valid = false;                          // the last forward wrote them
     float *act_t = nullptr, *d_act_t = nullptr;
     float *dec_in = nullptr, *d_dec_in = nullptr, *d_top = nullptr;
     float *d_o1 = nullptr, *d_o2 = nullptr, *d_ot = nullptr;
@@ -419,6 +422,7 @@ long ss_engine::carve(int B, int T, bool assign) {
         conv_ws(c1[i], "enc1.c1_" + std::to_string(i));
         conv_ws(c2[i], (kind == SS_GENERATOR_3 ? "enc1.c2_" : "enc3.c_") + std::to_string(i));
         xf[i] = slab(("enc.xf" + std::to_string(i)).c_str(), CE);
+        xf_img[i] = i < 2 ? slab(nullptr, CE) : nullptr;       // pre-split images of the resampled activations the next layer's convs read
     }
     act = slab("enc.act", CE);
     d_act = slab("enc.d_act", CE);
@@ -749,6 +753,7 @@ int conv_block_fwd(ss_engine* e, ConvBlk& cb, Slab x, Slab y, hipStream_t s) {
     const long TP = T + 2 * HALO;
     GemmDesc d{};
     d.A = {x.p, x.ld, TP * x.ld, cb.Cp, x.ld};
+    d.a_pre = x.img;
     d.B = {cb.wf, 5L * cb.Cp, 0, 0, 0};
     d.b_pre = (g_presplit & 1) ? cb.wf_img : nullptr;
     d.C = cb.cout + HALO * cb.Co;
@@ -779,6 +784,7 @@ int conv_block_bwd(ss_engine* e, ConvBlk& cb, Slab dy, Slab x, Slab dx, hipStrea
     GemmDesc d{};
     d.A = {dy.p + 2 * dy.ld, dy.ld, 0, 0, 0};
     d.B = {x.p, x.ld, 0, cb.Cp, x.ld};
+    d.b_pre = x.img;
     d.C = cb.gp;
     d.ldc = 5L * cb.Cp;
     d.M = cb.Co;
@@ -1259,6 +1265,7 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
     // on the branch stream and the two stacks run as independent chains on `s` and `b1` -- conv, GroupNorm, gather of their OWN columns --
     // down to their BLSTMs, instead of meeting before every gather.
     const bool indep = g3 && par && g_conv_par && g_trunk_indep && !g_graph;
+    e->xf_img_valid = indep && training && (g_presplit & 4) && e->xf_img[0];
     hipEvent_t plans = nullptr;
     if (indep && training) {
         for (int i = 0; i < 3; ++i)
@@ -1318,8 +1325,9 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
             if (!prio_fwd) CHK(branch_work());
         }
         if (indep) {
-            Slab x1 = i == 0 ? Slab{e->in_mel, e->hp.dim_freq} : Slab{e->xf[i - 1], CE};
-            Slab x2 = i == 0 ? Slab{e->in_f0, e->f0p} : Slab{e->xf[i - 1] + off2, CE};
+            const float* im = (training && (g_presplit & 4) && i > 0) ? e->xf_img[i - 1] : nullptr;
+            Slab x1 = i == 0 ? Slab{e->in_mel, e->hp.dim_freq} : Slab{e->xf[i - 1], CE, im};
+            Slab x2 = i == 0 ? Slab{e->in_f0, e->f0p} : Slab{e->xf[i - 1] + off2, CE, im ? im + off2 : nullptr};
             CHK(conv_block_fwd(e, e->c2[i], x2, Slab{y + off2, CE}, b1));
             CHK(conv_block_fwd(e, e->c1[i], x1, Slab{y, CE}, s));
             if (training) {
@@ -1328,8 +1336,10 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
                     HIPCHK(hipStreamWaitEvent(b1, plans, 0));
                     HIPCHK(hipStreamWaitEvent(s, plans, 0));
                 }
-                HIPCHK(interp_gather(pl, e->act + HALO * CE + off2, CE, TP * CE, e->xf[i] + HALO * CE + off2, CE, TP * CE, CE - off2, B, b1));
-                HIPCHK(interp_gather(pl, e->act + HALO * CE, CE, TP * CE, e->xf[i] + HALO * CE, CE, TP * CE, off2, B, s));
+                float* gi = ((g_presplit & 4) && e->xf_img[i]) ? e->xf_img[i] + HALO * CE : nullptr;
+                HIPCHK(interp_gather(pl, e->act + HALO * CE + off2, CE, TP * CE, e->xf[i] + HALO * CE + off2, CE, TP * CE, CE - off2, B, b1,
+                                     gi ? gi + off2 : nullptr));
+                HIPCHK(interp_gather(pl, e->act + HALO * CE, CE, TP * CE, e->xf[i] + HALO * CE, CE, TP * CE, off2, B, s, gi));
             }
             continue;
         }
@@ -1553,11 +1563,13 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
         // input gradients of layer i become d_xf (the gradient of xf[i-1]); dy is consumed before it is overwritten
         // only when dy != d_xf, so in eval mode the input gradient goes through d_act instead.
         float* dxbuf = training ? e->d_xf : e->d_act;
+        // the resampled activations also exist as pre-split images when the forward's gathers wrote them (training, independent trunk chains)
+        const float* bim = (training && e->xf_img_valid && i > 0) ? e->xf_img[i - 1] : nullptr;
         if (g3) {
-            Slab x1 = i == 0 ? Slab{e->in_mel, h.dim_freq} : Slab{e->xf[i - 1], CE};
+            Slab x1 = i == 0 ? Slab{e->in_mel, h.dim_freq} : Slab{e->xf[i - 1], CE, bim};
             CHK(conv_block_bwd(e, e->c1[i], Slab{dy, CE}, x1, i > 0 ? Slab{dxbuf, CE} : Slab{nullptr, 0}, s));
         }
-        Slab x2 = i == 0 ? Slab{e->in_f0, e->f0p} : Slab{e->xf[i - 1] + off2, CE};
+        Slab x2 = i == 0 ? Slab{e->in_f0, e->f0p} : Slab{e->xf[i - 1] + off2, CE, bim ? bim + off2 : nullptr};
         CHK(conv_block_bwd(e, e->c2[i], Slab{dy + off2, CE}, x2, i > 0 ? Slab{dxbuf + off2, CE} : Slab{nullptr, 0}, s));
         if (!training && i > 0) {
             // eval mode has no resampling between layers: the next (lower) layer reads its output gradient from d_xf
@@ -2199,7 +2211,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "prewarm" && value >= 0 && value <= 3) g_prewarm = value;
     else if (k == "batch_dirs" && value >= 0 && value <= 2) g_batch_dirs = value;
     else if (k == "compact0" && (value == 0 || value == 1)) g_compact0 = value;
-    else if (k == "presplit" && value >= 0 && value <= 3) g_presplit = value;
+    else if (k == "presplit" && value >= 0 && value <= 7) g_presplit = value;
     else if (k == "trunk_indep" && (value == 0 || value == 1)) g_trunk_indep = value;
     else if (k == "branch_low" && (value == 0 || value == 1)) g_branch_low = value;
     else if (k == "gemm_ws" && value >= 0 && value <= 2) g_gemm_ws = value;

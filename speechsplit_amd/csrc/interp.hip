@@ -71,11 +71,15 @@ __global__ __launch_bounds__(64) void interp_plan_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void interp_gather_kernel(const float* __restrict__ x, long x_ld, long x_bs,
                                                             float* __restrict__ y, long y_ld, long y_bs, int C, int P,
                                                             const int* __restrict__ i0, const float* __restrict__ lam,
-                                                            const int* __restrict__ nrows) {
+                                                            const int* __restrict__ nrows, float* __restrict__ y_img) {
+    // y_img (nullable, launcher: only with C % 4 == 0 and 16-byte aligned rows): the pre-split image of y for the GEMMs that read it
     const int r = blockIdx.x, b = blockIdx.y;
     float* yr = y + b * y_bs + r * y_ld;
+    float* yi = y_img ? y_img + b * y_bs + r * y_ld : nullptr;
     if (r >= nrows[b]) {
         for (int c = threadIdx.x; c < C; c += blockDim.x) yr[c] = 0.f;
+        if (yi)
+            for (int c = threadIdx.x; c < C; c += blockDim.x) yi[c] = 0.f;
         return;
     }
     const int i = i0[(long)b * P + r];
@@ -83,6 +87,19 @@ __global__ __launch_bounds__(256) void interp_gather_kernel(const float* __restr
     const float ol = __fsub_rn(1.0f, l);
     const float* xa = x + b * x_bs + (long)i * x_ld;
     const float* xb = xa + x_ld;
+    if (yi) {
+        for (int c = 4 * threadIdx.x; c < C; c += 4 * blockDim.x) {
+            const float4 a = *reinterpret_cast<const float4*>(xa + c), bb = *reinterpret_cast<const float4*>(xb + c);
+            float4 v;
+            v.x = __fadd_rn(__fmul_rn(ol, a.x), __fmul_rn(l, bb.x));      // model.py:430, the same three roundings as below
+            v.y = __fadd_rn(__fmul_rn(ol, a.y), __fmul_rn(l, bb.y));
+            v.z = __fadd_rn(__fmul_rn(ol, a.z), __fmul_rn(l, bb.z));
+            v.w = __fadd_rn(__fmul_rn(ol, a.w), __fmul_rn(l, bb.w));
+            *reinterpret_cast<float4*>(yr + c) = v;
+            *reinterpret_cast<uint4*>(yi + c) = ss_split_group(v.x, v.y, v.z, v.w);
+        }
+        return;
+    }
     for (int c = threadIdx.x; c < C; c += blockDim.x)
         yr[c] = __fadd_rn(__fmul_rn(ol, xa[c]), __fmul_rn(l, xb[c]));      // model.py:430
 }
@@ -157,10 +174,11 @@ hipError_t interp_plan(const InterpPlan& p, const float* scales, const int* len_
 }
 
 hipError_t interp_gather(const InterpPlan& p, const float* x, long x_ld, long x_bs, float* y, long y_ld, long y_bs, int C,
-                         int B, hipStream_t s) {
-    const int threads = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
+                         int B, hipStream_t s, float* y_img) {
+    if (y_img && (C % 4 || x_ld % 4 || y_ld % 4 || x_bs % 4 || y_bs % 4 || (((size_t)x | (size_t)y | (size_t)y_img) & 15))) y_img = nullptr;
+    const int threads = y_img ? (C >= 512 ? 128 : 64) : (C >= 256 ? 256 : (C >= 128 ? 128 : 64));
     hipLaunchKernelGGL(interp_gather_kernel, dim3(p.P, B), dim3(threads), 0, s, x, x_ld, x_bs, y, y_ld, y_bs, C, p.P, p.i0,
-                       p.lam, p.nrows);
+                       p.lam, p.nrows, y_img);
     return hipGetLastError();
 }
 

@@ -25,8 +25,9 @@ struct InterpPlan {
 };
 hipError_t interp_plan(const InterpPlan& p, const float* scales, const int* len_seg, const int* len_seq,
                        int len_seq_const, int B, hipStream_t s);
+// y_img (nullable): also write the pre-split image of y (GemmDesc::a_pre), same geometry as y
 hipError_t interp_gather(const InterpPlan& p, const float* x, long x_ld, long x_bs, float* y, long y_ld, long y_bs, int C,
-                         int B, hipStream_t s);
+                         int B, hipStream_t s, float* y_img = nullptr);
 hipError_t interp_quant(const InterpPlan& p, const float* mel, const float* f0, int CM, float* ymel, long ym_ld, long ym_bs,
                         float* yoh, long yo_ld, long yo_bs, int NOH, int* qidx, int B, hipStream_t s);
 hipError_t interp_scatter(const InterpPlan& p, const float* dy, long dy_ld, long dy_bs, float* dx, long dx_ld, long dx_bs,
