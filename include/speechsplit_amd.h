@@ -223,7 +223,9 @@ int ss_debug_relu_mask(ss_engine* e, const char* block, float* mask_dev, void* s
  * tests exercise the abort path), "deterministic" 0|1, "seq_tag" 0|1 (forward persistent recurrence: step tag in the hand-off
  * payload where every group sits on one XCD | always the flag line), "seq_wlead" 0..31 (backward persistent recurrence: steps
  * between a warm-up read and the operand request it serves, 0 = the kernel's default), "gemm_ws" 0|1|2 (wave-specialised form of
- * the 128 x 128 fp16 x 2 GEMM: never | where it measured faster in isolation | always), "prewarm" 0..3 (streaming pre-read of a decoder layer's operand slabs on a side stream beside its
+ * the 128 x 128 fp16 x 2 GEMM: never | where it measured faster in isolation | always), "presplit" 0..7 (pre-split operand images for the fp16 x 2 GEMMs: bit 0 weights, bit 1 decoder hidden states, bit 2 trunk
+ * activations), "compact0" 0|1 (decoder layer 0 on one row per block of repeated input frames), "trunk_indep" 0|1, "batch_dirs" 0..2,
+ * "prewarm" 0..3 (streaming pre-read of a decoder layer's operand slabs on a side stream beside its
  * persistent recurrence: bit 1 forward, bit 0 backward), "op_time_major" 0|1 (ss_op_lstm_fwd / _bwd
  * read their slabs as [T+4,B,C]; persistent kernels only -- a layout experiment).  The timing experiments that produce WRONG results ("lstm_mode",
  * "gemm_diag", "seq_prio" > 1) are compiled out of this library; `make -C speechsplit_amd/csrc diag` builds

@@ -1404,6 +1404,8 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
     const long HD = 2L * e->ld.H;
     GemmDesc d{};
     d.A = {e->ld.out[e->ld.L - 1] + HALO * HD, HD, TP * HD, 0, 0};
+    if ((g_presplit & 2) && e->ld.big() && g_persist && lstm_seq_supported(B, e->ld.H) && e->ld.out_img[e->ld.L - 1])
+        d.a_pre = e->ld.out_img[e->ld.L - 1] + HALO * HD;
     d.B = {e->P + e->head_w, HD, 0, 0, 0};
     d.C = e->out_slab + HALO * e->head_out;
     d.ldc = e->head_out;
