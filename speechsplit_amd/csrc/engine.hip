@@ -107,6 +107,7 @@ struct LstmBlk {
     std::vector<LstmDir> pd;               // [L*2]
     std::vector<float*> gates, out, csave; // per layer
     float* bsum = nullptr;                 // [L][2][4H]
+    bool out_img_valid = false;            // the last forward wrote out_img
     std::vector<float*> out_img;           // per layer: pre-split image of out (decoder-size blocks on the persistent kernels)
     std::vector<float*> wcat_img;          // per layer: pre-split image of wcat (decoder-size blocks only)
     std::vector<float*> wcat;              // per layer: [W_ih forward ; W_ih reverse] stacked, [8H][In] (input-gradient GEMM over both directions)
@@ -865,6 +866,8 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
     const int nch = persist ? 1 : make_chains(e, B, s, ch);
     if (persist) ch[0] = {0, B, s};
     if (nch == 2) CHK(fork_join(e, s, ch[1].st));
+    // only fp16 x 2 GEMMs read the hidden states' pre-split images, and only the persistent recurrences write them
+    lb.out_img_valid = persist && (g_presplit & 2) && e->precision == SS_PRECISION_F32 && g_fwd_f16x2 && !lb.out_img.empty() && lb.out_img[0];
     for (int l = 0; l < lb.L; ++l) {
         const int In = lb.in_of(l);
         Slab xi = l == 0 ? x : Slab{lb.out[l - 1], 2L * H};
@@ -888,7 +891,7 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
             } else {   // both directions in one GEMM against the stacked W_ih / summed biases of lstm_prep (N = 8H)
                 GemmDesc d{};
                 d.A = {xi.p + (r0 + HALO) * xi.ld, xi.ld, TP * xi.ld, 0, 0};
-                if (l > 0 && persist && (g_presplit & 2)) d.a_pre = lb.out_img[l - 1] + (r0 + HALO) * xi.ld;       // written by the layer below's recurrence
+                if (l > 0 && lb.out_img_valid) d.a_pre = lb.out_img[l - 1] + (r0 + HALO) * xi.ld;       // written by the layer below's recurrence
                 d.B = {lb.wcat[l], In, 0, 0, 0};
                 d.b_pre = (g_presplit & 1) ? lb.wcat_img[l] : nullptr;
                 d.C = lb.gates[l] + (r0 + HALO) * 8L * H;
@@ -917,7 +920,7 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
             }
             const int pi = prof_begin(e, SS_PROF_REC_FWD, s, 2.0 * 2 * B * T * 4.0 * H * H);
             HIPCHK(lstm_seq_fwd(lb.gates[l], e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.hf_l(l), lb.out[l], lb.csave[l],
-                                lb.sync_f(l), e->sticky, compact ? lb.xp0 : nullptr, compact ? lb.xf : 0, (g_presplit & 2) ? lb.out_img[l] : nullptr, B, T, H,
+                                lb.sync_f(l), e->sticky, compact ? lb.xp0 : nullptr, compact ? lb.xf : 0, lb.out_img_valid ? lb.out_img[l] : nullptr, B, T, H,
                                 false, false, s));
             prof_end(e, pi, s);
             if (pw) CHK(fork_join(e, e->side3, s));
@@ -979,7 +982,7 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
     const LstmDir &p0 = lb.pd[l * 2], &p1 = lb.pd[l * 2 + 1];
     const bool compact = l == 0 && lb.xf && xi.p == lb.xc;     // dW_ih from the block sums and one input row per block (K / xf)
     // the hidden-state slabs of a decoder-size block on the persistent kernels also exist as pre-split images (written by the forward)
-    const bool img_ok = (g_presplit & 2) && lb.big() && g_persist && lstm_seq_supported(B, H) && !lb.out_img.empty() && lb.out_img[l];
+    const bool img_ok = lb.out_img_valid && lb.out_img[l];
     // Both directions in ONE launch each (batch = 2) when their parameters sit at one stride in the arena (PyTorch's order: they do).
     // dW_hh: h_prev is `out` one row earlier (forward) / later (reverse), so the forward direction reads dG one row later instead.
     if (!compact && (g_batch_dirs == 2 || (g_batch_dirs == 1 && !lb.big())) && p1.wih - p0.wih == p1.whh - p0.whh && p1.wih > p0.wih) {
@@ -1265,7 +1268,7 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
     // on the branch stream and the two stacks run as independent chains on `s` and `b1` -- conv, GroupNorm, gather of their OWN columns --
     // down to their BLSTMs, instead of meeting before every gather.
     const bool indep = g3 && par && g_conv_par && g_trunk_indep && !g_graph;
-    e->xf_img_valid = indep && training && (g_presplit & 4) && e->xf_img[0];
+    e->xf_img_valid = indep && training && (g_presplit & 4) && e->xf_img[0] && e->precision == SS_PRECISION_F32 && g_fwd_f16x2;     // only fp16 x 2 GEMMs read images
     hipEvent_t plans = nullptr;
     if (indep && training) {
         for (int i = 0; i < 3; ++i)
@@ -1325,7 +1328,7 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
             if (!prio_fwd) CHK(branch_work());
         }
         if (indep) {
-            const float* im = (training && (g_presplit & 4) && i > 0) ? e->xf_img[i - 1] : nullptr;
+            const float* im = (e->xf_img_valid && i > 0) ? e->xf_img[i - 1] : nullptr;
             Slab x1 = i == 0 ? Slab{e->in_mel, e->hp.dim_freq} : Slab{e->xf[i - 1], CE, im};
             Slab x2 = i == 0 ? Slab{e->in_f0, e->f0p} : Slab{e->xf[i - 1] + off2, CE, im ? im + off2 : nullptr};
             CHK(conv_block_fwd(e, e->c2[i], x2, Slab{y + off2, CE}, b1));
@@ -1336,7 +1339,7 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
                     HIPCHK(hipStreamWaitEvent(b1, plans, 0));
                     HIPCHK(hipStreamWaitEvent(s, plans, 0));
                 }
-                float* gi = ((g_presplit & 4) && e->xf_img[i]) ? e->xf_img[i] + HALO * CE : nullptr;
+                float* gi = (e->xf_img_valid && e->xf_img[i]) ? e->xf_img[i] + HALO * CE : nullptr;
                 HIPCHK(interp_gather(pl, e->act + HALO * CE + off2, CE, TP * CE, e->xf[i] + HALO * CE + off2, CE, TP * CE, CE - off2, B, b1,
                                      gi ? gi + off2 : nullptr));
                 HIPCHK(interp_gather(pl, e->act + HALO * CE, CE, TP * CE, e->xf[i] + HALO * CE, CE, TP * CE, off2, B, s, gi));
@@ -1404,7 +1407,7 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
     const long HD = 2L * e->ld.H;
     GemmDesc d{};
     d.A = {e->ld.out[e->ld.L - 1] + HALO * HD, HD, TP * HD, 0, 0};
-    if ((g_presplit & 2) && e->ld.big() && g_persist && lstm_seq_supported(B, e->ld.H) && e->ld.out_img[e->ld.L - 1])
+    if (e->ld.out_img_valid)
         d.a_pre = e->ld.out_img[e->ld.L - 1] + HALO * HD;
     d.B = {e->P + e->head_w, HD, 0, 0, 0};
     d.C = e->out_slab + HALO * e->head_out;
