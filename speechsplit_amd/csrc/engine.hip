@@ -533,9 +533,10 @@ int geometry(ss_engine* e, int B, int T, hipStream_t s) {
     return 0;
 }
 
+int g_dw_wgs = 384;        // workgroups a split-K weight-gradient launch aims at (round 2: 384 = 1.5 per CU measured best in the step, 5.38 vs 5.48 ms at 512; 256: 5.5, 768+: 5.7)
 int pick_ksplit(int M, int N, long K) {
     const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
-    long ks = 512 / (tiles > 0 ? tiles : 1);
+    long ks = g_dw_wgs / (tiles > 0 ? tiles : 1);
     if (ks > K / 256) ks = K / 256;
     if (ks > 32) ks = 32;
     if (ks < 1) ks = 1;
@@ -2217,6 +2218,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "batch_dirs" && value >= 0 && value <= 2) g_batch_dirs = value;
     else if (k == "compact0" && (value == 0 || value == 1)) g_compact0 = value;
     else if (k == "presplit" && value >= 0 && value <= 7) g_presplit = value;
+    else if (k == "dw_wgs" && value >= 64 && value <= 4096) g_dw_wgs = value;
     else if (k == "trunk_indep" && (value == 0 || value == 1)) g_trunk_indep = value;
     else if (k == "branch_low" && (value == 0 || value == 1)) g_branch_low = value;
     else if (k == "gemm_ws" && value >= 0 && value <= 2) g_gemm_ws = value;
