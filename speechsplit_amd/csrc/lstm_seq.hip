@@ -375,7 +375,12 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_fwd_kernel(float* __re
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const bool loader = w == NW, helper = w >= NW;         // wave NW + 1 stores
     const int ngroups = 2 * nbt;
-    const int grp = blockIdx.x % ngroups, jt = blockIdx.x / ngroups;
+    // Up to 8 groups take the first `ngroups` of EIGHT slots per member index: under the round-robin placement slot = XCD, so every group
+    // sits on an XCD of its own (one shared L2: ordinary stores, payload-carried tags) also when there are fewer groups than XCDs; the
+    // workgroups of the unused slots leave at once.  (Locality is still measured in round 0, never assumed.)
+    const int slots = ngroups <= 8 ? 8 : ngroups;
+    const int grp = blockIdx.x % slots, jt = blockIdx.x / slots;
+    if (grp >= ngroups) return;
     const int dir = grp / nbt, bt = grp % nbt;
     const int TP = T + 2 * HALO;
     const int li = lane & 15, lq = lane >> 4;
@@ -634,7 +639,12 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
     // one wave it waited for the stores it had just issued before it touched a two-step-old load.
     const bool loader = w == NW, helper = w >= NW;       // wave NW + 1 stores
     const int ngroups = 2 * nbt;
-    const int grp = blockIdx.x % ngroups, jt = blockIdx.x / ngroups;
+    // Up to 8 groups take the first `ngroups` of EIGHT slots per member index: under the round-robin placement slot = XCD, so every group
+    // sits on an XCD of its own (one shared L2: ordinary stores, payload-carried tags) also when there are fewer groups than XCDs; the
+    // workgroups of the unused slots leave at once.  (Locality is still measured in round 0, never assumed.)
+    const int slots = ngroups <= 8 ? 8 : ngroups;
+    const int grp = blockIdx.x % slots, jt = blockIdx.x / slots;
+    if (grp >= ngroups) return;
     const int dir = grp / nbt, bt = grp % nbt;
     const int TP = T + 2 * HALO;
     const int li = lane & 15, lq = lane >> 4;
@@ -975,6 +985,7 @@ long lstm_seq_xbytes(int B, int H, bool backward) {
     return backward ? 2 * (2 * nbt * JT * JT * 1024) : 2 * (2 * nbt * 2 * (H / 32) * 1024);
 }
 
+static int seq_slots(int nbt) { return 2 * nbt <= 8 ? 8 : 2 * nbt; }       // group slots per member index (see the kernels)
 static int seq_prio_arg(bool time_major) { return (g_seq_prio & 0xFFFF) | ((g_seq_spin_log2 & 31) << 16) | (time_major ? 1 << 21 : 0) | ((g_seq_wlead & 31) << 22); }
 
 hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, float* out, float* csave,
@@ -993,11 +1004,11 @@ hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, vo
     // Measured (tools/kbench.py seqtag, us per step flags -> tagged): groups that sit on one XCD each (B = 64: 8 groups under the
     // round-robin placement) 2.47 -> 2.03; groups that span XCDs, whose polls and write-through payload cross the fabric,
     // 3.10 -> 3.23 (B = 16) and 3.00 -> 3.47 (B = 48).  The backward gains either way (3.13 -> 2.98, 3.40 -> 2.49, 4.13 -> 3.25).
-    const bool tag = g_seq_tag && (2 * nbt) % 8 == 0;
-    if (H == 512 && tag) hipLaunchKernelGGL((lstm_seq_fwd_kernel<512, 8, true>), dim3(2 * nbt * 32), dim3(640), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, xc, xf, out_img, B, T, nbt, pa);
-    else if (H == 512)         hipLaunchKernelGGL((lstm_seq_fwd_kernel<512, 8, false>), dim3(2 * nbt * 32), dim3(640), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, xc, xf, out_img, B, T, nbt, pa);
-    else if (tag)              hipLaunchKernelGGL((lstm_seq_fwd_kernel<256, 4, true>), dim3(2 * nbt * 16), dim3(384), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, xc, xf, out_img, B, T, nbt, pa);
-    else                       hipLaunchKernelGGL((lstm_seq_fwd_kernel<256, 4, false>), dim3(2 * nbt * 16), dim3(384), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, xc, xf, out_img, B, T, nbt, pa);
+    const bool tag = g_seq_tag && (2 * nbt <= 8 || (2 * nbt) % 8 == 0);      // groups expected on one XCD each (seq_slots)
+    if (H == 512 && tag) hipLaunchKernelGGL((lstm_seq_fwd_kernel<512, 8, true>), dim3(seq_slots(nbt) * 32), dim3(640), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, xc, xf, out_img, B, T, nbt, pa);
+    else if (H == 512)         hipLaunchKernelGGL((lstm_seq_fwd_kernel<512, 8, false>), dim3(seq_slots(nbt) * 32), dim3(640), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, xc, xf, out_img, B, T, nbt, pa);
+    else if (tag)              hipLaunchKernelGGL((lstm_seq_fwd_kernel<256, 4, true>), dim3(seq_slots(nbt) * 16), dim3(384), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, xc, xf, out_img, B, T, nbt, pa);
+    else                       hipLaunchKernelGGL((lstm_seq_fwd_kernel<256, 4, false>), dim3(seq_slots(nbt) * 16), dim3(384), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, xc, xf, out_img, B, T, nbt, pa);
     return hipGetLastError();
 }
 
@@ -1014,7 +1025,7 @@ hipError_t lstm_seq_bwd(float* gates, const float* whh_f, const float* whh_b, vo
     }
     unsigned char* xb = static_cast<unsigned char*>(xbuf);
     unsigned* am = reinterpret_cast<unsigned*>(amax);
-    const dim3 grid(2 * nbt * (H / 16)), block(640);
+    const dim3 grid(seq_slots(nbt) * (H / 16)), block(640);
     const int pa = seq_prio_arg(time_major);
     if (H == 512) hipLaunchKernelGGL((lstm_seq_bwd_kernel<512, 8>), grid, block, 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, am, gbias_f, gbias_b, dgs, xf, B, T, nbt, pa);
     else          hipLaunchKernelGGL((lstm_seq_bwd_kernel<256, 8>), grid, block, 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, am, gbias_f, gbias_b, dgs, xf, B, T, nbt, pa);
