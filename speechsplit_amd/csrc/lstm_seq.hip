@@ -10,8 +10,8 @@
 // fragments and nobody re-splits.  Backward: every workgroup multiplies its OWN 64 gate units of da(t+1) (straight from
 // LDS) into a partial dh for all H hidden units and hands 16x16 fp32 tiles to their owners, who add up JT tiles
 // (see lstm_seq_bwd_kernel).  Either way there is no grid-wide barrier, only 2*ceil(B/16) independent groups of
-// JT = H/16 workgroups.  The 1-D block id is laid out so that a group is blockIdx % ngroups: with B = 64 that is
-// 8 groups = the 8 XCDs under the observed round-robin placement.
+// JT = H/16 workgroups.  The 1-D block id is laid out so that a group is one of eight slots, blockIdx % 8 (for up to 8 groups; unused
+// slots' workgroups exit at once): slot = XCD under the observed round-robin placement, so every group has an XCD and its L2 to itself.
 //
 // Hand-off, two forms (both placement-independent, both bounded):
 //   tagged payload (backward always; forward when every group sits on one XCD): every payload dword carries its step's tag in
