@@ -174,13 +174,19 @@ int ss_collate(const float* mel_cat_dev, const float* f0_cat_dev, const float* e
  * While it is non-zero the Adam kernel SKIPS the update on the device (parameters, moments and step counter untouched --
  * no host round trip is involved), every later ss_*_forward / ss_*_train_step / ss_adam_step returns an error without
  * enqueueing anything, and ss_check() keeps failing until ss_clear_abort().  ss_check synchronises `stream`;
- * ss_status() reads the word without synchronising. */
+ * ss_status() reads the word without synchronising.
+ * LOCKSTEP mode (data parallel; switched on by ss_comm_init with world > 1, or by ss_set_lockstep for ranks that exchange their
+ * gradients outside the engine): the entry points do NOT refuse -- the word is set asynchronously, ranks would notice it at different
+ * iterations and the survivors would wait in a collective for ever.  Every rank keeps enqueueing (the device-side skip protects the
+ * weights, the status slot carries the failure to every rank within the same step) and learns of it from ss_check(), which all
+ * ranks call at the same iteration; all of them then either stop or call ss_clear_abort() and go on together. */
 #define SS_STATUS_ABORT 1u
 #define SS_STATUS_REMOTE 2u
 #define SS_STATUS_RANGE 4u
 int ss_check(ss_engine* e, void* stream);
 unsigned ss_status(const ss_engine* e);
 int ss_clear_abort(ss_engine* e, void* stream);
+int ss_set_lockstep(ss_engine* e, int on);
 
 /* ---- test / profiling hooks ---- */
 /* C[M,N] = A . B^T style fp32 MFMA GEMM used by every contraction on the path (flags: 1 = A stored [K,M], 2 = B stored [K,N], 8 = bf16-rounded operands) */
@@ -197,13 +203,20 @@ int ss_op_lstm_fwd(float* gates_dev, const float* whh_f_dev, const float* whh_b_
 /* BPTT of the same: d_out [B,T+4,2H]; gates is replaced by the pre-activation gradients. */
 int ss_op_lstm_bwd(float* gates_dev, const float* whh_f_dev, const float* whh_b_dev, const float* d_out_dev,
                    const float* csave_dev, float* scratch_dev, long scratch_floats, int B, int T, int H, void* stream);
-/* The pre-split ("planes") GEMM: fp32 [rows][cols] -> two fp16 planes of the fp16 x 2 split (scale a power of two; transpose != 0:
- * planes [cols][ldp] with the source rows along the contiguous axis), zero-padded to a multiple of 32 along the contiguous axis;
- * and C[M,N] (+)= A . B^T over such planes (K % 32 == 0, lda / ldb in fp16 elements, multiples of 8), unscale = 1 / (sa * sb). */
-int ss_op_split_planes(const float* src_dev, long ld, int rows, int cols, int transpose, float scale, void* plane_h_dev, void* plane_l_dev,
-                       long ldp, void* stream);
-int ss_op_gemm_planes(const void* ah_dev, const void* al_dev, long lda, const void* bh_dev, const void* bl_dev, long ldb, float* c_dev,
-                      long ldc, const float* bias_dev, int M, int N, int K, int ksplit, float unscale, void* stream);
+/* The GEMM over operand images (speechsplit_amd/csrc/gemm_img.hip), the engine's default for every large contraction: an IMAGE has the
+ * geometry of its fp32 matrix (4 bytes per element) with every aligned group of 8 elements along the contiguous axis replaced by 16 bytes of
+ * hi pieces and 16 bytes of lo pieces of the fp16 x 2 split of scale * x (scale a power of two).
+ *   ss_op_split_image: fp32 [rows][cols] (row stride ld) -> image (row stride ldi; cols % 8 == 0).
+ *   ss_op_gemm_img:    C[M,N] (+)= sum_k A(m,k) B(n,k) (+ bias) over two images split with scale_a / scale_b.  flags: 1 = A stored [K,M],
+ *                      2 = B stored [K,N], 4 = accumulate into C.  a_seglen / a_segstride: segmented K axis of a K-contiguous A (k = seg *
+ *                      seglen + w lives at column seg * segstride + w: a k=5 convolution over a haloed slab), 0 = none.  ksplit > 1 needs
+ *                      part_dev (ksplit * M * N floats of scratch; partial slabs, added in a fixed order).  zeros_dev: >= 1 KB of zero bytes
+ *                      (needed when both operands are reduction-major and K % 32 != 0).  cfg: -1 = choose the tile, 0 = 256 x 256,
+ *                      1 = 128 x 128, 2 = 256 x 128. */
+int ss_op_split_image(const float* src_dev, long ld, long rows, int cols, float scale, float* img_dev, long ldi, void* stream);
+int ss_op_gemm_img(const float* a_img_dev, long lda, const float* b_img_dev, long ldb, float* c_dev, long ldc, const float* bias_dev, int M, int N,
+                   int K, int flags, int ksplit, int cfg, float scale_a, float scale_b, int a_seglen, long a_segstride, float* part_dev,
+                   const void* zeros_dev, void* stream);
 /* One relu(GroupNorm(ConvNorm(x))) block (model.py:61-67,76-77; 16 channels per group) through the engine's own block
  * routines, forward and -- when dy is given -- backward.  x [B,T,Ci], w [Co,Ci,5], bias/gamma/beta [Co], y/dy [B,T,Co],
  * dx [B,T,Ci] (nullable), gw [Co,Ci,5], gb/ggamma/gbeta [Co]; scratch of ss_op_conv_block_scratch() floats. */

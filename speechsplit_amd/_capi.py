@@ -59,11 +59,12 @@ SYMBOLS = {
     'ss_check': (_i, [_vp, _vp]),
     'ss_status': (C.c_uint, [_vp]),
     'ss_clear_abort': (_i, [_vp, _vp]),
+    'ss_set_lockstep': (_i, [_vp, _i]),
     'ss_op_gemm': (_i, [_fp, _l, _fp, _l, _fp, _l, _fp, _i, _i, _i, _i, _i, _vp]),
     'ss_op_lstm_fwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _l, _i, _i, _i, _vp]),
     'ss_op_lstm_bwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _l, _i, _i, _i, _vp]),
-    'ss_op_split_planes': (_i, [_fp, _l, _i, _i, _i, _f, _vp, _vp, _l, _vp]),
-    'ss_op_gemm_planes': (_i, [_vp, _vp, _l, _vp, _vp, _l, _fp, _l, _fp, _i, _i, _i, _i, _f, _vp]),
+    'ss_op_split_image': (_i, [_fp, _l, _l, _i, _f, _fp, _l, _vp]),
+    'ss_op_gemm_img': (_i, [_fp, _l, _fp, _l, _fp, _l, _fp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _l, _fp, _vp, _vp]),
     'ss_op_conv_block_scratch': (_l, [_i, _i, _i, _i]),
     'ss_op_conv_block': (_i, [_fp] * 13 + [_l, _i, _i, _i, _i, _vp]),
     'ss_debug_relu_mask': (_i, [_vp, C.c_char_p, _fp, _vp]),

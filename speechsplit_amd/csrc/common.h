@@ -48,40 +48,56 @@ struct GemmDesc {
     // scales the operand by the power of two that brings this maximum into [128, 256).  Null: the fixed scale for O(1) data.
     const float* amax_a;
     const float* amax_b;
-    // Optional pre-split images of an operand (GEMM_F16X2 with the FIXED scale only, i.e. amax_* null): the same matrix geometry (ld,
-    // strides, 4 bytes per element), but every aligned group of four elements along the contiguous axis holds the packed fp16 pieces
-    // (h0h1, h2h3, l0l1, l2l3) of 16 x the values instead of four floats -- written once by whoever produces the operand
-    // (split_image in elementwise.hip, the forward recurrence's storing wave).  The launcher uses an image when the kernel form it picks
-    // loads that operand in whole groups (K-contiguous, or the transposing-read image); otherwise it falls back to the fp32 operand.
+    // Optional IMAGES of an operand (format v2, see ImgGemmDesc below; GEMM_F16X2 only): the same matrix geometry (ld, strides, 4 bytes per
+    // element), every aligned group of eight elements along the contiguous axis replaced by its hi / lo fp16 pieces -- written once by whoever
+    // produces the operand (weight re-layouts, the forward recurrence's storing wave, the gathers, split_image for gradient slabs).  With both
+    // images present the engine runs the contraction on the image GEMM (gemm_img.hip); this kernel takes an image when the form it picks loads
+    // that operand in whole groups (K-contiguous, or the transposing-read image) and falls back to the fp32 operand otherwise.
     const float* a_pre;
     const float* b_pre;
+    // device words holding the power-of-two scale an image was split with (null: the fixed 16)
+    const float* a_pre_scale;
+    const float* b_pre_scale;
 };
 
 // C[b][m][n] (+)= sum_k A(m,k) * B(n,k) (+ bias[n]);  fp32 in, fp32 MFMA accumulate (exact fp32 fma chain)
 hipError_t launch_gemm(const GemmDesc& d, hipStream_t stream);
 
-// ---- gemm_planes.hip: the same contraction over operands that are ALREADY split into fp16 hi / lo planes, K-contiguous ----
-struct PlanesDesc {
-    const _Float16 *ah, *al, *bh, *bl;      // A planes [M][lda], B planes [N][ldb] (fp16 elements), K % 32 == 0
-    long lda, ldb, a_bs, b_bs;              // row / batch strides in fp16 elements (multiples of 8)
-    float* c;
-    long ldc, c_bs;
-    const float* bias;                      // per output column, nullable
-    int M, N, K, batch, ksplit, accumulate; // ksplit > 1: fp32 atomics into a zeroed / live C
-    float unscale;                          // 1 / (product of the FIXED scales the planes were split with)
-    const float *amax_a, *amax_b;           // nullable: device words with the measured maximum of an operand that was split with
-                                            // pow2_scale_of(maximum); the result is divided by those scales as well
-    int diag;                               // SS_DIAG builds only (timing ablations, wrong results)
-    int row_period, row_lo, row_hi;         // row_period > 0: store only rows with row % row_period in [row_lo, row_hi) (slab halos)
+// ---- gemm_img.hip: the contraction over operand IMAGES (format v2, below) -------------------------------------------------------
+// Image format v2: the geometry of the fp32 tensor (4 bytes per element, same row stride), but every aligned group of EIGHT
+// elements along the contiguous axis holds 16 bytes of hi pieces (fp16 of scale * x, elements 0..7) followed by 16 bytes of lo pieces
+// (fp16 of scale * x - hi).  16 bytes = one MFMA fragment of one piece; a 128-byte line = 32 elements with both pieces, so an LDS-DMA
+// of whole lines serves the K-contiguous use (k along the row) and the reduction-major use (k = row index) of the same image alike.
+struct ImgOperand {
+    const void* p;          // image; element (row, col) of the underlying matrix: see Operand (ld / bstride / segments in ELEMENTS)
+    long ld, bstride;
+    int seglen;             // K-contiguous use: k = seg * seglen + w -> + seg * segstride + w; reduction-major use: the same along the columns
+    long segstride;
 };
-hipError_t launch_gemm_planes(const PlanesDesc& d, hipStream_t s);
-// fp32 [rows][cols] (row stride ld) -> planes [rows][ldp], zero-filled up to the next multiple of 32 columns.  Scale:
-// pow2_scale_of(*amax) when amax is given (a device word), else fixed_scale.
-hipError_t split_planes(const float* src, long ld, int rows, int cols, const float* amax, float fixed_scale, void* ph, void* pl, long ldp,
-                        hipStream_t s);
-// transposing: -> planes [cols][ldp] with the source ROWS along the contiguous axis (zero-filled up to a multiple of 32 rows)
-hipError_t split_planes_t(const float* src, long ld, int rows, int cols, const float* amax, float fixed_scale, void* ph, void* pl, long ldp,
-                          hipStream_t s);
+struct ImgGemmDesc {
+    ImgOperand A, B;
+    float* C;
+    long ldc, cstride;
+    const float* bias;
+    int M, N, K, batch, ksplit;
+    int flags;                          // GEMM_TA / GEMM_TB / GEMM_ACCUM
+    int row_period, row_off, row_lo, row_hi;      // as GemmDesc (ksplit == 1 only)
+    // rm_T > 0 (K-contiguous A only): logical row m of A and of C is row (m / rm_T) * rm_TP + m % rm_T of the memory -- a contraction over
+    // the B * T real rows of haloed slabs [B][rm_TP = T + 4][.] with the halo rows skipped outright (no masked rows, no padding tiles)
+    int rm_T, rm_TP;
+    float* part;                        // ksplit > 1: batch * ksplit * M * N floats of scratch for the partial slabs
+    const float *scale_a, *scale_b;     // device words holding the scale an image was split with; null: the fixed 16
+    const void* zeros;                  // >= 1 KB of zero bytes (TA && TB with K % 32 != 0: the A rows past K)
+    int cfg;                            // -1: choose; 0: 256 x 256, 1: 128 x 128, 2: 256 x 128
+    int diag;                           // SS_DIAG builds only
+    int gm, gn, bh, bw;                 // filled by the launcher: tile grid and the 2-D block shape of the tile order
+};
+bool gemm_img_supported(const ImgGemmDesc& d);
+hipError_t launch_gemm_img(const ImgGemmDesc& d, hipStream_t s);
+// fp32 [rows][cols] -> image (cols % 8 == 0).  Scale: pow2_scale_of(*amax) when amax is given (device word), else fixed_scale; written to
+// *scale_out (nullable) for the GEMM's epilogue
+hipError_t split_image(const float* src, long ld, long rows, int cols, const float* amax, float fixed_scale, float* img, long ldi, float* scale_out,
+                       hipStream_t s);
 
 // phase probe of the bf16x3 kernel (timing experiments): 4 waves x {5 phases, k-tile count} tick sums; see gemm_bf16x3.hip
 hipError_t gemm_phase_probe(unsigned long long out[24], bool reset);
@@ -105,11 +121,33 @@ __device__ __forceinline__ float pow2_scale_of(float m) {
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
-// Four consecutive values -> their group of the pre-split operand image (GemmDesc::a_pre / b_pre): packed fp16 pieces of 16 x the
-// values, (h0 h1, h2 h3, l0 l1, l2 l3), h = fp16(16 v) to nearest, l = fp16(16 v - h) -- exactly what the GEMM's in-loop split produces
-// with its fixed scale.
+// Four consecutive values -> packed fp16 pieces of 16 x the values, (h0 h1, h2 h3, l0 l1, l2 l3), h = fp16(16 v) to nearest,
+// l = fp16(16 v - h) -- exactly what the GEMM's in-loop split produces with its fixed scale.  ss_store_group puts them into an image.
 __device__ __forceinline__ uint4 ss_split_group(float v0, float v1, float v2, float v3) {
     const float s = 16.0f;
+    uint4 r;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(r.x) : "v"(v0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(r.x) : "v"(v1), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(r.y) : "v"(v2), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(r.y) : "v"(v3), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r.z) : "v"(v0), "v"(s), "v"(r.x));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(r.z) : "v"(v1), "v"(s), "v"(r.x));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r.w) : "v"(v2), "v"(s), "v"(r.y));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(r.w) : "v"(v3), "v"(s), "v"(r.y));
+    return r;
+}
+// Store such a group into a v2 image: `at` is the address the four fp32 values have in a tensor of the image's geometry (image base 32-byte
+// aligned, row strides multiples of 8 elements): the hi pieces go to the first 16 bytes of the enclosing group of eight, the lo pieces to
+// the second, each at the half this group of four belongs to.
+__device__ __forceinline__ void ss_store_group(float* at, uint4 g) {
+    const size_t a = (size_t)at;
+    char* base = (char*)(a & ~(size_t)31);
+    const int half = (int)((a >> 4) & 1) * 8;
+    *reinterpret_cast<uint2*>(base + half) = make_uint2(g.x, g.y);
+    *reinterpret_cast<uint2*>(base + 16 + half) = make_uint2(g.z, g.w);
+}
+// the same with a caller-supplied power-of-two scale
+__device__ __forceinline__ uint4 ss_split_group_s(float v0, float v1, float v2, float v3, float s) {
     uint4 r;
     asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(r.x) : "v"(v0), "v"(s));
     asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(r.x) : "v"(v1), "v"(s));

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict_
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = cp + j < Ci ? w[((long)co * Ci + cp + j) * 5 + k] : 0.f;
             reinterpret_cast<float4*>(wf)[gi] = make_float4(v[0], v[1], v[2], v[3]);
-            if (wf_img) reinterpret_cast<uint4*>(wf_img)[gi] = ss_split_group(v[0], v[1], v[2], v[3]);
+            if (wf_img) ss_store_group(wf_img + 4 * gi, ss_split_group(v[0], v[1], v[2], v[3]));
         } else if (wb) {
             const long q = (gi - nf) * 4;
             const int co = (int)(q % Co);
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict_
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = w[((long)(co + j) * Ci + ci) * 5 + (4 - k)];
             reinterpret_cast<float4*>(wb)[gi - nf] = make_float4(v[0], v[1], v[2], v[3]);
-            if (wb_img) reinterpret_cast<uint4*>(wb_img)[gi - nf] = ss_split_group(v[0], v[1], v[2], v[3]);
+            if (wb_img) ss_store_group(wb_img + 4 * (gi - nf), ss_split_group(v[0], v[1], v[2], v[3]));
         }
     }
 }
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepTable tb) {
                 v.x += w.x, v.y += w.y, v.z += w.z, v.w += w.w;
             }
             d[i] = v;
-            if (t.img) reinterpret_cast<uint4*>(t.img)[i] = ss_split_group(v.x, v.y, v.z, v.w);
+            if (t.img) ss_store_group(t.img + 4 * i, ss_split_group(v.x, v.y, v.z, v.w));
         }
     } else {
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < t.n; i += stride) t.dst[i] = t.a[i] + (t.b ? t.b[i] : 0.f);

@@ -20,6 +20,7 @@ using namespace ss;
 
 namespace ss {
 extern int g_small_lds, g_gemm_tr, g_deterministic;
+extern int g_img_cfg;
 extern int g_lstm_nw, g_lstm_g, g_lstm_mode, g_gemm_bk, g_gemm_want, g_gemm_diag, g_seq_prio, g_gemm_mode, g_seq_spin_log2, g_seq_tag, g_seq_wlead, g_gemm_ws;
 int g_fwd_f16x2 = 1;   // 1: forward contractions (operands bounded by construction: mel, one-hot, GroupNorm/ReLU outputs, |h| < 1, weights)
                        //    use the fp16 x 2 split (3 MFMAs) instead of bf16 x 3 (6 MFMAs); gradients keep bf16 x 3 (their range is not bounded)
@@ -33,6 +34,12 @@ int g_side_prio = 0;   // 1: create the side stream with the lowest priority (re
                        //    (35 ms vs 14.8 ms per step): the low-priority queue starves behind 768 tiny step launches.
 int g_branch_low = 0;      // experiment: the probed branch streams are created with the lowest priority (read at ss_bind); measured 5.78 vs 5.80 ms, off
 int g_trunk_indep = 1;     // Encoder_7 forward: content and pitch conv stacks run as two INDEPENDENT chains (they share only the resampling plans)
+int g_img = 1;             // 1: contractions whose two operands exist as images run on the image GEMM (gemm_img.hip); 0: round 2's kernels only
+int g_img_mask = (1 << SS_PROF_DEC_PROJ) | (1 << SS_PROF_CONV_FWD) | (1 << SS_PROF_CONV_DX);     // ... per profile class (bit SS_PROF_*): which classes may take the image GEMM (A/B runs)
+int g_img_batch = 1;       // image GEMM: the decoder's weight gradients of both directions in one launch per matrix
+int g_img_dw_cfg = -1;     // experiment: tile configuration of the split-K (weight-gradient) image GEMMs (-1: the rule in try_img_gemm)
+int g_img_dw_wgs = 256;    // ... and the number of workgroups their split aims at
+int g_cur_klass = -1;      // profile class of the contraction being launched (set by the PGEMM macros)
 int g_presplit = 7;        // weights (and, bit 1, the decoder's hidden states) reach the fp16 x 2 GEMMs as pre-split images: bit 0 weights, bit 1 the decoder's hidden states, bit 2 the trunk's resampled activations
 int g_compact0 = 1;        // decoder layer 0: input projections, input gradient and W_ih gradient once per block of repeated input frames
 int g_batch_dirs = 1;      // BLSTM weight gradients: both directions of a layer in one launch per matrix (batch = 2) + one bias kernel:
@@ -96,6 +103,7 @@ struct ConvBlk {
     float *wf = nullptr, *wb = nullptr, *gp = nullptr, *cout = nullptr, *stats = nullptr, *part = nullptr;
     int amax_i = -1;                       // slot in ss_engine::amax
     bool need_dx = false;
+    bool img_ok() const { return Cp % 8 == 0 && Co % 8 == 0; }       // wf_img / wb_img are written (rows of whole image groups)
 };
 
 struct LstmDir {
@@ -133,6 +141,8 @@ struct LstmBlk {
     int xf = 0, xcols = 0;                 // xcols: leading input columns whose gradient is needed (0: all)
     float *xc = nullptr, *xp0 = nullptr, *dgs = nullptr, *d_xc = nullptr;
     bool big() const { return H > 32; }
+    // image of the stacked W_ih of layer l (written by lstm_prep when its rows are whole image groups)
+    const float* wimg(int l) const { return (!wcat_img.empty() && wcat_img[l] && in_of(l) % 8 == 0) ? wcat_img[l] : nullptr; }
     int in_of(int l) const { return l == 0 ? In : 2 * H; }
 };
 
@@ -148,6 +158,7 @@ struct ss_engine {
     int kind;
     ss_hparams hp;
     int maxB, maxT;
+    int bound_max_len_pad = 0;             // hp.max_len_pad as given to ss_create: what a step WITHOUT SS_STEP_BUCKET runs with
     int precision = SS_PRECISION_F32;
     std::vector<ParamInfo> params;
     long arena = 0;                        // floats per arena, INCLUDING the 4-float status slot at the end
@@ -155,6 +166,7 @@ struct ss_engine {
                                            // all-reduce sums it, so every rank's Adam kernel sees a non-zero value and skips
     void* comm = nullptr;                  // ncclComm_t of ss_comm_init (RCCL, dlopen'd)
     int comm_rank = 0, comm_world = 1;
+    bool lockstep = false;                 // data-parallel member: entry points never refuse on the status word (entry_check)
     unsigned* sticky = nullptr;            // engine status word in host-coherent pinned memory (kernels.h SS_STICKY_*): written by
                                            // kernels, read by the host without synchronising; cleared only by ss_clear_abort
 
@@ -178,7 +190,7 @@ struct ss_engine {
 
     // workspace slabs
     float *in_mel = nullptr, *in_f0 = nullptr, *org = nullptr, *emb = nullptr;
-    int f0p = 0;                           // padded one-hot width (260)
+    int f0p = 0;                           // padded one-hot width (264)
     float *act = nullptr, *d_act = nullptr, *d_xf = nullptr, *xf[3] = {nullptr, nullptr, nullptr};
     float* xf_img[3] = {nullptr, nullptr, nullptr};     // pre-split images of xf[0], xf[1] (training forward only: written by the gathers)
     bool xf_img_valid = false;                          // the last forward wrote them
@@ -187,6 +199,13 @@ struct ss_engine {
     float *d_o1 = nullptr, *d_o2 = nullptr, *d_ot = nullptr;
     float *out_slab = nullptr, *d_out_slab = nullptr;
     float* gp_all = nullptr;               // packed conv weight-gradient images (all blocks)
+    // gradient slabs as images for the image GEMM: written by split_image with the measured scale (gscale[i] beside amax[i])
+    float* dg_img[3] = {nullptr, nullptr, nullptr};       // decoder layers' pre-activation gradients [B, TP, 8H]
+    float *d_img = nullptr, *d_img_t = nullptr;           // conv-output gradients of the trunk [B, TP, CE] / Encoder_t [B, TP, dim_enc_2]
+    float* gscale = nullptr;               // [16]
+    void* zeros = nullptr;                 // 1 KB of zero bytes (image GEMM: reduction rows past K)
+    float* part = nullptr;                 // split-K partial slabs of the image GEMM: a bump allocator over part_cap floats, reset per step
+    long part_cap = 0, part_off = 0;
     float* amax = nullptr;                 // [16] max |gradient| of the slabs the fp16 x 2 gradient GEMMs read: decoder layers 0..2, then the 7 convs
     long gp_bytes = 0;
     float *loss_part = nullptr;
@@ -323,7 +342,7 @@ void build_table(ss_engine* e) {
     e->ld.amax0 = 0;                      // decoder layers: slots 0..2 of ss_engine::amax (the convs follow from 3)
     e->status_off = align4(tb.off);
     e->arena = e->status_off + 4;
-    e->f0p = (int)align4(h.dim_f0);
+    e->f0p = (int)((h.dim_f0 + 7) & ~7);      // a multiple of 8: the packed conv weights of convolutions_2[0] then have rows of whole image groups
     for (int i = 0; i < 3; ++i) {
         e->c1[i].need_dx = i > 0;
         e->c2[i].need_dx = i > 0;
@@ -427,6 +446,10 @@ long ss_engine::carve(int B, int T, bool assign) {
     }
     act = slab("enc.act", CE);
     d_act = slab("enc.d_act", CE);
+    d_img = slab(nullptr, CE);
+    d_img_t = slab(nullptr, hp.dim_enc_2);
+    gscale = (float*)take(16 * 4);
+    zeros = take(1024);
     d_xf = slab("enc.d_xf", CE);
     conv_ws(ct, "enc2.c");
     {   // packed weight-gradient images of every conv, contiguous so one memset per backward zeroes them all
@@ -450,6 +473,7 @@ long ss_engine::carve(int B, int T, bool assign) {
     lstm_ws(l2, kind == SS_GENERATOR_3 ? "enc1.lstm2" : "enc3.lstm");
     lstm_ws(lt, "enc2.lstm");
     lstm_ws(ld, "dec.lstm");
+    for (int l = 0; l < ld.L && l < 3; ++l) dg_img[l] = ld.big() ? slab(nullptr, 8L * ld.H) : nullptr;
     if (l1.L) d_o1 = slab("enc1.d_o1", 2L * l1.H);
     d_o2 = slab("enc.d_o2", 2L * l2.H);
     d_ot = slab("enc2.d_ot", 2L * lt.H);
@@ -543,13 +567,87 @@ int pick_ksplit(int M, int N, long K) {
     return (int)ks;
 }
 
+// Image GEMM (gemm_img.hip) for a contraction whose two operands exist as images.  Returns 1 when it was launched, 0 when the
+// contraction has to take round 2's kernels (no images, shape outside what the image kernel supports), < 0 on error.
+int try_img_gemm(ss_engine* e, const GemmDesc& d, hipStream_t st) {
+    if (!g_img || !(d.flags & GEMM_F16X2) || (d.flags & GEMM_BF16) || !d.a_pre || !d.b_pre) return 0;
+    if (g_cur_klass >= 0 && !((g_img_mask >> g_cur_klass) & 1)) return 0;
+    ImgGemmDesc g{};
+    g.A = {d.a_pre, d.A.ld, d.A.bstride, d.A.seglen, d.A.segstride};
+    g.B = {d.b_pre, d.B.ld, d.B.bstride, d.B.seglen, d.B.segstride};
+    g.C = d.C;
+    g.ldc = d.ldc;
+    g.cstride = d.cstride;
+    g.bias = d.bias;
+    g.M = d.M;
+    g.N = d.N;
+    g.K = d.K;
+    g.batch = d.batch;
+    g.flags = d.flags & (GEMM_TA | GEMM_TB | GEMM_ACCUM);
+    g.row_period = d.row_period;
+    g.row_off = d.row_off;
+    g.row_lo = d.row_lo;
+    g.row_hi = d.row_hi;
+    g.scale_a = d.a_pre_scale;
+    g.scale_b = d.b_pre_scale;
+    g.zeros = e->zeros;
+    g.cfg = -1;
+    g.ksplit = 1;
+    g.diag = g_gemm_diag;
+    // Per-utterance batches of T rows over haloed slabs (and their flatten_rows form) become ONE matrix over the B * T real rows: the
+    // kernel maps logical rows to slab rows, so the 256-row tiles neither end at every utterance nor compute halo rows
+    const int T = e->curT;
+    const long TP = T + 2 * HALO;
+    if (!(g.flags & GEMM_TA) && T >= 32 && g.B.bstride == 0) {
+        if (g.batch > 1 && g.M == T && !g.row_period && g.A.bstride == TP * g.A.ld && g.cstride == TP * g.ldc) {
+            g.M = g.batch * T;
+            g.batch = 1;
+            g.A.bstride = g.cstride = 0;
+            g.rm_T = T;
+            g.rm_TP = (int)TP;
+        } else if (g.batch == 1 && g.row_period == TP && g.row_off == HALO && g.row_lo == HALO && g.row_hi == HALO + T && (g.M + 2 * HALO) % TP == 0) {
+            g.M = (int)((g.M + 2 * HALO) / TP) * T;
+            g.row_period = 0;
+            g.rm_T = T;
+            g.rm_TP = (int)TP;
+        }
+    }
+    // tile and split: measured on the step's shapes (tools/img_bench.py) -- without split-K the largest tile that still gives every CU a
+    // workgroup; reductions that are much longer than the result is large (weight gradients, d.ksplit > 1 on entry: C is zeroed or
+    // live) are cut along K into partial slabs, on 256 x 128 tiles (128 x 128 for narrow results)
+    auto wgs = [&](int bm, int bn) { return (long)cdiv(g.M, bm) * cdiv(g.N, bn) * g.batch; };
+    if (d.ksplit > 1 && !g.row_period) {
+        g.cfg = (g.M >= 256 && g.N >= 128) ? 2 : 1;
+        if (g_img_dw_cfg >= 0) g.cfg = g_img_dw_cfg;
+        const long t = g.cfg == 2 ? wgs(256, 128) : (g.cfg == 0 ? wgs(256, 256) : wgs(128, 128));
+        long ks = (g_img_dw_wgs + t / 2) / (t > 0 ? t : 1);
+        if (ks > g.K / 512) ks = g.K / 512;
+        if (ks > 16) ks = 16;
+        if (ks < 1) ks = 1;
+        const long need = ks > 1 ? ks * (long)g.M * g.N * g.batch : 0;
+        if (need && g.N % 4 == 0 && e->part && e->part_off + need <= e->part_cap) {
+            g.ksplit = (int)ks;
+            g.part = e->part + e->part_off;
+            e->part_off += (need + 63) & ~63L;
+        }
+    } else {
+        g.cfg = wgs(256, 256) >= 256 ? 0 : (wgs(256, 128) >= 224 ? 2 : 1);
+    }
+    if (!gemm_img_supported(g)) return 0;
+    HIPCHK(launch_gemm_img(g, st));
+    return 1;
+}
+
 // every contraction of the engine honours its precision mode (ss_set_precision)
+int gemm_on(ss_engine* e, GemmDesc& d, hipStream_t st) {
+    if (e->precision == SS_PRECISION_BF16) d.flags |= GEMM_BF16;
+    const int r = try_img_gemm(e, d, st);
+    if (r < 0) return r;
+    if (r == 0) HIPCHK(launch_gemm(d, st));
+    return 0;
+}
 #define GEMM(d) GEMM_ON(d, s)
-#define GEMM_ON(d, st)                                  \
-    do {                                                \
-        if (e->precision == SS_PRECISION_BF16) (d).flags |= GEMM_BF16; \
-        HIPCHK(launch_gemm(d, st));                     \
-    } while (0)
+#define GEMM_ON(d, st) CHK(gemm_on(e, d, st))
 // forward contraction: both operands are O(1) by construction
 #define GEMM_FWD_ON(d, st)                              \
     do {                                                \
@@ -578,6 +676,13 @@ int sticky_check(ss_engine* e) {
                                       "results were discarded and the parameters left untouched; ss_clear_abort() to continue"
                                     : "another data-parallel rank reported an aborted step: the update was skipped on every rank; ss_clear_abort() to continue");
 }
+
+// What a step / forward / Adam entry point does about the status word.  One engine on its own refuses to enqueue (its caller learns
+// of the failure at once).  In LOCKSTEP mode (data parallel: ss_comm_init with world > 1, or ss_set_lockstep) it enqueues regardless:
+// the word is set asynchronously, so ranks would see it at DIFFERENT host iterations, one would return while the others have already
+// enqueued collectives that never get a partner.  The weights are safe either way (the Adam kernel skips on the device); the status is
+// reported by ss_check(), which every rank calls at the same iteration, and cleared there by every rank (ss_clear_abort).
+int entry_check(ss_engine* e) { return e->lockstep ? 0 : sticky_check(e); }
 
 // Scope of one C-ABI call: work goes to the engine's main stream, which first waits for everything the caller's stream holds;
 // on exit the caller's stream waits for the call's work, so the stream-ordered contract of the ABI is unchanged.
@@ -710,13 +815,17 @@ double gemm_flops(const GemmDesc& d) { return 2.0 * d.M * d.N * (double)d.K * (d
 #define PGEMM_ON(k, d, st)                                   \
     do {                                                     \
         const int _pi = prof_begin(e, k, st, gemm_flops(d)); \
+        g_cur_klass = k;                                     \
         GEMM_ON(d, st);                                      \
+        g_cur_klass = -1;                                    \
         prof_end(e, _pi, st);                                \
     } while (0)
 #define PGEMM_FWD_ON(k, d, st)                               \
     do {                                                     \
         const int _pi = prof_begin(e, k, st, gemm_flops(d)); \
+        g_cur_klass = k;                                     \
         GEMM_FWD_ON(d, st);                                  \
+        g_cur_klass = -1;                                    \
         prof_end(e, _pi, st);                                \
     } while (0)
 
@@ -740,13 +849,23 @@ void flatten_rows(GemmDesc& d, int B, int T) {
 
 // ---- convolution block -------------------------------------------------------------------------------------
 int conv_pack_all(ss_engine* e, ConvBlk& cb, hipStream_t s) {
-    HIPCHK(conv_pack(e->P + cb.w, cb.Co, cb.Ci, cb.Cp, cb.wf, cb.wb, cb.wf_img, cb.wb_img, s));
+    const bool img = cb.img_ok();
+    HIPCHK(conv_pack(e->P + cb.w, cb.Co, cb.Ci, cb.Cp, cb.wf, cb.wb, img ? cb.wf_img : nullptr, img ? cb.wb_img : nullptr, s));
     return 0;
 }
 
 int zero_conv_grads(ss_engine* e, hipStream_t s) {
     HIPCHK(hipMemsetAsync(e->gp_all, 0, e->gp_bytes, s));
     return 0;
+}
+
+// where the image of a conv-output gradient slab view goes (the trunk's views share d_img, Encoder_t's has d_img_t); null: no image
+float* grad_img_of(ss_engine* e, const float* p, long R) {
+    auto in = [&](const float* b, long cols) { return b && p >= b && p < b + R * cols; };
+    if (in(e->d_act, e->CE)) return e->d_img + (p - e->d_act);
+    if (in(e->d_xf, e->CE)) return e->d_img + (p - e->d_xf);
+    if (in(e->d_act_t, e->hp.dim_enc_2)) return e->d_img_t + (p - e->d_act_t);
+    return nullptr;
 }
 
 // y = relu(GN(conv5(x)))   x: slab view (ld), y: slab view
@@ -757,7 +876,7 @@ int conv_block_fwd(ss_engine* e, ConvBlk& cb, Slab x, Slab y, hipStream_t s) {
     d.A = {x.p, x.ld, TP * x.ld, cb.Cp, x.ld};
     d.a_pre = x.img;
     d.B = {cb.wf, 5L * cb.Cp, 0, 0, 0};
-    d.b_pre = (g_presplit & 1) ? cb.wf_img : nullptr;
+    d.b_pre = ((g_presplit & 1) && cb.img_ok()) ? cb.wf_img : nullptr;
     d.C = cb.cout + HALO * cb.Co;
     d.ldc = cb.Co;
     d.cstride = TP * cb.Co;
@@ -782,9 +901,24 @@ int conv_block_bwd(ss_engine* e, ConvBlk& cb, Slab dy, Slab x, Slab dx, hipStrea
     float* am = (g_bwd_f16x2 && cb.amax_i >= 0) ? e->amax + cb.amax_i : nullptr;
     HIPCHK(gn_relu_bwd(cb.cout, cb.Co, TP * cb.Co, dy.p, dy.ld, TP * dy.ld, e->P + cb.ga, e->P + cb.be, cb.stats,
                        e->G + cb.ga, e->G + cb.be, e->G + cb.b, am, cb.part, B, T, cb.Co, s));
+    // the conv-output gradient as an image for the image GEMM (scale: the power of two for the maximum gn_relu_bwd has just measured)
+    const float* dimg = nullptr;
+    const float* dsc = nullptr;
+    if (g_img && (g_img_mask & ((1 << SS_PROF_CONV_DW) | (1 << SS_PROF_CONV_DX))) && am && e->precision == SS_PRECISION_F32 && cb.Co % 8 == 0 && dy.ld % 8 == 0) {
+        float* im = grad_img_of(e, dy.p, R);
+        if (im) {
+            HIPCHK(split_image(dy.p, dy.ld, R, cb.Co, am, 0.f, im, dy.ld, e->gscale + cb.amax_i, s));
+            dimg = im;
+            dsc = e->gscale + cb.amax_i;
+        }
+    }
     // weight gradient: one reduction over every slab row (halo rows of dy are zero); cb.gp was zeroed by zero_conv_grads
     GemmDesc d{};
     d.A = {dy.p + 2 * dy.ld, dy.ld, 0, 0, 0};
+    if (dimg) {
+        d.a_pre = dimg + 2 * dy.ld;
+        d.a_pre_scale = dsc;
+    }
     d.B = {x.p, x.ld, 0, cb.Cp, x.ld};
     d.b_pre = x.img;
     d.C = cb.gp;
@@ -801,8 +935,12 @@ int conv_block_bwd(ss_engine* e, ConvBlk& cb, Slab dy, Slab x, Slab dx, hipStrea
     if (dx.p) {
         GemmDesc g{};
         g.A = {dy.p, dy.ld, TP * dy.ld, cb.Co, dy.ld};
+        if (dimg) {
+            g.a_pre = dimg;
+            g.a_pre_scale = dsc;
+        }
         g.B = {cb.wb, 5L * cb.Co, 0, 0, 0};
-        g.b_pre = (g_presplit & 1) ? cb.wb_img : nullptr;
+        g.b_pre = ((g_presplit & 1) && cb.img_ok()) ? cb.wb_img : nullptr;
         g.C = dx.p + HALO * dx.ld;
         g.ldc = dx.ld;
         g.cstride = TP * dx.ld;
@@ -848,7 +986,7 @@ int lstm_prep(ss_engine* e, LstmBlk& lb, PrepTable& tb, hipStream_t s) {
             const long n = 4L * H * lb.in_of(l);
             if (tb.n + 2 > PREP_MAX) return fail("lstm_prep: task table full");
             tb.t[tb.n++] = {e->P + pd.bih, e->P + pd.bhh, lb.bsum + ((long)l * 2 + dir) * 4 * H, 4L * H};       // summed biases
-            tb.t[tb.n++] = {e->P + pd.wih, nullptr, lb.wcat[l] + dir * n, n, lb.wcat_img[l] ? lb.wcat_img[l] + dir * n : nullptr};      // stacked W_ih (+ image)
+            tb.t[tb.n++] = {e->P + pd.wih, nullptr, lb.wcat[l] + dir * n, n, (lb.wcat_img[l] && lb.in_of(l) % 8 == 0) ? lb.wcat_img[l] + dir * n : nullptr};      // stacked W_ih (+ image: rows of whole groups of eight)
         }
         // fragment-major W_hh for the one-launch-per-step schedule (the persistent kernels read the parameters directly)
         if (lb.big() && !persist) HIPCHK(lstm_pack_w(e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.wfrag[l], H, 0, s));
@@ -879,7 +1017,7 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
                 GemmDesc d{};
                 d.A = {lb.xc, In, 0, 0, 0};
                 d.B = {lb.wcat[l], In, 0, 0, 0};
-                d.b_pre = (g_presplit & 1) ? lb.wcat_img[l] : nullptr;
+                d.b_pre = (g_presplit & 1) ? lb.wimg(l) : nullptr;
                 d.C = lb.xp0;
                 d.ldc = 8L * H;
                 d.bias = lb.bsum + (long)l * 8 * H;
@@ -894,7 +1032,7 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
                 d.A = {xi.p + (r0 + HALO) * xi.ld, xi.ld, TP * xi.ld, 0, 0};
                 if (l > 0 && lb.out_img_valid) d.a_pre = lb.out_img[l - 1] + (r0 + HALO) * xi.ld;       // written by the layer below's recurrence
                 d.B = {lb.wcat[l], In, 0, 0, 0};
-                d.b_pre = (g_presplit & 1) ? lb.wcat_img[l] : nullptr;
+                d.b_pre = (g_presplit & 1) ? lb.wimg(l) : nullptr;
                 d.C = lb.gates[l] + (r0 + HALO) * 8L * H;
                 d.ldc = 8L * H;
                 d.cstride = TP * 8L * H;
@@ -954,7 +1092,7 @@ int lstm_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
             GemmDesc d{};
             d.A = {xi.p + HALO * xi.ld, xi.ld, TP * xi.ld, 0, 0};
             d.B = {lb.wcat[l], In, 0, 0, 0};
-            d.b_pre = (g_presplit & 1) ? lb.wcat_img[l] : nullptr;
+            d.b_pre = (g_presplit & 1) ? lb.wimg(l) : nullptr;
             d.C = lb.gates[l] + HALO * 8L * H;
             d.ldc = 8L * H;
             d.cstride = TP * 8L * H;
@@ -984,9 +1122,20 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
     const bool compact = l == 0 && lb.xf && xi.p == lb.xc;     // dW_ih from the block sums and one input row per block (K / xf)
     // the hidden-state slabs of a decoder-size block on the persistent kernels also exist as pre-split images (written by the forward)
     const bool img_ok = lb.out_img_valid && lb.out_img[l];
+    // the decoder's pre-activation gradients as an image for the image GEMM (scale: the power of two for the maximum the recurrence measured)
+    const float* dimg = nullptr;
+    const float* dsc = nullptr;
+    if (g_img && ((g_img_mask >> SS_PROF_DEC_DW) & 1) && am && &lb == &e->ld && l < 3 && e->dg_img[l] && e->precision == SS_PRECISION_F32 && img_ok) {
+        HIPCHK(split_image(dG, 8L * H, R, 8 * H, am, 0.f, e->dg_img[l], 8L * H, e->gscale + lb.amax0 + l, ws));
+        dimg = e->dg_img[l];
+        dsc = e->gscale + lb.amax0 + l;
+    }
     // Both directions in ONE launch each (batch = 2) when their parameters sit at one stride in the arena (PyTorch's order: they do).
     // dW_hh: h_prev is `out` one row earlier (forward) / later (reverse), so the forward direction reads dG one row later instead.
-    if (!compact && (g_batch_dirs == 2 || (g_batch_dirs == 1 && !lb.big())) && p1.wih - p0.wih == p1.whh - p0.whh && p1.wih > p0.wih) {
+    // (With the image GEMM the decoder's launches are batched as well: 64 + 32 tile jobs per layer instead of 4 x (32 or 16) halve the
+    // split-K factor, i.e. the partial-slab traffic and the number of reduce passes.)
+    const bool img_batch = dimg && g_img_batch && ((g_img_mask >> SS_PROF_DEC_DW) & 1);
+    if ((!compact || img_batch) && (g_batch_dirs == 2 || (g_batch_dirs == 1 && !lb.big()) || img_batch) && p1.wih - p0.wih == p1.whh - p0.whh && p1.wih > p0.wih) {
         const long pstride = p1.wih - p0.wih;
         GemmDesc a{};
         a.A = {dG, 8L * H, 4L * H, 0, 0};
@@ -1001,10 +1150,20 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
         a.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM | (am ? GEMM_F16X2 : 0);
         a.amax_a = am;                              // gradient slab: measured scale; the layer input is O(1)
         a.ksplit = pick_ksplit(a.M, a.N, a.K);
-        PGEMM_ON(lb.big() ? SS_PROF_DEC_DW : SS_PROF_ENC_LSTM, a, ws);
+        if (dimg && l > 0) {
+            a.a_pre = dimg;
+            a.a_pre_scale = dsc;
+            a.b_pre = lb.out_img[l - 1];
+        }
+        if (!compact) PGEMM_ON(lb.big() ? SS_PROF_DEC_DW : SS_PROF_ENC_LSTM, a, ws);
         GemmDesc h{};
         h.A = {dG + 8L * H, 8L * H, 4L * H - 8L * H, 0, 0};                    // forward: rows 1 .., reverse: rows 0 .. of its own columns
         h.B = {lb.out[l], 2L * H, 2L * H + H, 0, 0};                           // forward: rows 0 .. of h_f, reverse: rows 1 .. of h_b
+        if (dimg) {
+            h.a_pre = dimg + 8L * H;
+            h.a_pre_scale = dsc;
+            h.b_pre = lb.out_img[l];
+        }
         h.C = e->G + p0.whh;
         h.ldc = H;
         h.cstride = pstride;
@@ -1017,6 +1176,24 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
         h.ksplit = pick_ksplit(h.M, h.N, h.K);
         PGEMM_ON(lb.big() ? SS_PROF_DEC_DW : SS_PROF_ENC_LSTM, h, ws);
         if (!bias_done) HIPCHK(colsum_bias(dG, 8L * H, (int)R, 4 * H, e->G + p0.bih, e->G + p0.bhh, e->G + p1.bih, e->G + p1.bhh, ws));
+        if (!compact) return 0;
+        // compact layer 0: dW_hh went out batched above, dW_ih comes from the block sums below, per direction
+        for (int dir = 0; dir < 2; ++dir) {
+            const LstmDir& pd = lb.pd[l * 2 + dir];
+            GemmDesc c{};
+            c.A = {lb.dgs + dir * 4L * H, 8L * H, 0, 0, 0};
+            c.B = {xi.p, xi.ld, 0, 0, 0};
+            c.C = e->G + pd.wih;
+            c.ldc = In;
+            c.M = 4 * H;
+            c.N = In;
+            c.K = B * (T / lb.xf);
+            c.batch = 1;
+            c.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM | (am ? GEMM_F16X2 : 0);
+            c.amax_a = am;
+            c.ksplit = pick_ksplit(c.M, c.N, c.K);
+            PGEMM_ON(SS_PROF_DEC_DW, c, ws);
+        }
         return 0;
     }
     for (int dir = 0; dir < 2; ++dir) {
@@ -1025,6 +1202,10 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
         // dW_ih[n][k] = sum_r dG[r][n] * X[r][k]
         GemmDesc a{};
         a.A = {compact ? lb.dgs + dir * 4L * H : dGd, 8L * H, 0, 0, 0};
+        if (dimg && !compact) {
+            a.a_pre = dimg + (a.A.p - dG);
+            a.a_pre_scale = dsc;
+        }
         a.B = {xi.p, xi.ld, 0, 0, 0};
         if (img_ok && l > 0) a.b_pre = lb.out_img[l - 1];
         a.C = e->G + pd.wih;
@@ -1040,6 +1221,10 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
         // dW_hh[n][k] = sum_r dG[r][n] * h_prev[r][k];  h_prev = out one row earlier (fwd) / later (reverse)
         GemmDesc h{};
         h.A = {dir == 0 ? dGd + 8L * H : dGd, 8L * H, 0, 0, 0};
+        if (dimg) {
+            h.a_pre = dimg + (h.A.p - dG);
+            h.a_pre_scale = dsc;
+        }
         h.B = {dir == 0 ? lb.out[l] : lb.out[l] + 2L * H + H, 2L * H, 0, 0, 0};
         if (img_ok) h.b_pre = dir == 0 ? lb.out_img[l] : lb.out_img[l] + 2L * H + H;
         h.C = e->G + pd.whh;
@@ -1069,7 +1254,7 @@ int lstm_input_grad(ss_engine* e, LstmBlk& lb, int l, Slab dxi, long r0, long nr
         GemmDesc g{};
         g.A = {lb.dgs, 8L * H, 0, 0, 0};
         g.B = {lb.wcat[0], In, 0, 0, 0};
-        g.b_pre = ((g_presplit & 1) && !lb.wcat_img.empty()) ? lb.wcat_img[0] : nullptr;
+        g.b_pre = (g_presplit & 1) ? lb.wimg(0) : nullptr;
         g.C = lb.d_xc;
         g.ldc = In;
         g.M = (int)R8;
@@ -1090,7 +1275,7 @@ int lstm_input_grad(ss_engine* e, LstmBlk& lb, int l, Slab dxi, long r0, long nr
     GemmDesc g{};
     g.A = {lb.gates[l] + r0 * 8L * H, 8L * H, 0, 0, 0};
     g.B = {lb.wcat[l], In, 0, 0, 0};
-    g.b_pre = ((g_presplit & 1) && !lb.wcat_img.empty()) ? lb.wcat_img[l] : nullptr;
+    g.b_pre = ((g_presplit & 8) && (g_presplit & 1)) ? lb.wimg(l) : nullptr;       // measured with image format v2: 573 us per step with the image, 532 without (round 3)
     g.C = dxi.p + r0 * dxi.ld;
     g.ldc = dxi.ld;
     g.M = (int)nr;
@@ -1245,6 +1430,7 @@ int join_side(ss_engine* e, hipStream_t s) {
 // Encoder_7 (G3) / Encoder_6 (G6) trunk + their LSTMs, Encoder_t, decoder, head.  Inputs already in in_mel/in_f0/org/emb.
 int forward_core(ss_engine* e, bool training, const float* scales, const int* len_seg, int draw0, hipStream_t s) {
     const int B = e->curB, T = e->curT;
+    e->part_off = 0;           // split-K scratch: every launch of a step gets its own region; the previous step is through (stream order) when this one's first kernel runs
     const long TP = T + 2 * HALO;
     const int CE = e->CE;
     const bool g3 = e->kind == SS_GENERATOR_3;
@@ -1584,6 +1770,7 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
     }
     // ---- everything that only has to be finished by the end of the step
     if (e->dec_w_pending) {                        // backward_decoder(late): decoder + head weight gradients, behind the decoder chain
+        if (g_exp & 1) CHK(fork_join(e, s, e->side));      // experiment: ... and behind the conv trunk's backward as well (the two chains run one after the other)
         HIPCHK(hipStreamWaitEvent(e->side, e->ev_join[1], 0));
         CHK(lstm_late_weights(e, e->ld, dec_compact(e) ? Slab{e->ld.xc, e->dec_in_dim} : Slab{e->dec_in, e->dec_in_dim}, e->side));
         CHK(head_weight_grads(e, e->side));
@@ -1673,6 +1860,7 @@ ss_engine* ss_create(int kind, const ss_hparams* hp, int max_batch, int max_fram
     ss_engine* e = new ss_engine();
     e->kind = kind;
     e->hp = *hp;
+    e->bound_max_len_pad = hp->max_len_pad;
     e->maxB = max_batch;
     e->maxT = max_frames;
     build_table(e);
@@ -1735,10 +1923,14 @@ int ss_param_info(const ss_engine* e, int i, char* name, int cap, long* offset, 
 
 long ss_arena_numel(const ss_engine* e) { return e->arena; }
 
-long ss_workspace_bytes(const ss_engine* e) {
+// split-K scratch of the image GEMM behind the planned workspace (never zeroed, independent of the geometry): partial slabs have the
+// size of weight tensors, so 16 arenas' worth holds a step's launches at ksplit <= 8 with room to spare
+static long part_floats(const ss_engine* e) { return e->kind == SS_INTERP_ONLY ? 0 : 16 * ((e->arena + 63) & ~63L); }
+static long plan_bytes(const ss_engine* e) {
     ss_engine tmp = *e;             // dry run on a copy: carve() assigns the slab pointers
-    return tmp.carve(e->maxB, e->maxT, false);
+    return (tmp.carve(e->maxB, e->maxT, false) + 255) & ~255L;
 }
+long ss_workspace_bytes(const ss_engine* e) { return plan_bytes(e) + part_floats(e) * 4; }
 
 int ss_bind(ss_engine* e, float* params, float* grads, float* m, float* v, void* workspace, long ws_bytes, void* stream) {
     if (!workspace || (e->kind != SS_INTERP_ONLY && (!params || !grads))) return fail("ss_bind: null arena");
@@ -1751,10 +1943,13 @@ int ss_bind(ss_engine* e, float* params, float* grads, float* m, float* v, void*
     e->Mm = m;
     e->Vv = v;
     e->ws = (char*)workspace;
-    e->ws_bytes = ws_bytes;
+    e->ws_bytes = plan_bytes(e);
+    e->part = (float*)(e->ws + e->ws_bytes);
+    e->part_cap = part_floats(e);
+    e->part_off = 0;
     e->curB = e->curT = 0;
     e->have_fwd = false;
-    HIPCHK(hipMemsetAsync(e->ws, 0, ws_bytes, S(stream)));
+    HIPCHK(hipMemsetAsync(e->ws, 0, e->ws_bytes, S(stream)));
     e->carve(e->maxB, e->maxT, true);
     if (!e->sticky) {       // host-coherent pinned word: kernels OR into it (system scope), the host reads it without a sync
         void* p = nullptr;
@@ -1816,7 +2011,7 @@ static int adam_enqueue(ss_engine* e, float grad_scale, hipStream_t s) {
 }
 
 int ss_adam_step(ss_engine* e, float grad_scale, void* stream) {
-    CHK(sticky_check(e));
+    CHK(entry_check(e));
     Own own(e, stream);
     return adam_enqueue(e, grad_scale, own.s);
 }
@@ -1831,7 +2026,7 @@ int ss_zero_grads(ss_engine* e, void* stream) {
 int ss_g3_forward(ss_engine* e, const float* x_f0, const float* x_org, const float* c_trg, const float* scales,
                   const int* len_seg, int B, int T, int training, float* out, void* stream) {
     if (e->kind != SS_GENERATOR_3) return fail("ss_g3_forward on a Generator_6 engine");
-    CHK(sticky_check(e));
+    CHK(entry_check(e));
     Own own(e, stream);
     hipStream_t s = own.s;
     if (training && T != e->hp.max_len_pad)
@@ -1881,7 +2076,7 @@ int ss_g3_rhythm(ss_engine* e, const float* x_org, int B, int T, float* codes, v
 int ss_g6_forward(ss_engine* e, const float* x_org, const float* f0_trg, const float* scales, const int* len_seg, int B,
                   int T, int training, float* out, void* stream) {
     if (e->kind != SS_GENERATOR_6) return fail("ss_g6_forward on a Generator_3 engine");
-    CHK(sticky_check(e));
+    CHK(entry_check(e));
     Own own(e, stream);
     hipStream_t s = own.s;
     if (training && T != e->hp.max_len_pad) return fail("train-mode forward needs T == max_len_pad (model.py:370)");
@@ -1949,20 +2144,30 @@ static int g3_step_body(ss_engine* e, const float* mel, const float* f0, const f
     return 0;
 }
 
+// Length buckets (SS_STEP_BUCKET): a bucketed step runs with max_len_pad = T; a step WITHOUT the flag runs with the max_len_pad the
+// engine was created with again, whatever bucket came before (a loader that mixes buckets with full-length batches sends the
+// latter without the flag: speechsplit_amd/solver.py).
+static int apply_bucket(ss_engine* e, int T, int flags) {
+    int want = e->bound_max_len_pad;
+    if (flags & SS_STEP_BUCKET) {      // this batch's length bucket: the step runs with max_len_pad = T (SURVEY.md D6)
+        if (T < 8 || T > e->maxT || T % 8) return fail("SS_STEP_BUCKET: T must be a multiple of 8 within the engine's max_frames");
+        want = T;
+    }
+    if (e->hp.max_len_pad != want) {
+        e->hp.max_len_pad = want;
+        e->curB = e->curT = 0;         // InterpLnr plans are sized by max_len_pad: carve again
+    }
+    return 0;
+}
+
 int ss_g3_train_step(ss_engine* e, const float* mel, const float* f0, const float* emb, const int* len_org,
                      const float* scales, const int* len_seg, int B, int T, float grad_scale, int flags, float* loss,
                      void* stream) {
     if (e->kind != SS_GENERATOR_3) return fail("ss_g3_train_step on a Generator_6 engine");
-    CHK(sticky_check(e));
+    CHK(entry_check(e));
     Own own(e, stream);
     hipStream_t s = own.s;
-    if (flags & SS_STEP_BUCKET) {      // this batch's length bucket: the step runs with max_len_pad = T (SURVEY.md D6)
-        if (T < 8 || T > e->maxT || T % 8) return fail("SS_STEP_BUCKET: T must be a multiple of 8 within the engine's max_frames");
-        if (e->hp.max_len_pad != T) {
-            e->hp.max_len_pad = T;
-            e->curB = e->curT = 0;     // InterpLnr plans are sized by max_len_pad: carve again
-        }
-    }
+    CHK(apply_bucket(e, T, flags));
     const ss_hparams& h = e->hp;
     if (T != h.max_len_pad) return fail("training needs T == max_len_pad (model.py:105,157,370); pass SS_STEP_BUCKET for a length-bucketed batch");
     CHK(geometry(e, B, T, s));
@@ -2040,10 +2245,7 @@ long ss_grad_split(const ss_engine* e) {
 int ss_g6_train_step(ss_engine* e, const float* mel, const float* f0_onehot, const int* target_idx, const float* scales,
                      const int* len_seg, int B, int T, float grad_scale, int flags, float* loss, void* stream) {
     if (e->kind != SS_GENERATOR_6) return fail("ss_g6_train_step on a Generator_3 engine");
-    if ((flags & SS_STEP_BUCKET) && T >= 8 && T <= e->maxT && T % 8 == 0 && e->hp.max_len_pad != T) {
-        e->hp.max_len_pad = T;
-        e->curB = e->curT = 0;
-    }
+    CHK(apply_bucket(e, T, flags));
     Own own(e, stream);
     hipStream_t s = own.s;
     CHK(ss_g6_forward(e, mel, f0_onehot, scales, len_seg, B, T, 1, nullptr, (void*)s));
@@ -2127,24 +2329,22 @@ int ss_op_gemm(const float* a, long lda, const float* b, long ldb, float* c, lon
     return 0;
 }
 
-int ss_op_split_planes(const float* src, long ld, int rows, int cols, int transpose, float scale, void* plane_h, void* plane_l, long ldp,
-                       void* stream) {
-    if (!src || !plane_h || !plane_l) return fail("ss_op_split_planes: null pointer");
-    HIPCHK(transpose ? split_planes_t(src, ld, rows, cols, nullptr, scale, plane_h, plane_l, ldp, S(stream))
-                     : split_planes(src, ld, rows, cols, nullptr, scale, plane_h, plane_l, ldp, S(stream)));
+int ss_op_split_image(const float* src, long ld, long rows, int cols, float scale, float* img, long ldi, void* stream) {
+    if (!src || !img) return fail("ss_op_split_image: null pointer");
+    HIPCHK(split_image(src, ld, rows, cols, nullptr, scale, img, ldi, nullptr, S(stream)));
     return 0;
 }
 
-int ss_op_gemm_planes(const void* ah, const void* al, long lda, const void* bh, const void* bl, long ldb, float* c, long ldc,
-                      const float* bias, int M, int N, int K, int ksplit, float unscale, void* stream) {
-    PlanesDesc d{};
-    d.ah = (const _Float16*)ah;
-    d.al = (const _Float16*)al;
-    d.bh = (const _Float16*)bh;
-    d.bl = (const _Float16*)bl;
-    d.lda = lda;
-    d.ldb = ldb;
-    d.c = c;
+int ss_op_gemm_img(const float* a_img, long lda, const float* b_img, long ldb, float* c, long ldc, const float* bias, int M, int N, int K, int flags,
+                   int ksplit, int cfg, float scale_a, float scale_b, int a_seglen, long a_segstride, float* part, const void* zeros, void* stream) {
+    static float* sc = nullptr;           // the two scales as device words (test hook: one call at a time)
+    if (!sc) HIPCHK(hipMalloc((void**)&sc, 256));
+    const float h[2] = {scale_a, scale_b};
+    HIPCHK(hipMemcpyAsync(sc, h, sizeof(h), hipMemcpyHostToDevice, S(stream)));
+    ImgGemmDesc d{};
+    d.A = {a_img, lda, 0, a_seglen, a_segstride};
+    d.B = {b_img, ldb, 0, 0, 0};
+    d.C = c;
     d.ldc = ldc;
     d.bias = bias;
     d.M = M;
@@ -2152,9 +2352,15 @@ int ss_op_gemm_planes(const void* ah, const void* al, long lda, const void* bh, 
     d.K = K;
     d.batch = 1;
     d.ksplit = ksplit < 1 ? 1 : ksplit;
-    d.unscale = unscale;
+    d.flags = (flags & 1 ? GEMM_TA : 0) | (flags & 2 ? GEMM_TB : 0) | (flags & 4 ? GEMM_ACCUM : 0);
+    d.part = part;
+    d.scale_a = sc;
+    d.scale_b = sc + 1;
+    d.zeros = zeros;
+    d.cfg = cfg;
     d.diag = g_gemm_diag;
-    HIPCHK(launch_gemm_planes(d, S(stream)));
+    if (!gemm_img_supported(d)) return fail("ss_op_gemm_img: shape / alignment not supported by the image GEMM");
+    HIPCHK(launch_gemm_img(d, S(stream)));
     return 0;
 }
 
@@ -2217,7 +2423,13 @@ int ss_tune(const char* key, int value) {
     else if (k == "prewarm" && value >= 0 && value <= 3) g_prewarm = value;
     else if (k == "batch_dirs" && value >= 0 && value <= 2) g_batch_dirs = value;
     else if (k == "compact0" && (value == 0 || value == 1)) g_compact0 = value;
-    else if (k == "presplit" && value >= 0 && value <= 7) g_presplit = value;
+    else if (k == "presplit" && value >= 0 && value <= 15) g_presplit = value;
+    else if (k == "img" && (value == 0 || value == 1)) g_img = value;
+    else if (k == "img_mask" && value >= 0 && value < 2048) g_img_mask = value;
+    else if (k == "img_batch" && (value == 0 || value == 1)) g_img_batch = value;
+    else if (k == "img_dw_cfg" && value >= -1 && value <= 2) g_img_dw_cfg = value;
+    else if (k == "img_dw_wgs" && value >= 32 && value <= 4096) g_img_dw_wgs = value;
+    else if (k == "img_cfg" && value >= -1 && value <= 2) g_img_cfg = value;
     else if (k == "dw_wgs" && value >= 64 && value <= 4096) g_dw_wgs = value;
     else if (k == "trunk_indep" && (value == 0 || value == 1)) g_trunk_indep = value;
     else if (k == "branch_low" && (value == 0 || value == 1)) g_branch_low = value;
@@ -2510,6 +2722,13 @@ int ss_comm_init(ss_engine* e, const char* id128, int rank, int world) {
     e->comm = c;
     e->comm_rank = rank;
     e->comm_world = world;
+    if (world > 1) e->lockstep = true;
+    return 0;
+}
+
+int ss_set_lockstep(ss_engine* e, int on) {
+    if (!e) return fail("ss_set_lockstep: null engine");
+    e->lockstep = on != 0;
     return 0;
 }
 
@@ -2532,15 +2751,9 @@ int ss_g3_dp_train_step(ss_engine* e, const float* mel, const float* f0, const f
                         const int* len_seg, int B, int T, int flags, float* loss, void* stream) {
     if (e->kind != SS_GENERATOR_3) return fail("ss_g3_dp_train_step on a Generator_6 engine");
     if (!e->comm) return fail("ss_g3_dp_train_step: call ss_comm_init first");
-    if (flags & SS_STEP_BUCKET) {      // every rank runs the same bucket (speechsplit_amd/buckets.py)
-        if (T < 8 || T > e->maxT || T % 8) return fail("SS_STEP_BUCKET: T must be a multiple of 8 within the engine's max_frames");
-        if (e->hp.max_len_pad != T) {
-            e->hp.max_len_pad = T;
-            e->curB = e->curT = 0;
-        }
-    }
+    CHK(apply_bucket(e, T, flags));      // every rank runs the same bucket (speechsplit_amd/buckets.py)
     if (T != e->hp.max_len_pad) return fail("training needs T == max_len_pad (model.py:105,157,370); pass SS_STEP_BUCKET for a length-bucketed batch");
-    CHK(sticky_check(e));
+    CHK(entry_check(e));
     Own own(e, stream);
     hipStream_t s = own.s;
     CHK(geometry(e, B, T, s));

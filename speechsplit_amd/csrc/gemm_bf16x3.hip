@@ -116,7 +116,9 @@ template <int BM, int BN, bool TA, bool TB, int NPL, bool PROBE = false, bool TR
 __global__ __launch_bounds__(WS ? 512 : 256, (NPL == 2 && !WS && !PROBE) ? 3 : 1) void gemm_bf16x3_kernel(const GemmDesc d) {
     constexpr bool TRA = TR && TA && BM == 128, TRB = TR && TB && BN == 128;
     constexpr int MI = BM / 64, NI = BN / 64;
-    constexpr int PA = BM * 64, PB = BN * 64;                 // bytes per plane
+    // plane stride in bytes.  fp16 x 2: 64 bytes of padding between the hi and the lo plane -- a staged IMAGE slot is 16 bytes of ONE
+    // piece, neighbouring lanes store hi / lo chunks of the same position, and without the shift each such pair hits the same banks
+    constexpr int PA = BM * 64 + (NPL == 2 ? 64 : 0), PB = BN * 64 + (NPL == 2 ? 64 : 0);
     constexpr int NBUF = WS ? 2 : 1;
     __shared__ __attribute__((aligned(16))) unsigned char As[NBUF * NPL * PA];
     __shared__ __attribute__((aligned(16))) unsigned char Bs[NBUF * NPL * PB];
@@ -197,8 +199,8 @@ __global__ __launch_bounds__(WS ? 512 : 256, (NPL == 2 && !WS && !PROBE) ? 3 : 1
 
     typedef f32x4 Slot;
     // fp16 x 2 only: per-operand power-of-two scales (measured maximum or the fixed one), undone in the epilogue
-    const float sc_a = NPL == 2 ? (d.amax_a ? pow2_scale(*d.amax_a) : F16_SCALE) : 1.0f;
-    const float sc_b = NPL == 2 ? (d.amax_b ? pow2_scale(*d.amax_b) : F16_SCALE) : 1.0f;
+    const float sc_a = NPL == 2 ? ((d.flags & GEMM_A_PRE) ? (d.a_pre_scale ? *d.a_pre_scale : F16_SCALE) : (d.amax_a ? pow2_scale(*d.amax_a) : F16_SCALE)) : 1.0f;
+    const float sc_b = NPL == 2 ? ((d.flags & GEMM_B_PRE) ? (d.b_pre_scale ? *d.b_pre_scale : F16_SCALE) : (d.amax_b ? pow2_scale(*d.amax_b) : F16_SCALE)) : 1.0f;
     // full: the whole k-tile lies inside [kbeg, kend), so the load needs no predicate at all (rows / columns past the
     // matrix edge read row / column 0: their products land in accumulator entries the epilogue never stores).
     auto fetch = [&](const Operand& op, bool T, bool TRX, const float*& p, int& w, bool ok, int kpos, bool full) -> Slot {
@@ -259,10 +261,12 @@ __global__ __launch_bounds__(WS ? 512 : 256, (NPL == 2 && !WS && !PROBE) ? 3 : 1
             return;
         }
         if (NPL == 2) {
-            if (pre) {      // the operand is already the interleaved image of its two pieces: (h01, h23, l01, l23) per group of four
-                const u32x4 w = __builtin_bit_cast(u32x4, s);
-                *reinterpret_cast<u32x2*>(S + o) = u32x2{w[0], w[1]};
-                *reinterpret_cast<u32x2*>(S + P + o) = u32x2{w[2], w[3]};
+            if (pre) {      // the operand is an image (format v2): this slot is the 16 bytes of hi pieces (even slot) or of lo pieces (odd slot)
+                            // of a group of EIGHT elements -> one 16-byte store into that piece's plane, at the group's position
+                const int kk = T ? 0 : (f % 8) * 4, xx = 4 * (f % 32);
+                const int plane = TRX ? (f & 1) : ((kk >> 2) & 1);
+                const int o8 = TRX ? lds_off_t(f / 32, xx & ~7) : lds_off(row, kk & ~7);
+                *reinterpret_cast<u32x4*>(S + plane * P + o8) = __builtin_bit_cast(u32x4, s);
                 return;
             }
             unsigned ha, la, hb, lb;
@@ -454,16 +458,18 @@ hipError_t launch_cfg(const GemmDesc& din, hipStream_t s) {
     // reduction-major operands through the transposing-read image (which the code below then has to choose).
     const bool tr_all = CAN_TR && g_gemm_tr && (g_gemm_tr == 1 || !(TA && TB)) && !(d.flags & GEMM_BF16) && quad_ok(d.A, TA, d.M) && quad_ok(d.B, TB, d.N);
     const bool f16 = (d.flags & GEMM_F16X2) && !(d.flags & GEMM_BF16) && !d.diag;
-    auto pre_ok = [&](const Operand& op, bool T, const float* img, const float* amax) {
-        if (!img || !f16 || amax || (((size_t)img) & 15)) return false;
-        if (T) return tr_all;
-        return d.K % 4 == 0 && op.ld % 4 == 0 && (op.seglen == 0 || (op.seglen % 4 == 0 && op.segstride % 4 == 0));
+    // (whole groups of EIGHT: image format v2)
+    auto pre_ok = [&](const Operand& op, bool T, const float* img, int X) {
+        if (!img || !f16 || (((size_t)img) & 31) || op.ld % 8 || op.bstride % 8) return false;
+        if (op.seglen && (op.seglen % 8 || op.segstride % 8)) return false;
+        if (T) return tr_all && X % 8 == 0;
+        return d.K % 8 == 0;
     };
-    if (pre_ok(d.A, TA, d.a_pre, d.amax_a)) {
+    if (pre_ok(d.A, TA, d.a_pre, d.M)) {
         d.A.p = d.a_pre;
         d.flags |= GEMM_A_PRE;
     }
-    if (pre_ok(d.B, TB, d.b_pre, d.amax_b)) {
+    if (pre_ok(d.B, TB, d.b_pre, d.N)) {
         d.B.p = d.b_pre;
         d.flags |= GEMM_B_PRE;
     }

@@ -464,7 +464,7 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_fwd_kernel(float* __re
                     float* dst = o < 4 ? gates + r * (8 * H) + dir * 4 * H + o * H + jt * 16 + 4 * q
                                        : (o == 4 ? csave : out) + r * (2 * H) + dir * H + jt * 16 + 4 * q;
                     *reinterpret_cast<f32x4*>(dst) = v;
-                    if (o == 5 && out_img) *reinterpret_cast<uint4*>(out_img + r * (2 * H) + dir * H + jt * 16 + 4 * q) = ss_split_group(v[0], v[1], v[2], v[3]);
+                    if (o == 5 && out_img) ss_store_group(out_img + r * (2 * H) + dir * H + jt * 16 + 4 * q, ss_split_group(v[0], v[1], v[2], v[3]));
                 }
             };
             for (int st = 0; st < T; ++st) {

@@ -287,6 +287,11 @@ class Engine:
     def clear_abort(self):
         _capi.check(self.lib.ss_clear_abort(self.h, _stream()))
 
+    def set_lockstep(self, on=True):
+        """Data-parallel member whose gradients are exchanged outside the engine (torch.distributed): entry points never refuse on the
+        status word, check() reports it at a point all ranks reach together (ss_set_lockstep; the native communicator sets it itself)."""
+        _capi.check(self.lib.ss_set_lockstep(self.h, 1 if on else 0))
+
     def zero_grads(self):
         _capi.check(self.lib.ss_zero_grads(self.h, _stream()))
 
@@ -369,29 +374,37 @@ class Engine:
         return flat.view(B, T + 4, cols.value)[:, 2:2 + T].clone()
 
 
-def split_planes(x, transpose=False, scale=16.0):
-    """Test hook (ss_op_split_planes): fp32 [rows, cols] -> (hi, lo) fp16 planes, [rows, pad32(cols)] or, transposed,
-    [cols, pad32(rows)]."""
+def split_image(x, scale=16.0):
+    """Test hook (ss_op_split_image): fp32 [rows, cols] (cols % 8 == 0) -> its operand image, a float32-typed tensor of the same shape whose
+    bytes are, per 8 elements, 16 B of fp16 hi pieces and 16 B of fp16 lo pieces of scale * x (csrc/common.h, image format v2)."""
     lib = _capi.lib()
     rows, cols = x.shape
     x = x.contiguous()
-    shape = (cols, (rows + 31) // 32 * 32) if transpose else (rows, (cols + 31) // 32 * 32)
-    ph = torch.zeros(shape, dtype=torch.float16, device=x.device)
-    pl = torch.zeros(shape, dtype=torch.float16, device=x.device)
-    _capi.check(lib.ss_op_split_planes(_ptr(x), x.stride(0), rows, cols, int(transpose), float(scale), _ptr(ph), _ptr(pl), shape[1], _stream()))
-    return ph, pl
+    img = torch.empty_like(x)
+    _capi.check(lib.ss_op_split_image(_ptr(x), x.stride(0), rows, cols, float(scale), _ptr(img), img.stride(0), _stream()))
+    return img
 
 
-def gemm_planes(a_planes, b_planes, M, N, bias=None, ksplit=1, scale_a=16.0, scale_b=16.0, out=None):
-    """Test hook (ss_op_gemm_planes): C[M,N] = A . B^T over pre-split planes ([M, Kp] and [N, Kp])."""
+_ZEROS = {}
+
+
+def gemm_img(a_img, b_img, ta=False, tb=False, bias=None, ksplit=1, cfg=-1, scale_a=16.0, scale_b=16.0, out=None, accumulate=False, a_seg=(0, 0),
+             M=None, K=None, part=None):
+    """Test hook (ss_op_gemm_img): C[M,N] = A(m,k) B(n,k) over operand images.  a_img [M,K] ([K,M] if ta), b_img [N,K] ([K,N] if tb)."""
     lib = _capi.lib()
-    ah, al = a_planes
-    bh, bl = b_planes
-    K = ah.shape[1]
-    assert bh.shape[1] == K
-    c = torch.zeros(M, N, device=ah.device) if out is None else out
-    _capi.check(lib.ss_op_gemm_planes(_ptr(ah), _ptr(al), ah.stride(0), _ptr(bh), _ptr(bl), bh.stride(0), _ptr(c), N, _ptr(bias), M, N, K,
-                                      int(ksplit), 1.0 / (scale_a * scale_b), _stream()))
+    if M is None:
+        M = a_img.shape[1] if ta else a_img.shape[0]
+    if K is None:
+        K = a_img.shape[0] if ta else a_img.shape[1]
+    N = b_img.shape[1] if tb else b_img.shape[0]
+    dev = a_img.device
+    c = torch.zeros(M, N, device=dev) if out is None else out
+    if ksplit > 1 and part is None:
+        part = torch.empty(ksplit * M * N, device=dev)
+    z = _ZEROS.setdefault(str(dev), torch.zeros(1024, device=dev))
+    _capi.check(lib.ss_op_gemm_img(_ptr(a_img), a_img.stride(0), _ptr(b_img), b_img.stride(0), _ptr(c), c.stride(0), _ptr(bias), M, N, K,
+                                   (1 if ta else 0) | (2 if tb else 0) | (4 if accumulate else 0), int(ksplit), int(cfg), float(scale_a),
+                                   float(scale_b), int(a_seg[0]), int(a_seg[1]), _ptr(part), _ptr(z), _stream()))
     return c
 
 

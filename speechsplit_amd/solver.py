@@ -66,6 +66,7 @@ class Solver(object):
             _dist.init('nccl', self.device)
             import torch.distributed as dist
             dist.broadcast(self.eng.params, src=0)   # identical replicas
+            self.eng.set_lockstep(True)              # never refuse a step on the status word: check() reports it on every rank at the same iteration
             if self.GENERATOR is Generator:
                 # the engine's own RCCL communicator: its data-parallel step launches the collectives on the engine's streams and costs
                 # nothing over the one-GPU step, where torch.distributed's path measured +0.5 ms

@@ -63,6 +63,32 @@ def test_bucketed_steps_equal_reference_run_per_bucket(E):
         assert np.array_equal(eng.debug_buffer('in.mel', B, T).cpu().numpy(), xi[:, :, :80].numpy())      # index path: bit-exact
     with pytest.raises(RuntimeError, match='SS_STEP_BUCKET'):              # without the flag the engine insists on its max_len_pad
         eng.g3_train_step(*synth_batch(1, B, 152, 150)[:4], stack_draws(draws_for(2, B, 4)))
+    # ... and that is the max_len_pad it was created with, whatever bucket ran last (round-2 advisor finding: a 192-frame batch sent
+    # WITHOUT the flag after a 104-frame bucket used to be refused)
+    mel, f0, emb, lens = synth_batch(310, B, 192, 185)
+    draws = draws_for(410, B, 4)
+    loss = eng.g3_train_step(mel, f0, emb, lens, stack_draws(draws), no_adam=True)
+    with torch.no_grad():
+        lo, _ = ref_model.g3_loss(st.P, hp192, mel, f0, emb, lens.numpy(), draws)           # the oracle at the same (four times updated) weights
+    assert abs(float(loss) - float(lo)) <= 1e-5 * float(lo), (float(loss), float(lo))
+
+
+def test_solver_walks_buckets_and_full_length(E, tmp_path):
+    """Solver.train_on_batch recognises buckets by their frame count: T, max_len_pad, T in a row (the full-length batch goes out
+    without SS_STEP_BUCKET) -- the sequence a BucketedDeviceBatcher produces in about 8 % of its steps."""
+    from types import SimpleNamespace
+    from speechsplit_amd import solver as S, hparams as HPM
+    hp = HPM.default_hparams(batch_size=4)              # max_len_pad = 192
+    cfg = SimpleNamespace(num_iters=3, g_lr=1e-4, beta1=0.9, beta2=0.999, resume_iters=None, use_tensorboard=False, device_id=0,
+                          log_dir=str(tmp_path), sample_dir=str(tmp_path), model_save_dir=str(tmp_path), log_step=1, sample_step=10 ** 9,
+                          model_save_step=10 ** 9)
+    s = S.Solver([], cfg, hp)
+    losses = []
+    for it, T in enumerate((144, 192, 104, 192, 192, 144)):
+        mel, f0, emb, lens = synth_batch(500 + it, 4, T, T - 7)
+        losses.append(float(s.train_on_batch((mel, emb, f0, lens))))
+        s.eng.check()
+    assert all(np.isfinite(losses)), losses
 
 
 def test_bucketed_device_batcher(E):

@@ -745,15 +745,46 @@ def test_solver_validation_path_and_prefetcher(E, tmp_path):
     s.train()                       # one iteration + validation print through the prefetcher
 
 
-def test_planes_gemm_against_fp64(E):
-    """gemm_planes.hip (pre-split fp16 x 2 operands, LDS-DMA, 256 x 256 tiles; parked -- not on the product path yet, see
-    DESIGN.md): the same fp32-grade result as the in-loop-split kernel, from row-major and from transposed sources."""
-    g = torch.Generator().manual_seed(11)
-    for M, N, K, ks in [(300, 200, 100, 1), (1000, 520, 1024, 1), (512, 512, 4096, 4)]:
+@pytest.mark.parametrize('cfg', [0, 1, 2])
+@pytest.mark.parametrize('layout', [(False, False), (False, True), (True, True)])
+def test_image_gemm_against_fp64(E, layout, cfg):
+    """gemm_img.hip (operand images, LDS-DMA ring, deterministic split-K): fp32-grade results against fp64 in every layout and tile
+    configuration, with ragged M / N (multiples of 8 / 4 only), K tails of a reduction-major pair, bias, accumulation and split-K."""
+    ta, tb = layout
+    g = torch.Generator().manual_seed(11 + cfg)
+    shapes = [(264, 200, 96, 1), (1000, 520, 1024, 1), (512, 512, 4096, 4), (2048, 1024, 2112, 8)]
+    if ta and tb:
+        shapes += [(512, 264, 1027, 3), (256, 256, 8447, 8), (136, 128, 31, 1)]
+    for M, N, K, ks in shapes:
         A = torch.randn(M, K, generator=g).cuda()
         Bm = (torch.randn(N, K, generator=g) * 0.05).cuda()
-        bias = torch.randn(N, generator=g).cuda() if ks == 1 else None
-        ref = A.double() @ Bm.double().t() + (bias.double() if bias is not None else 0)
-        c = E.gemm_planes(E.split_planes(A), E.split_planes(Bm), M, N, bias, ks)
-        ct = E.gemm_planes(E.split_planes(A.t().contiguous(), transpose=True), E.split_planes(Bm.t().contiguous(), transpose=True), M, N, bias, ks)
-        assert rel(c, ref) < 5e-6 and rel(ct, ref) < 5e-6, (M, N, K, ks)
+        bias = torch.randn(N, generator=g).cuda()
+        c0 = torch.randn(M, N, generator=g).cuda()
+        ref = A.double() @ Bm.double().t() + bias.double() + c0.double()
+        ai = E.split_image(A.t().contiguous() if ta else A)
+        bi = E.split_image(Bm.t().contiguous() if tb else Bm)
+        c = E.gemm_img(ai, bi, ta, tb, bias, ks, cfg, out=c0.clone(), accumulate=True)
+        assert rel(c, ref) < 5e-6, (M, N, K, ks, layout, cfg)
+        # bit-identical on a second run (partial slabs are added in a fixed order)
+        c2 = E.gemm_img(ai, bi, ta, tb, bias, ks, cfg, out=c0.clone(), accumulate=True)
+        assert torch.equal(c, c2)
+
+
+def test_image_gemm_conv_windows_and_scales(E):
+    """The segmented K axis (a k=5 convolution read as one GEMM over overlapping rows of a haloed slab) and images split with other
+    power-of-two scales."""
+    g = torch.Generator().manual_seed(5)
+    B, T, Ci, Co = 3, 40, 64, 128
+    TP = T + 4
+    x = torch.zeros(B, TP, Ci)
+    x[:, 2:2 + T] = torch.randn(B, T, Ci, generator=g)
+    w = torch.randn(Co, 5, Ci, generator=g) * 0.05                 # [Co][tap][ci]: K-contiguous pack
+    xs = x.reshape(B * TP, Ci).cuda()
+    rows = B * TP - 4
+    ref = torch.zeros(rows, Co, dtype=torch.float64)
+    for tap in range(5):
+        ref += xs[tap:tap + rows].double().cpu() @ w[:, tap].double().t()
+    for cfg in (0, 1, 2):
+        c = E.gemm_img(E.split_image(xs, 4.0), E.split_image(w.reshape(Co, 5 * Ci).cuda(), 64.0), cfg=cfg, scale_a=4.0, scale_b=64.0,
+                       a_seg=(Ci, Ci), M=rows, K=5 * Ci)
+        assert rel(c, ref) < 5e-6, cfg
