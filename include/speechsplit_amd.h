@@ -169,8 +169,8 @@ int ss_collate(const float* mel_cat_dev, const float* f0_cat_dev, const float* e
  *                     256-workgroup grid was not co-resident): that step's gradients are garbage;
  *   SS_STATUS_REMOTE  another data-parallel rank reported the same through the gradient arena's status slot (the last four
  *                     floats of the arena; the all-reduce sums it);
- *   SS_STATUS_RANGE   a parameter is not finite or reached |p| >= 64, outside what the fixed-scale fp16 x 2 forward
- *                     products are valid for.
+ *   SS_STATUS_RANGE   a parameter is not finite or reached |p| >= 2048, outside what the fixed scale of the WEIGHTS' fp16 x 2
+ *                     split is valid for (activations and gradients carry data-dependent scales and have no such limit).
  * While it is non-zero the Adam kernel SKIPS the update on the device (parameters, moments and step counter untouched --
  * no host round trip is involved), every later ss_*_forward / ss_*_train_step / ss_adam_step returns an error without
  * enqueueing anything, and ss_check() keeps failing until ss_clear_abort().  ss_check synchronises `stream`;
@@ -250,9 +250,12 @@ int ss_tune(const char* key, int value);
  *     fp16 x 2 (default wherever an operand's magnitude is known): y = s*x = h + l, h = fp16(y), l = fp16(y - h), s a power of
  *       two; 3 v_mfma_f32_32x32x16_f16 per k-step (h.l, l.h, h.h): 22 significand bits relative to the operand's scaled
  *       maximum (elements more than 2^22 below it lose relative precision; the residual goes subnormal 2^-3 below the
- *       maximum's binade and flushes at 2^-33 of it).  Forward operands use the fixed scale s = 16 (|x| < 4094 survives);
- *       ss_bind / every parameter load checks max|w| against that range and the engine falls back to bf16 x 3 when it
- *       does not hold.  Gradient operands are scaled by the power of two their producer kernel measured.
+ *       maximum's binade and flushes at 2^-33 of it).  Scales: WEIGHTS, hidden states (|h| < 1) and the network inputs use the fixed
+ *       s = 16 (|x| < 4094 survives); the conv blocks' outputs use min(16, the power of two that keeps sqrt(16 T) max|gamma| +
+ *       max|beta| inside fp16) computed on the device from their GroupNorm affine every step (a gamma of 100 or 1000 trains in this
+ *       mode, at the same 1e-4 parity); gradient operands the power of two for the maximum their producer kernel measured.  What is
+ *       refused -- status SS_STATUS_RANGE, the Adam update skipped on the device -- is a parameter that is not finite or reaches
+ *       |p| >= 2048, checked inside every forward (there is no silent overflow and no automatic change of split).
  *     bf16 x 3 (head, encoder BLSTMs, unaligned shapes; everything with ss_tune("fwd_f16x2" / "bwd_f16x2", 0)): exact
  *       3-way truncation split x = h + m + l, 6 v_mfma_f32_32x32x16_bf16 per k-step, dropped terms <= 2^-24 relative.
  *     ss_tune("gemm_mode", 0): true fp32 MFMA (v_mfma_f32_32x32x2_f32), the A/B reference.

@@ -225,6 +225,13 @@ class TrainState:
         self.P = as_params(weights)
         self.opt = torch.optim.Adam(list(self.P.values()), lr, list(betas))
 
+    def load_adam(self, exp_avg, exp_avg_sq, step):
+        """Continue from an optimiser state (dicts name -> array, and the step count): what solver.py:84-90 restores from a checkpoint."""
+        for n, p in self.P.items():
+            self.opt.state[p] = {'step': torch.tensor(float(step)),
+                                 'exp_avg': torch.as_tensor(np.array(exp_avg[n], dtype=np.float32)).clone().reshape(p.shape),
+                                 'exp_avg_sq': torch.as_tensor(np.array(exp_avg_sq[n], dtype=np.float32)).clone().reshape(p.shape)}
+
     def step_g3(self, hp, mel, f0, emb, len_org, draws):
         loss, out = g3_loss(self.P, hp, mel, f0, emb, len_org, draws)
         self.opt.zero_grad()                                                 # solver.py:170

@@ -55,7 +55,8 @@ struct GemmDesc {
     // that operand in whole groups (K-contiguous, or the transposing-read image) and falls back to the fp32 operand otherwise.
     const float* a_pre;
     const float* b_pre;
-    // device words holding the power-of-two scale an image was split with (null: the fixed 16)
+    // device words holding the power-of-two scale of a FIXED-scale operand (null: 16): what its image was split with, and what the in-loop
+    // split uses when the operand is read as fp32 (amax_* null).  The conv trunk's activations carry one (kernels.h act_scales).
     const float* a_pre_scale;
     const float* b_pre_scale;
 };

@@ -737,7 +737,42 @@ __global__ __launch_bounds__(256) void param_guard_kernel(const float* __restric
     if (__any(bad) && (threadIdx.x & 63) == 0) __hip_atomic_fetch_or(sticky, SS_STICKY_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// one workgroup per conv block
+__global__ __launch_bounds__(256) void act_scale_kernel(ActScaleTable tb, float rt, float* __restrict__ out) {
+    __shared__ float red[2][4];
+    const int b = blockIdx.x;
+    float mg = 0.f, mb = 0.f;
+    for (int c = threadIdx.x; c < tb.C[b]; c += 256) {
+        mg = fmaxf(mg, fabsf(tb.gamma[b][c]));
+        mb = fmaxf(mb, fabsf(tb.beta[b][c]));
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mg = fmaxf(mg, __shfl_xor(mg, o));
+        mb = fmaxf(mb, __shfl_xor(mb, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = mg;
+        red[1][threadIdx.x >> 6] = mb;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mg = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+        mb = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+        const float bound = rt * mg + mb;
+        float sc = 16.0f;
+        // (a non-finite bound keeps 16: the parameter guard reports that case)
+        while (sc > 1.0f / 1048576.0f && bound * sc > 32768.0f) sc *= 0.5f;
+        out[b] = sc;
+    }
+}
+
 }  // namespace
+
+hipError_t act_scales(const ActScaleTable& tb, int T, float* out, hipStream_t s) {
+    if (tb.n < 1) return hipSuccess;
+    hipLaunchKernelGGL(act_scale_kernel, dim3(tb.n), dim3(256), 0, s, tb, sqrtf(16.0f * (float)T), out);
+    return hipGetLastError();
+}
 
 hipError_t status_publish(const unsigned* sticky, float* status, hipStream_t s) {
     hipLaunchKernelGGL(status_publish_kernel, dim3(1), dim3(1), 0, s, sticky, status);

@@ -102,6 +102,7 @@ struct ConvBlk {
     float *wf_img = nullptr, *wb_img = nullptr;      // pre-split images of wf / wb (GemmDesc::b_pre)
     float *wf = nullptr, *wb = nullptr, *gp = nullptr, *cout = nullptr, *stats = nullptr, *part = nullptr;
     int amax_i = -1;                       // slot in ss_engine::amax
+    int scale_i = -1;                      // slot in ss_engine::act_scale (scale of the fp16 x 2 split of this block's OUTPUT)
     bool need_dx = false;
     bool img_ok() const { return Cp % 8 == 0 && Co % 8 == 0; }       // wf_img / wb_img are written (rows of whole image groups)
 };
@@ -150,6 +151,7 @@ struct Slab {   // view of a haloed slab: p points at slab row 0, first channel 
     float* p = nullptr;
     long ld = 0;
     const float* img = nullptr;      // the slab's pre-split image at the same position, if its producer wrote one (GemmDesc::a_pre / b_pre)
+    const float* scale = nullptr;    // device word: power-of-two scale of the fp16 x 2 split of this slab's values (null: 16); conv-block outputs carry one
 };
 
 }  // namespace
@@ -203,6 +205,7 @@ struct ss_engine {
     float* dg_img[3] = {nullptr, nullptr, nullptr};       // decoder layers' pre-activation gradients [B, TP, 8H]
     float *d_img = nullptr, *d_img_t = nullptr;           // conv-output gradients of the trunk [B, TP, CE] / Encoder_t [B, TP, dim_enc_2]
     float* gscale = nullptr;               // [16]
+    float* act_scale = nullptr;            // [8] per conv block: scale of its output's fp16 x 2 split (act_scales, from the GroupNorm affine)
     void* zeros = nullptr;                 // 1 KB of zero bytes (image GEMM: reduction rows past K)
     float* part = nullptr;                 // split-K partial slabs of the image GEMM: a bump allocator over part_cap floats, reset per step
     long part_cap = 0, part_off = 0;
@@ -449,6 +452,7 @@ long ss_engine::carve(int B, int T, bool assign) {
     d_img = slab(nullptr, CE);
     d_img_t = slab(nullptr, hp.dim_enc_2);
     gscale = (float*)take(16 * 4);
+    act_scale = (float*)take(8 * 4);
     zeros = take(1024);
     d_xf = slab("enc.d_xf", CE);
     conv_ws(ct, "enc2.c");
@@ -463,6 +467,7 @@ long ss_engine::carve(int B, int T, bool assign) {
         int slot = 3;
         for (ConvBlk* cb : all) {
             cb->gp = cb->Co ? p : nullptr;
+            cb->scale_i = slot - 3;
             cb->amax_i = slot++;
             p += align4((long)cb->Co * 5 * cb->Cp);
         }
@@ -670,8 +675,8 @@ int sticky_check(ss_engine* e) {
     const unsigned v = *(volatile unsigned*)e->sticky;
     if (!v) return 0;
     if (v & SS_STICKY_RANGE)
-        return fail("a parameter is not finite or left the range (|p| < 64) the fixed-scale fp16 x 2 forward products are valid for: the step was "
-                    "not applied.  Use ss_tune(\"fwd_f16x2\", 0) and ss_tune(\"bwd_f16x2\", 0) (bf16 x 3 products, no range limit), then ss_clear_abort()");
+        return fail("a parameter is not finite or left the range (|p| < 2048) the fixed-scale fp16 x 2 products of the WEIGHTS are valid for: the step "
+                    "was not applied.  Use ss_tune(\"fwd_f16x2\", 0) and ss_tune(\"bwd_f16x2\", 0) (bf16 x 3 products, no range limit), then ss_clear_abort()");
     return fail(v & SS_STICKY_ABORT ? "a persistent LSTM kernel gave up waiting for its group (bounded spin expired) in an earlier step: that step's "
                                       "results were discarded and the parameters left untouched; ss_clear_abort() to continue"
                                     : "another data-parallel rank reported an aborted step: the update was skipped on every rank; ss_clear_abort() to continue");
@@ -875,6 +880,7 @@ int conv_block_fwd(ss_engine* e, ConvBlk& cb, Slab x, Slab y, hipStream_t s) {
     GemmDesc d{};
     d.A = {x.p, x.ld, TP * x.ld, cb.Cp, x.ld};
     d.a_pre = x.img;
+    d.a_pre_scale = x.scale;
     d.B = {cb.wf, 5L * cb.Cp, 0, 0, 0};
     d.b_pre = ((g_presplit & 1) && cb.img_ok()) ? cb.wf_img : nullptr;
     d.C = cb.cout + HALO * cb.Co;
@@ -921,6 +927,7 @@ int conv_block_bwd(ss_engine* e, ConvBlk& cb, Slab dy, Slab x, Slab dx, hipStrea
     }
     d.B = {x.p, x.ld, 0, cb.Cp, x.ld};
     d.b_pre = x.img;
+    d.b_pre_scale = x.scale;
     d.C = cb.gp;
     d.ldc = 5L * cb.Cp;
     d.M = cb.Co;
@@ -1091,6 +1098,7 @@ int lstm_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
         {   // both directions in one GEMM (stacked W_ih and summed biases from lstm_prep)
             GemmDesc d{};
             d.A = {xi.p + HALO * xi.ld, xi.ld, TP * xi.ld, 0, 0};
+            d.a_pre_scale = xi.scale;                  // conv-block output (layer 0); hidden states |h| < 1 take the fixed 16
             d.B = {lb.wcat[l], In, 0, 0, 0};
             d.b_pre = (g_presplit & 1) ? lb.wimg(l) : nullptr;
             d.C = lb.gates[l] + HALO * 8L * H;
@@ -1426,6 +1434,24 @@ int join_side(ss_engine* e, hipStream_t s) {
     return 0;
 }
 
+// Scale of the fp16 x 2 split of every conv block's output, from its GroupNorm affine (kernels.h act_scales): 16 for any sane
+// parameters, smaller powers of two when a large gamma could push an activation past fp16's range -- the contractions that read the
+// block's output (as an image or as fp32) take the scale from these words, so no parameter magnitude makes a forward product overflow.
+int act_scales_all(ss_engine* e, hipStream_t s) {
+    ActScaleTable tb{};
+    ConvBlk* all[7] = {&e->c1[0], &e->c1[1], &e->c1[2], &e->c2[0], &e->c2[1], &e->c2[2], &e->ct};
+    for (ConvBlk* cb : all) {
+        const int i = cb->scale_i;
+        if (i < 0 || i >= ACT_SCALE_MAX) return fail("act_scales_all: bad slot");
+        tb.gamma[i] = cb->Co ? e->P + cb->ga : e->P;
+        tb.beta[i] = cb->Co ? e->P + cb->be : e->P;
+        tb.C[i] = cb->Co;                  // an absent block (Generator_6 has no convolutions_1) has C = 0: bound 0, scale 16
+        if (i + 1 > tb.n) tb.n = i + 1;
+    }
+    HIPCHK(act_scales(tb, e->curT, e->act_scale, s));
+    return 0;
+}
+
 // ---- whole-model schedules ---------------------------------------------------------------------------------
 // Encoder_7 (G3) / Encoder_6 (G6) trunk + their LSTMs, Encoder_t, decoder, head.  Inputs already in in_mel/in_f0/org/emb.
 int forward_core(ss_engine* e, bool training, const float* scales, const int* len_seg, int draw0, hipStream_t s) {
@@ -1443,6 +1469,7 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
     e->grads_zeroed = false;               // set again below when this forward belongs to a fused training step
     if (g3) CHK(conv_pack_all(e, e->c1[0], s));
     CHK(conv_pack_all(e, e->c2[0], s));
+    CHK(act_scales_all(e, s));             // before every branch forks: the scale words of the conv blocks' outputs
     if (par) CHK(fork_join(e, s, b2));
     if (e->late_org && !g_graph) {
         const ss_hparams& hh = e->hp;
@@ -1495,13 +1522,14 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
             HIPCHK(hipMemsetAsync(e->amax, 0, 16 * 4, b2));
             e->grads_zeroed = true;
         }
-        // fp16 x 2 products scale weights and activations by a FIXED 16 (forward and gradient contractions alike), valid while every parameter (weights, GroupNorm affine) stays
-        // below 64 in magnitude: weights < 4094 / 16, and |GroupNorm output| <= 64 * sqrt(16 T) + 64 < 4094.  Outside that
-        // range (or for a non-finite parameter) the step is marked invalid instead of silently overflowing to inf.
-        if ((g_fwd_f16x2 || g_bwd_f16x2) && e->precision == SS_PRECISION_F32 && e->sticky) HIPCHK(param_guard(e->P, e->arena, 64.0f, e->sticky, b2));
+        // fp16 x 2 products scale WEIGHTS by a fixed 16 (forward and gradient contractions alike, and the persistent recurrences' W_hh):
+        // fine up to |w| < 4094.  Activations carry their own scale (act_scales_all) and gradients their measured one, so the only thing
+        // left to refuse is a parameter beyond 2048 in magnitude, or a non-finite one: the step is then marked invalid (status RANGE)
+        // instead of silently overflowing to inf.
+        if ((g_fwd_f16x2 || g_bwd_f16x2) && e->precision == SS_PRECISION_F32 && e->sticky) HIPCHK(param_guard(e->P, e->arena, 2048.0f, e->sticky, b2));
         // Encoder_t (model.py:74-89)
-        CHK(conv_block_fwd(e, e->ct, Slab{e->org, e->hp.dim_freq}, Slab{e->act_t, e->hp.dim_enc_2}, b2));
-        CHK(lstm_fwd(e, e->lt, Slab{e->act_t, e->hp.dim_enc_2}, b2));
+        CHK(conv_block_fwd(e, e->ct, Slab{e->org, e->hp.dim_freq}, Slab{e->act_t, e->hp.dim_enc_2, nullptr, e->act_scale + e->ct.scale_i}, b2));
+        CHK(lstm_fwd(e, e->lt, Slab{e->act_t, e->hp.dim_enc_2, nullptr, e->act_scale + e->ct.scale_i}, b2));
         return 0;
     };
     for (int i = 0; i < 3; ++i) {
@@ -1516,8 +1544,8 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
         }
         if (indep) {
             const float* im = (e->xf_img_valid && i > 0) ? e->xf_img[i - 1] : nullptr;
-            Slab x1 = i == 0 ? Slab{e->in_mel, e->hp.dim_freq} : Slab{e->xf[i - 1], CE, im};
-            Slab x2 = i == 0 ? Slab{e->in_f0, e->f0p} : Slab{e->xf[i - 1] + off2, CE, im ? im + off2 : nullptr};
+            Slab x1 = i == 0 ? Slab{e->in_mel, e->hp.dim_freq} : Slab{e->xf[i - 1], CE, im, e->act_scale + e->c1[i - 1].scale_i};
+            Slab x2 = i == 0 ? Slab{e->in_f0, e->f0p} : Slab{e->xf[i - 1] + off2, CE, im ? im + off2 : nullptr, e->act_scale + e->c2[i - 1].scale_i};
             CHK(conv_block_fwd(e, e->c2[i], x2, Slab{y + off2, CE}, b1));
             CHK(conv_block_fwd(e, e->c1[i], x1, Slab{y, CE}, s));
             if (training) {
@@ -1528,8 +1556,8 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
                 }
                 float* gi = (e->xf_img_valid && e->xf_img[i]) ? e->xf_img[i] + HALO * CE : nullptr;
                 HIPCHK(interp_gather(pl, e->act + HALO * CE + off2, CE, TP * CE, e->xf[i] + HALO * CE + off2, CE, TP * CE, CE - off2, B, b1,
-                                     gi ? gi + off2 : nullptr));
-                HIPCHK(interp_gather(pl, e->act + HALO * CE, CE, TP * CE, e->xf[i] + HALO * CE, CE, TP * CE, off2, B, s, gi));
+                                     gi ? gi + off2 : nullptr, e->act_scale + e->c2[i].scale_i));
+                HIPCHK(interp_gather(pl, e->act + HALO * CE, CE, TP * CE, e->xf[i] + HALO * CE, CE, TP * CE, off2, B, s, gi, e->act_scale + e->c1[i].scale_i));
             }
             continue;
         }
@@ -1539,10 +1567,10 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
         hipStream_t sp = cpar ? b1 : s;
         if (cpar) CHK(fork_join(e, s, b1));
         if (g3) {
-            Slab x1 = i == 0 ? Slab{e->in_mel, e->hp.dim_freq} : Slab{e->xf[i - 1], CE};
+            Slab x1 = i == 0 ? Slab{e->in_mel, e->hp.dim_freq} : Slab{e->xf[i - 1], CE, nullptr, e->act_scale + e->c1[i - 1].scale_i};
             if (!cpar) CHK(conv_block_fwd(e, e->c1[i], x1, Slab{y, CE}, s));
         }
-        Slab x2 = i == 0 ? Slab{e->in_f0, e->f0p} : Slab{e->xf[i - 1] + off2, CE};
+        Slab x2 = i == 0 ? Slab{e->in_f0, e->f0p} : Slab{e->xf[i - 1] + off2, CE, nullptr, e->act_scale + e->c2[i - 1].scale_i};
         CHK(conv_block_fwd(e, e->c2[i], x2, Slab{y + off2, CE}, sp));
         if (training) {
             // one warp for both streams (model.py:202-206), len_seq = max_len_pad for every utterance (:105,157,203)
@@ -1551,7 +1579,7 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
                                e->hp.max_len_pad, B, sp));
         }
         if (cpar) {
-            Slab x1 = i == 0 ? Slab{e->in_mel, e->hp.dim_freq} : Slab{e->xf[i - 1], CE};
+            Slab x1 = i == 0 ? Slab{e->in_mel, e->hp.dim_freq} : Slab{e->xf[i - 1], CE, nullptr, e->act_scale + e->c1[i - 1].scale_i};
             CHK(conv_block_fwd(e, e->c1[i], x1, Slab{y, CE}, s));
             CHK(fork_join(e, b1, s));
         }
@@ -1566,8 +1594,8 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
         if (indep) CHK(fork_join(e, b2, b1));      // the pitch chain does not wait for the content chain
         else CHK(fork_join(e, s, b1));
     }
-    CHK(lstm_fwd(e, e->l2, Slab{e->xf[2] + off2, CE}, b1));
-    if (g3) CHK(lstm_fwd(e, e->l1, Slab{e->xf[2], CE}, s));
+    CHK(lstm_fwd(e, e->l2, Slab{e->xf[2] + off2, CE, nullptr, e->act_scale + e->c2[2].scale_i}, b1));
+    if (g3) CHK(lstm_fwd(e, e->l1, Slab{e->xf[2], CE, nullptr, e->act_scale + e->c1[2].scale_i}, s));
     if (par) CHK(fork_join(e, b1, s));
     // decoder input (model.py:301-309 / 341-347)
     CodeSrc src[3];
@@ -1733,14 +1761,14 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
     if (par && !prio) CHK(fork_join(e, b2, b3));
     // encoder BLSTMs -> gradient of the last fused slab
     const bool early = par && !e->l2.big() && g_early_join;         // the join event of the lstm_2 branch is taken as soon as its last kernel is queued
-    CHK(lstm_bwd(e, e->l2, e->d_o2, Slab{e->xf[2] + off2, CE}, Slab{e->d_xf + off2, CE}, b2, (early || prio) ? e->ev_join[0] : nullptr, prio));
+    CHK(lstm_bwd(e, e->l2, e->d_o2, Slab{e->xf[2] + off2, CE, nullptr, e->act_scale + e->c2[2].scale_i}, Slab{e->d_xf + off2, CE}, b2, (early || prio) ? e->ev_join[0] : nullptr, prio));
     if (g3) {
-        CHK(lstm_bwd(e, e->l1, e->d_o1, Slab{e->xf[2], CE}, Slab{e->d_xf, CE}, s, nullptr, prio));
+        CHK(lstm_bwd(e, e->l1, e->d_o1, Slab{e->xf[2], CE, nullptr, e->act_scale + e->c1[2].scale_i}, Slab{e->d_xf, CE}, s, nullptr, prio));
         if (prio) HIPCHK(hipEventRecord(e->ev_join[3], s));                 // lstm_1's chain done: its weight gradients may start
     }
     if (!prio) {
         // Encoder_t
-        CHK(lstm_bwd(e, e->lt, e->d_ot, Slab{e->act_t, h.dim_enc_2}, Slab{e->d_act_t, h.dim_enc_2}, b3));
+        CHK(lstm_bwd(e, e->lt, e->d_ot, Slab{e->act_t, h.dim_enc_2, nullptr, e->act_scale + e->ct.scale_i}, Slab{e->d_act_t, h.dim_enc_2}, b3));
         CHK(conv_block_bwd(e, e->ct, Slab{e->d_act_t, h.dim_enc_2}, Slab{e->org, h.dim_freq}, Slab{nullptr, 0}, b3));
     }
     if (early || prio) HIPCHK(hipStreamWaitEvent(s, e->ev_join[0], 0));
@@ -1758,10 +1786,10 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
         // the resampled activations also exist as pre-split images when the forward's gathers wrote them (training, independent trunk chains)
         const float* bim = (training && e->xf_img_valid && i > 0) ? e->xf_img[i - 1] : nullptr;
         if (g3) {
-            Slab x1 = i == 0 ? Slab{e->in_mel, h.dim_freq} : Slab{e->xf[i - 1], CE, bim};
+            Slab x1 = i == 0 ? Slab{e->in_mel, h.dim_freq} : Slab{e->xf[i - 1], CE, bim, e->act_scale + e->c1[i - 1].scale_i};
             CHK(conv_block_bwd(e, e->c1[i], Slab{dy, CE}, x1, i > 0 ? Slab{dxbuf, CE} : Slab{nullptr, 0}, s));
         }
-        Slab x2 = i == 0 ? Slab{e->in_f0, e->f0p} : Slab{e->xf[i - 1] + off2, CE, bim ? bim + off2 : nullptr};
+        Slab x2 = i == 0 ? Slab{e->in_f0, e->f0p} : Slab{e->xf[i - 1] + off2, CE, bim ? bim + off2 : nullptr, e->act_scale + e->c2[i - 1].scale_i};
         CHK(conv_block_bwd(e, e->c2[i], Slab{dy + off2, CE}, x2, i > 0 ? Slab{dxbuf + off2, CE} : Slab{nullptr, 0}, s));
         if (!training && i > 0) {
             // eval mode has no resampling between layers: the next (lower) layer reads its output gradient from d_xf
@@ -1779,13 +1807,13 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
     }
     if (prio) {
         HIPCHK(hipStreamWaitEvent(b3, e->ev_join[0], 0));                   // lstm_2's pre-activation gradients (and the zeroed conv images)
-        CHK(lstm_late_weights(e, e->l2, Slab{e->xf[2] + off2, CE}, b3));
+        CHK(lstm_late_weights(e, e->l2, Slab{e->xf[2] + off2, CE, nullptr, e->act_scale + e->c2[2].scale_i}, b3));
         if (g3) {
             HIPCHK(hipStreamWaitEvent(b3, e->ev_join[3], 0));
-            CHK(lstm_late_weights(e, e->l1, Slab{e->xf[2], CE}, b3));
+            CHK(lstm_late_weights(e, e->l1, Slab{e->xf[2], CE, nullptr, e->act_scale + e->c1[2].scale_i}, b3));
         }
         HIPCHK(hipStreamWaitEvent(b3, e->ev_join[2], 0));                   // d_ot from dec_in_grad
-        CHK(lstm_bwd(e, e->lt, e->d_ot, Slab{e->act_t, h.dim_enc_2}, Slab{e->d_act_t, h.dim_enc_2}, b3));
+        CHK(lstm_bwd(e, e->lt, e->d_ot, Slab{e->act_t, h.dim_enc_2, nullptr, e->act_scale + e->ct.scale_i}, Slab{e->d_act_t, h.dim_enc_2}, b3));
         CHK(conv_block_bwd(e, e->ct, Slab{e->d_act_t, h.dim_enc_2}, Slab{e->org, h.dim_freq}, Slab{nullptr, 0}, b3));
     }
     if (par) CHK(fork_join(e, b3, s));
@@ -2062,8 +2090,9 @@ int ss_g3_rhythm(ss_engine* e, const float* x_org, int B, int T, float* codes, v
     tb.n = 0;
     CHK(lstm_prep(e, e->lt, tb, s));
     HIPCHK(prep_run(tb, s));
-    CHK(conv_block_fwd(e, e->ct, Slab{e->org, h.dim_freq}, Slab{e->act_t, h.dim_enc_2}, s));
-    CHK(lstm_fwd(e, e->lt, Slab{e->act_t, h.dim_enc_2}, s));
+    CHK(act_scales_all(e, s));
+    CHK(conv_block_fwd(e, e->ct, Slab{e->org, h.dim_freq}, Slab{e->act_t, h.dim_enc_2, nullptr, e->act_scale + e->ct.scale_i}, s));
+    CHK(lstm_fwd(e, e->lt, Slab{e->act_t, h.dim_enc_2, nullptr, e->act_scale + e->ct.scale_i}, s));
     // codes = cat(fwd[:, 7::8], bwd[:, ::8]) (model.py:84-87): reuse the decoder-input assembler on a 2H-wide row and pick t % freq == 0
     CodeSrc src{e->lt.out[0], nullptr, h.dim_neck_2, h.freq_2, 0};
     HIPCHK(build_dec_in(&src, 1, nullptr, 0, 2 * h.dim_neck_2, e->d_ot, 2 * h.dim_neck_2, B, T, s));

@@ -199,8 +199,8 @@ __global__ __launch_bounds__(WS ? 512 : 256, (NPL == 2 && !WS && !PROBE) ? 3 : 1
 
     typedef f32x4 Slot;
     // fp16 x 2 only: per-operand power-of-two scales (measured maximum or the fixed one), undone in the epilogue
-    const float sc_a = NPL == 2 ? ((d.flags & GEMM_A_PRE) ? (d.a_pre_scale ? *d.a_pre_scale : F16_SCALE) : (d.amax_a ? pow2_scale(*d.amax_a) : F16_SCALE)) : 1.0f;
-    const float sc_b = NPL == 2 ? ((d.flags & GEMM_B_PRE) ? (d.b_pre_scale ? *d.b_pre_scale : F16_SCALE) : (d.amax_b ? pow2_scale(*d.amax_b) : F16_SCALE)) : 1.0f;
+    const float sc_a = NPL == 2 ? (((d.flags & GEMM_A_PRE) || !d.amax_a) ? (d.a_pre_scale ? *d.a_pre_scale : F16_SCALE) : pow2_scale(*d.amax_a)) : 1.0f;
+    const float sc_b = NPL == 2 ? (((d.flags & GEMM_B_PRE) || !d.amax_b) ? (d.b_pre_scale ? *d.b_pre_scale : F16_SCALE) : pow2_scale(*d.amax_b)) : 1.0f;
     // full: the whole k-tile lies inside [kbeg, kend), so the load needs no predicate at all (rows / columns past the
     // matrix edge read row / column 0: their products land in accumulator entries the epilogue never stores).
     auto fetch = [&](const Operand& op, bool T, bool TRX, const float*& p, int& w, bool ok, int kpos, bool full) -> Slot {

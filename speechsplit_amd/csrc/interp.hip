@@ -71,7 +71,7 @@ __global__ __launch_bounds__(64) void interp_plan_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void interp_gather_kernel(const float* __restrict__ x, long x_ld, long x_bs,
                                                             float* __restrict__ y, long y_ld, long y_bs, int C, int P,
                                                             const int* __restrict__ i0, const float* __restrict__ lam,
-                                                            const int* __restrict__ nrows, float* __restrict__ y_img) {
+                                                            const int* __restrict__ nrows, float* __restrict__ y_img, const float* __restrict__ img_scale) {
     // y_img (nullable, launcher: only with C % 8 == 0 and 32-byte aligned rows): the pre-split image of y for the GEMMs that read it
     const int r = blockIdx.x, b = blockIdx.y;
     float* yr = y + b * y_bs + r * y_ld;
@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void interp_gather_kernel(const float* __restr
     const float* xa = x + b * x_bs + (long)i * x_ld;
     const float* xb = xa + x_ld;
     if (yi) {
+        const float isc = img_scale ? *img_scale : 16.0f;
         for (int c = 4 * threadIdx.x; c < C; c += 4 * blockDim.x) {
             const float4 a = *reinterpret_cast<const float4*>(xa + c), bb = *reinterpret_cast<const float4*>(xb + c);
             float4 v;
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void interp_gather_kernel(const float* __restr
             v.z = __fadd_rn(__fmul_rn(ol, a.z), __fmul_rn(l, bb.z));
             v.w = __fadd_rn(__fmul_rn(ol, a.w), __fmul_rn(l, bb.w));
             *reinterpret_cast<float4*>(yr + c) = v;
-            ss_store_group(yi + c, ss_split_group(v.x, v.y, v.z, v.w));
+            ss_store_group(yi + c, ss_split_group_s(v.x, v.y, v.z, v.w, isc));
         }
         return;
     }
@@ -174,11 +175,11 @@ hipError_t interp_plan(const InterpPlan& p, const float* scales, const int* len_
 }
 
 hipError_t interp_gather(const InterpPlan& p, const float* x, long x_ld, long x_bs, float* y, long y_ld, long y_bs, int C,
-                         int B, hipStream_t s, float* y_img) {
+                         int B, hipStream_t s, float* y_img, const float* img_scale) {
     if (y_img && (C % 8 || x_ld % 4 || y_ld % 8 || x_bs % 4 || y_bs % 8 || (((size_t)x | (size_t)y) & 15) || (((size_t)y_img) & 31))) y_img = nullptr;     // image format v2: groups of eight
     const int threads = y_img ? (C >= 512 ? 128 : 64) : (C >= 256 ? 256 : (C >= 128 ? 128 : 64));
     hipLaunchKernelGGL(interp_gather_kernel, dim3(p.P, B), dim3(threads), 0, s, x, x_ld, x_bs, y, y_ld, y_bs, C, p.P, p.i0,
-                       p.lam, p.nrows, y_img);
+                       p.lam, p.nrows, y_img, img_scale);
     return hipGetLastError();
 }
 

@@ -26,8 +26,9 @@ struct InterpPlan {
 hipError_t interp_plan(const InterpPlan& p, const float* scales, const int* len_seg, const int* len_seq,
                        int len_seq_const, int B, hipStream_t s);
 // y_img (nullable): also write the pre-split image of y (GemmDesc::a_pre), same geometry as y
+// img_scale (nullable: 16): device word with the power-of-two scale the image is split with (act_scales)
 hipError_t interp_gather(const InterpPlan& p, const float* x, long x_ld, long x_bs, float* y, long y_ld, long y_bs, int C,
-                         int B, hipStream_t s, float* y_img = nullptr);
+                         int B, hipStream_t s, float* y_img = nullptr, const float* img_scale = nullptr);
 hipError_t interp_quant(const InterpPlan& p, const float* mel, const float* f0, int CM, float* ymel, long ym_ld, long ym_bs,
                         float* yoh, long yo_ld, long yo_bs, int NOH, int* qidx, int B, hipStream_t s);
 hipError_t interp_scatter(const InterpPlan& p, const float* dy, long dy_ld, long dy_bs, float* dx, long dx_ld, long dx_bs,
@@ -117,6 +118,17 @@ hipError_t adam_step(float* p, const float* g, float* m, float* v, long n, AdamS
                      const float* status, hipStream_t s);
 // *status = (*sticky != 0)   (one thread; enqueued behind the decoder's recurrences, in front of the all-reduce that sums it)
 hipError_t status_publish(const unsigned* sticky, float* status, hipStream_t s);
+// Scale of the fp16 x 2 split for the OUTPUT of each conv block (GroupNorm + ReLU, then resampled: a convex combination), from its affine
+// parameters: |y| <= sqrt(16 T) max|gamma| + max|beta| = bound; out[i] = min(16, largest power of two with bound * scale <= 32768).
+// 16 -- the scale every other forward operand uses -- whenever bound <= 2048, i.e. for any sane GroupNorm affine.
+constexpr int ACT_SCALE_MAX = 8;
+struct ActScaleTable {
+    const float* gamma[ACT_SCALE_MAX];
+    const float* beta[ACT_SCALE_MAX];
+    int C[ACT_SCALE_MAX];
+    int n;
+};
+hipError_t act_scales(const ActScaleTable& tb, int T, float* out, hipStream_t s);
 // sticky |= SS_STICKY_RANGE if any of the n parameters is not finite or |p| >= limit
 hipError_t param_guard(const float* p, long n, float limit, unsigned* sticky, hipStream_t s);
 

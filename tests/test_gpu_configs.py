@@ -117,7 +117,7 @@ def check_fp32_step(r, tag):
 
 def check_adam(r, tag, step):
     """(a) the engine's update == torch.optim.Adam's single-tensor formulas on the engine's own gradients (first step only:
-    moments start at zero); (b) against the oracle's weights: hard bound 2.1 * lr, at most 0.1 % of a tensor beyond 1e-4 * max|p|."""
+    moments start at zero); (b) against the oracle's weights: hard bound 2.1 * lr, at most 2e-5 of a tensor's elements (or 2) beyond 1e-4 * max|p|."""
     tot, off = 0, 0
     for n, pc in r['p_cpu'].items():
         pa, pb, g = r['p_after'][n].double(), r['p_before'][n].double(), r['grads_gpu'][n].double()
@@ -132,7 +132,7 @@ def check_adam(r, tag, step):
         bad = int((d > TOL * amax).sum())
         tot += d.numel()
         off += bad
-        assert bad <= max(2, 1e-3 * d.numel()), (tag, n, bad, d.numel())
+        assert bad <= max(2, 2e-5 * d.numel()), (tag, n, bad, d.numel())      # measured: 0 of 19.4 M (round 2); 2e-5 leaves room for the sign of a ~0 gradient
     print(f'[{tag}] post-Adam weights: {off} of {tot} elements beyond 1e-4 * max|p| of their tensor (sign of a ~0 gradient)')
 
 
@@ -153,6 +153,52 @@ def test_g3_fp32_config_shapes(E, shape):
     assert np.array_equal(c.eng.debug_buffer('in.mel', B, T).cpu().numpy(), xi[:, :, :80].numpy())
     cls = c.eng.debug_buffer('in.f0', B, T)[:, :, :257].argmax(-1).cpu().numpy()
     assert np.array_equal(cls, interp_np.quantize_f0(xi[:, :, -1].numpy()))
+
+
+# --------------------------------------------------------------------------------------------- parity away from initialisation
+@pytest.mark.parametrize('case', [('G3', 64, 128, 64, 1000), ('G6', 32, 192, 96, 600)], ids=['g3_64x128_1000steps', 'g6_32x192_600steps'])
+def test_trained_state_step_matches_oracle(E, case):
+    """Round-2 review: every oracle comparison ran on near-initialisation weights, while the fp16 x 2 arithmetic leans on operand-range
+    assumptions.  Here the ENGINE trains for N steps on a rotating set of batches (weights, Adam moments and the step counter all far
+    from their start), the whole state -- weights, exp_avg, exp_avg_sq, step -- is handed to the oracle's TrainState, and one further step
+    is compared at the standing bars: loss 1e-5, output and every gradient element 1e-4, post-Adam weights."""
+    kind, B, T, len_lo, steps = case
+    c = Case(E, kind, B, T, len_lo, wseed=3, bseed=1300 + B)
+    eng = c.eng
+    batches = [synth_batch(1400 + i, B, T, len_lo) for i in range(4)]
+    loss0 = lossN = None
+    for i in range(steps):
+        mel, f0, emb, lens = batches[i % 4]
+        d = stack_draws(draws_for(20000 + i, B, c.ncalls))
+        if kind == 'G3':
+            loss = eng.g3_train_step(mel, f0, emb, lens, d)
+        else:
+            q = torch.from_numpy(interp_np.quantize_f0(f0[:, :, 0].numpy()))
+            loss = eng.g6_train_step(mel, torch.nn.functional.one_hot(q, 257).float(), q, d)
+        if i == 0:
+            loss0 = float(loss)
+    eng.check()
+    lossN = float(loss)
+    assert lossN < 0.7 * loss0, (loss0, lossN)                 # it did train
+    pv = {n: v.clone().cpu() for n, v in eng.param_views().items()}
+    moved = max(float((pv[n] - p.detach()).abs().max()) for n, p in c.st.P.items())
+    assert moved > 0.02, moved                                 # far from the initial weights (lr * steps = 0.06 .. 0.1 at most)
+    c.st = ref_model.TrainState({n: v.numpy() for n, v in pv.items()}, LR)
+    c.st.load_adam({n: v.cpu().numpy() for n, v in eng.views(eng.adam_m).items()}, {n: v.cpu().numpy() for n, v in eng.views(eng.adam_v).items()}, steps)
+    r = c.step(steps)
+    tag = f'{kind} {B}x{T} after {steps} engine steps (loss {loss0:.4f} -> {lossN:.4f}, weights moved by up to {moved:.3f})'
+    check_fp32_step(r, tag)
+    # one Adam step from the SAME state on both sides
+    tot = off = 0
+    for n, pc in r['p_cpu'].items():
+        pa, pb = r['p_after'][n].double(), r['p_before'][n].double()
+        d = (pa - pc.double()).abs()
+        assert float(d.max()) <= 2.1 * LR, (tag, n, float(d.max()))
+        bad = int((d > TOL * float(pb.abs().max())).sum())
+        tot += d.numel()
+        off += bad
+        assert bad <= max(2, 2e-5 * d.numel()), (tag, n, bad, d.numel())
+    print(f'[{tag}] post-Adam weights: {off} of {tot} elements beyond 1e-4 * max|p| of their tensor')
 
 
 # --------------------------------------------------------------------------------------------- fp32, Generator_6 (config 4's shape)

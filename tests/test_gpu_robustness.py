@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import weights as W
+from oracle import ref_model, weights as W
 from oracle.gen_fixtures import draws_for, synth_batch
 
 pytestmark = pytest.mark.gpu
@@ -16,6 +16,12 @@ pytestmark = pytest.mark.gpu
 def E():
     from speechsplit_amd import engine
     return engine
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
 def stack_draws(draws):
@@ -95,16 +101,51 @@ def test_remote_abort_reaches_every_rank_through_the_status_slot(E):
     assert not torch.equal(eng.params, p0)
 
 
+def test_large_groupnorm_affine_trains_in_the_default_mode(E):
+    """Round-2 review: a GroupNorm gamma of 100 made the default (fp16 x 2) engine refuse every step.  The conv blocks' outputs now carry
+    their own split scale, computed on the device from the block's affine parameters, so such weights train in the default mode and match
+    the oracle at the standing 1e-4 bars: loss, output, every gradient element, two Adam steps."""
+    B, T = 4, 128
+    hp = W.default_hparams(max_len_pad=T)
+    w = W.make_weights('G3', hp, 7)
+    w['encoder_1.convolutions_1.1.1.weight'][3] = 100.0        # gamma of one channel of a 512-channel block
+    w['encoder_1.convolutions_2.0.1.weight'][:] *= 300.0       # a whole block's gamma: its output scale drops below 16
+    w['encoder_2.convolutions.0.1.bias'][5] = -40.0
+    eng = E.Engine('G3', hp, B, T)
+    eng.load_weights(w)
+    eng.set_adam(1e-4, 0.9, 0.999, 1e-8, 0)
+    st = ref_model.TrainState(w)
+    for it in range(2):
+        mel, f0, emb, lens = synth_batch(50 + it, B, T, 64)
+        draws = draws_for(60 + it, B, 4)
+        loss = eng.g3_train_step(mel, f0, emb, lens, stack_draws(draws), no_adam=True)
+        eng.check()
+        assert eng.status() == 0
+        out = eng.debug_buffer('out', B, T).cpu()
+        grads = {n: v.clone().cpu() for n, v in eng.grad_views().items()}
+        masks = {k: v.cpu() for k, v in eng.relu_masks(B, T).items()}
+        eng.adam_step()
+        ref_model.MASK, ref_model.MASK_STATS = masks, {}
+        try:
+            lo, ro = st.step_g3(hp, mel, f0, emb, lens.numpy(), draws)
+        finally:
+            ref_model.MASK, ref_model.MASK_STATS = None, None
+        assert abs(float(loss) - float(lo)) <= 1e-5 * float(lo), (it, float(loss), float(lo))
+        assert rel(out, ro) < 1e-4, it
+        worst = max((rel(grads[n], p.grad), n) for n, p in st.P.items())
+        assert worst[0] < 1e-4, (it, worst)
+
+
 def test_parameter_outside_fp16x2_range_is_refused(E):
-    """The forward contractions scale their operands by a FIXED 16 before the fp16 x 2 split: a weight >= 4094 would become inf.
-    The engine refuses long before (|p| >= 64, which also bounds the GroupNorm outputs): status RANGE, no update; with
-    ss_tune("fwd_f16x2", 0) + ("bwd_f16x2", 0) (bf16 x 3 products, fp32 exponent range) the same weights train."""
+    """The contractions scale WEIGHTS by a fixed 16 before the fp16 x 2 split: a weight >= 4094 would become inf.  The engine refuses
+    long before (|p| >= 2048, or a non-finite parameter): status RANGE, no update; with ss_tune("fwd_f16x2", 0) + ("bwd_f16x2", 0)
+    (bf16 x 3 products, fp32 exponent range) the same weights train."""
     B, T = 4, 128
     eng = fresh(E, B, T)
     mel, f0, emb, lens = synth_batch(5, B, T, 64)
     d = stack_draws(draws_for(6, B, 4))
     pv = eng.param_views()
-    pv['encoder_1.convolutions_1.1.1.weight'][3] = 100.0       # a GroupNorm gamma nobody would call unreasonable
+    pv['decoder.lstm.weight_ih_l1'][3, 7] = 3000.0
     p0 = eng.params.clone()
     eng.g3_train_step(mel, f0, emb, lens, d)
     torch.cuda.synchronize()
