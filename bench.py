@@ -125,25 +125,31 @@ def kernel_report(eng, steps, ms_step, precision, top, survey, T):
     ach = fl / us / 1e6
     peak = PEAK_16BIT_MFMA_TFLOPS / mfmas[top]
     names = {'dec_dw': 'gemm_bf16x3_kernel<128,128,TN> split-K: decoder weight gradients dW_ih / dW_hh (12 launches per step, beside the encoder backward)',
-             'dec_proj': 'gemm_bf16x3_kernel<128,128,NT>: decoder input projection, layers 1-2',
+             'dec_proj': 'gemm_img_kernel<128,64,2,4,NT> (256 x 256 tiles, LDS-DMA ring): decoder input projection, layers 1-2',
              'dec_dx': 'gemm_bf16x3_kernel<128,128,NN>: decoder input gradients',
-             'conv_fwd': 'gemm_bf16x3_kernel<.,.,NT> segmented-K: conv trunk forward',
+             'conv_fwd': 'gemm_img_kernel<64,64,.,.,NT> segmented-K: conv trunk forward (layer 0: gemm_bf16x3_kernel)',
              'conv_dw': 'gemm_bf16x3_kernel<.,.,TN> split-K: conv weight gradients',
-             'conv_dx': 'gemm_bf16x3_kernel<.,.,NT> segmented-K: conv input gradients'}
-    traffic = None
-    try:      # HBM bytes per launch from the separate rocprofv3 --pmc passes kept under profiles/ (tools/pmc_summary.py)
-        recs = [r for r in json.load(open(os.path.join(ROOT, 'profiles', 'r02', 'gemm_pmc.json'))) if r.get('class') == top]
-        if recs:      # mean over the shapes of the class (dec_dw: dW_ih and dW_hh, six launches each per step)
-            traffic = sum(r['hbm_read_bytes'] + r['hbm_write_bytes'] for r in recs) / len(recs)
-    except Exception:
-        pass
+             'conv_dx': 'gemm_img_kernel<64,64,.,.,NT> segmented-K: conv input gradients'}
+    traffic, traffic_source = None, None
+    for rnd in ('r03', 'r02'):      # HBM bytes per launch: NOT measured in this run -- from the separate rocprofv3 --pmc passes kept under profiles/ (tools/pmc_summary.py)
+        try:
+            path = os.path.join('profiles', rnd, 'gemm_pmc.json')
+            recs = [r for r in json.load(open(os.path.join(ROOT, path))) if r.get('class') == top]
+            if recs:      # mean over the shapes of the class (dec_dw: dW_ih and dW_hh, six launches each per step)
+                traffic = sum(r['hbm_read_bytes'] + r['hbm_write_bytes'] for r in recs) / len(recs)
+                traffic_source = f'{path} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gemm_pmc.py with the gfx950 correction; a profile figure, not measured in this run)'
+                break
+        except Exception:
+            pass
     roof = {'bound': 'mfma', 'kernel': names.get(top, top), 'class': top, 'achieved': round(ach, 2), 'peak': round(peak, 1),
             'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
             'peak_basis': f'dense 16-bit MFMA {PEAK_16BIT_MFMA_TFLOPS:.0f} TFLOP/s / {mfmas[top]} MFMA products per fp32 multiply-add',
             'mfma_tflops_executed': round(mfmas[top] * ach, 1), 'fp32_mfma_peak': PEAK_F32_MFMA_TFLOPS,
             'vs_fp32_mfma_peak': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'launches_timed': n,
             'flops_per_launch': round(fl / n), 'us_per_launch': round(us / n, 2),
-            'share_of_bracketed_gpu_time': round(survey[0][top][1] / sum(v[1] for v in survey[0].values()), 3), 'traffic': traffic}
+            'share_of_bracketed_gpu_time': round(survey[0][top][1] / sum(v[1] for v in survey[0].values()), 3), 'traffic': traffic,
+            'traffic_source': traffic_source,
+            'flops_basis': 'algorithmic: reductions and stored rows over the B x T real frames (halo rows of the slabs not counted)'}
     recur = None
     if 'rec_fwd' in rec and 'rec_bwd' in rec:
         nf, uf, _ = rec['rec_fwd']
@@ -232,7 +238,7 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     eng.set_adam(1e-4, 0.9, 0.999, 1e-8, 0)
     eng.set_precision(args.precision)
-    native = dp and args.dp_backend == 'native' and kind == 'G3'
+    native = dp and args.dp_backend == 'native'             # the engine's own RCCL communicator, both generators (round 3: ss_g6_dp_train_step)
     if native:
         eng.comm_init(rank, world)
     mel, f0, emb, lens = synth(B, T, 1000 + rank, dev)
@@ -245,6 +251,7 @@ def main():
         onehot, qidx = onehot.contiguous(), qidx.to(torch.int32).contiguous()
     stream = None
     frames_done = [0]
+    timed_frames = [0]
     if args.workload == 'config5':
         from speechsplit_amd import buckets, data_loader, staging
         corpus = data_loader.DeviceCorpus(data_loader.SyntheticUtterances(4 * B, seed=7 + rank), dev)
@@ -267,7 +274,9 @@ def main():
             else:
                 eng.g3_train_step(bm, bf, be, bl, (sc, ls), bucket=True)
         elif kind == 'G6':
-            if dp:
+            if native:
+                eng.g6_dp_train_step_native(mel, onehot, qidx, (sc, ls))
+            elif dp:
                 eng.dp_g6_train_step(mel, onehot, qidx, (sc, ls), world)
             else:
                 eng.g6_train_step(mel, onehot, qidx, (sc, ls))
@@ -290,11 +299,13 @@ def main():
         barrier()
         if profile:
             eng.profile(profile)
+        f0_ = frames_done[0]
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         barrier()
         dt = time.perf_counter() - t0
+        timed_frames[0] = frames_done[0] - f0_          # frames of the batches of THIS timed region (config 5: their lengths vary)
         if profile:
             eng.profile(False)
         if dist is not None:
@@ -314,10 +325,11 @@ def main():
     eng.check()                  # outside the timed region: no persistent kernel reported a bounded-wait expiry
     ms = dt / args.steps * 1e3
     value = B * world / (dt / args.steps)
+    mean_T = timed_frames[0] / max(1, args.steps) if stream is not None else T      # config 5: mean frames per batch over the timed batches only
 
     if rank == 0:
         print(f'[bench] gpu: {ms:.3f} ms/step, {value:.1f} utt/s on {world} GPU(s)', file=sys.stderr, flush=True)
-        roof, classes, recur = kernel_report(eng, args.steps, ms, args.precision, top, survey, T if stream is None else frames_done[0] / max(1, args.steps + args.warmup + 8)) if top else (None, None, None)
+        roof, classes, recur = kernel_report(eng, args.steps, ms, args.precision, top, survey, T if stream is None else mean_T) if top else (None, None, None)
         print(f'[bench] roofline: {roof}', file=sys.stderr, flush=True)
     alt = None
     if not args.no_extras and args.precision == 'f32' and kind == 'G3' and args.workload == 'fixed':
@@ -326,7 +338,16 @@ def main():
         for name, knobs in (('bf16x3_exact_split_ms', {'fwd_f16x2': 0, 'bwd_f16x2': 0}), ('fp32_mfma_ms', {'gemm_mode': 0})):
             for k, v in knobs.items():
                 tune(k, v)
-            alt[name] = round(timed(8, 2, False) / 8 * 1e3, 3)
+            prof = [top] if (name.startswith('bf16x3') and top and not args.no_profile) else False
+            alt[name] = round(timed(8, 2, prof) / 8 * 1e3, 3)
+            if prof and rank == 0:      # the fp32-grade headline (exact 3-way split, 6 MFMAs per product) with a roofline of its own
+                r2 = eng.profile_read()
+                if r2 and top in r2:
+                    n2, us2, fl2 = r2[top]
+                    alt['bf16x3_exact_split'] = {'ms_per_step': alt[name], 'utterances_per_s': round(B * world / alt[name] * 1e3, 1),
+                                                 'roofline': {'bound': 'mfma', 'class': top, 'achieved': round(fl2 / us2 / 1e6, 2), 'peak': round(PEAK_16BIT_MFMA_TFLOPS / 6, 1),
+                                                              'unit': 'TFLOP/s', 'frac': round(fl2 / us2 / 1e6 / (PEAK_16BIT_MFMA_TFLOPS / 6), 4), 'launches_timed': n2,
+                                                              'us_per_launch': round(us2 / n2, 2), 'peak_basis': 'dense 16-bit MFMA 2500 TFLOP/s / 6 MFMA products per fp32 multiply-add'}}
             for k in knobs:
                 tune(k, 1)
         eng.check()
@@ -345,16 +366,16 @@ def main():
             'metric': 'utterances/sec (fwd+bwd, 128-frame 80-mel, batch 64) at 1/2/4/8 MI355X',
             'value': round(value, 1), 'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': args.precision, 'data': 'synthetic',
+            'dtype': 'f32 (fp16x2 products)' if args.precision == 'f32' else 'bf16 products (fp32 storage)', 'data': 'synthetic',
             'config': {'workload': (f'Generator_3 full training step (host draws+resample+quantise+fwd+MSE+bwd+Adam), '
                                     f'{B} utterances/GPU x {T} frames x 80 mel + F0, max_len_pad={T}' if kind == 'G3' and args.workload == 'fixed' else
                                     f'Generator_3 full training step over length-bucketed batches (BASELINE config 5): crops of 96..192 frames, one bucket '
-                                    f'(multiple of 8) per batch, max_len_pad = bucket, {B} utterances/GPU, mean {frames_done[0] / max(1, args.steps + args.warmup + (8 if not args.no_profile else 0)):.1f} frames/batch, '
+                                    f'(multiple of 8) per batch, max_len_pad = bucket, {B} utterances/GPU, mean {mean_T:.1f} frames/batch in the timed region, '
                                     f'batches assembled on the GPU + DevicePrefetcher inside the timed region' if kind == 'G3' else
                                     f'Generator_6 full training step (host draws+fwd+cross-entropy+bwd+Adam; BASELINE config 4 shape), {B} utterances/GPU x {T} frames'),
                        'global_batch': B * world, 'seq_len': T, 'parallelism': f'dp{world}' + (' (forced DP path)' if args.force_dp and world == 1 else '') + (f', {args.dp_backend} RCCL' if dp else ''),
                        'products': PRODUCTS[args.precision]},
-            'step_tflops': round(3 * 2 * (MAC_PER_FRAME_G3 if kind == 'G3' else MAC_PER_FRAME_G6) * (T if args.workload == 'fixed' else 144) * B * world / (dt / args.steps) / 1e12, 2),
+            'step_tflops': round(3 * 2 * (MAC_PER_FRAME_G3 if kind == 'G3' else MAC_PER_FRAME_G6) * mean_T * B * world / (dt / args.steps) / 1e12, 2),
             'roofline': roof, 'kernel_classes': classes, 'recurrence': recur, 'alt_precisions': alt,
             'solver_loop': sl,
             'cpu_baseline': None if args.no_cpu_baseline else cpu_baseline(T),

@@ -123,12 +123,19 @@ int ss_comm_destroy(ss_engine* e);
 /* in-place sum over the ranks of grads[offset, offset + count) (floats), enqueued on `stream` */
 int ss_allreduce_grads(ss_engine* e, long offset, long count, void* stream);
 /* The whole data-parallel step on this rank's shard (utterances [rank*B, (rank+1)*B) of the global batch and the matching
- * slices of the draws): forward, decoder backward, all-reduce of the head + decoder bucket (arena offsets >= ss_grad_split(),
- * 80 % of the bytes, incl. the status slot) ON the engine stream that carries the decoder's weight-gradient GEMMs -- so it
- * runs beside the encoder backward --, encoder backward, all-reduce of the encoder bucket, Adam with the 1/world mean folded
- * in.  flags: 0 or SS_STEP_BUCKET (every rank passes the same T).  loss: this rank's local mean loss. */
+ * slices of the draws): the one-GPU step with the gradient arena all-reduced in BUCKETS on a communication stream of the engine's
+ * own while the backward is still running -- each decoder layer (25 / 25 / 11 MB for Generator_3) as soon as its weight-gradient
+ * GEMMs have retired (layer 2 first; they run beside the encoder backward), the head, the two wide layers of the conv trunk as the
+ * trunk's backward passes them, and last the few MB that are final only at the end (layer-0 convolutions, encoder BLSTMs, Encoder_t,
+ * the status slot); then Adam with the 1/world mean folded in.  flags: 0 or SS_STEP_BUCKET (every rank passes the same T).  loss: this
+ * rank's local mean loss.  ss_g6_dp_train_step: the same for Generator_6 (cross-entropy step of ss_g6_train_step).
+ * ss_tune("dp_model", R) MODELS an R-rank run on one GPU without a communicator: every collective is replaced by a stand-in kernel of
+ * the modelled duration (ring all-reduce over one 153 GB/s xGMI link + 25 us), so a kernel trace shows where each bucket would sit
+ * (tools/dp_timeline.sh); ss_tune("dp_buckets", 0) restores round 2's two buckets behind the whole backward. */
 int ss_g3_dp_train_step(ss_engine* e, const float* mel_dev, const float* f0_dev, const float* emb_dev, const int* len_org_dev,
                         const float* scales_dev, const int* len_seg_dev, int B, int T, int flags, float* loss_dev, void* stream);
+int ss_g6_dp_train_step(ss_engine* e, const float* mel_dev, const float* f0_onehot_dev, const int* target_idx_dev, const float* scales_dev,
+                        const int* len_seg_dev, int B, int T, int flags, float* loss_dev, void* stream);
 
 /* torch.optim.Adam(G.parameters(), lr, [beta1, beta2]) (solver.py:62,172).  `step` = updates already applied. */
 int ss_set_adam(ss_engine* e, double lr, double beta1, double beta2, double eps, long step, void* stream);
@@ -230,13 +237,13 @@ int ss_op_conv_block(const float* x_dev, const float* w_dev, const float* bias_d
  * comparison of gradients does not depend on that coin flip. */
 int ss_debug_relu_mask(ss_engine* e, const char* block, float* mask_dev, void* stream);
 /* tuning knobs (process-global; every value leaves the results correct): "lstm_nw" 4|8|16, "lstm_g" 0..16, "gemm_bk" 16|32,
- * "gemm_want" >= 1, "overlap" 0|1, "graph" 0|1, "persist" 0|1, "split" 0|1, "gemm_mode" 0 (fp32 MFMA) | 1 (split arithmetic on
+ * "gemm_want" >= 1, "overlap" 0|1, "persist" 0|1, "split" 0|1, "gemm_mode" 0 (fp32 MFMA) | 1 (split arithmetic on
  * the 16-bit pipe), "fwd_f16x2" / "bwd_f16x2" 0|1 (fp16 x 2 instead of bf16 x 3 for the forward / the scaled gradient
  * contractions), "seq_spin_log2" 0..24 (log2 of the persistent kernels' bounded wait; 0 makes it expire at once -- how the
  * tests exercise the abort path), "deterministic" 0|1, "seq_tag" 0|1 (forward persistent recurrence: step tag in the hand-off
  * payload where every group sits on one XCD | always the flag line), "seq_wlead" 0..31 (backward persistent recurrence: steps
  * between a warm-up read and the operand request it serves, 0 = the kernel's default), "gemm_ws" 0|1|2 (wave-specialised form of
- * the 128 x 128 fp16 x 2 GEMM: never | where it measured faster in isolation | always), "presplit" 0..7 (pre-split operand images for the fp16 x 2 GEMMs: bit 0 weights, bit 1 decoder hidden states, bit 2 trunk
+ * the 128 x 128 fp16 x 2 GEMM: never | where it measured faster in isolation | always), "img" 0|1 and "img_mask" (bit = SS_PROF_* class: which contractions run on the image GEMM, csrc/gemm_img.hip; default decoder projections, conv forward, conv input gradients), "dp_model" 0|2..64 and "dp_buckets" 0|1 (data-parallel schedule, see ss_g3_dp_train_step), "presplit" 0..15 (operand images for the fp16 x 2 GEMMs: bit 0 weights, bit 1 decoder hidden states, bit 2 trunk
  * activations), "compact0" 0|1 (decoder layer 0 on one row per block of repeated input frames), "trunk_indep" 0|1, "batch_dirs" 0..2,
  * "prewarm" 0..3 (streaming pre-read of a decoder layer's operand slabs on a side stream beside its
  * persistent recurrence: bit 1 forward, bit 0 backward), "op_time_major" 0|1 (ss_op_lstm_fwd / _bwd

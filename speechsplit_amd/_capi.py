@@ -51,6 +51,7 @@ SYMBOLS = {
     'ss_comm_destroy': (_i, [_vp]),
     'ss_allreduce_grads': (_i, [_vp, _l, _l, _vp]),
     'ss_g3_dp_train_step': (_i, [_vp, _fp, _fp, _fp, _ip, _fp, _ip, _i, _i, _i, _fp, _vp]),
+    'ss_g6_dp_train_step': (_i, [_vp, _fp, _fp, _ip, _fp, _ip, _i, _i, _i, _fp, _vp]),
     'ss_set_adam': (_i, [_vp, _d, _d, _d, _d, _l, _vp]),
     'ss_adam_step': (_i, [_vp, _f, _vp]),
     'ss_zero_grads': (_i, [_vp, _vp]),

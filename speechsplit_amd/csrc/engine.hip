@@ -9,6 +9,9 @@
 #include <map>
 #include <string>
 #include <vector>
+#include <algorithm>
+#include <utility>
+#include <functional>
 #include <cstring>
 #include <cstdio>
 
@@ -39,6 +42,9 @@ int g_img_mask = (1 << SS_PROF_DEC_PROJ) | (1 << SS_PROF_CONV_FWD) | (1 << SS_PR
 int g_img_batch = 1;       // image GEMM: the decoder's weight gradients of both directions in one launch per matrix
 int g_img_dw_cfg = -1;     // experiment: tile configuration of the split-K (weight-gradient) image GEMMs (-1: the rule in try_img_gemm)
 int g_img_dw_wgs = 256;    // ... and the number of workgroups their split aims at
+int g_dp_model = 0;        // > 1: MODEL a data-parallel run of that many ranks on one GPU: every collective is replaced by a stand-in kernel of
+                           // the modelled duration (tools/dp_timeline.sh); no communicator needed
+int g_dp_buckets = 1;      // 1: per-layer gradient buckets on the communication stream; 0: round 2's two buckets
 int g_cur_klass = -1;      // profile class of the contraction being launched (set by the PGEMM macros)
 int g_presplit = 7;        // weights (and, bit 1, the decoder's hidden states) reach the fp16 x 2 GEMMs as pre-split images: bit 0 weights, bit 1 the decoder's hidden states, bit 2 the trunk's resampled activations
 int g_compact0 = 1;        // decoder layer 0: input projections, input gradient and W_ih gradient once per block of repeated input frames
@@ -50,8 +56,19 @@ int g_op_time_major = 0;   // experiment: ss_op_lstm_fwd / _bwd take time-major 
 int g_persist = 1;     // 1: decoder recurrences run as ONE persistent launch per layer (lstm_seq.hip) when the batch fits
 int g_split = 0;       // 1: decoder recurrences run as two batch-half chains on two streams (GEMMs of one half fill the
                        //    machine while the other half sits in its latency-bound time loop)
-int g_graph = 0;       // 1: the fused training step is captured into a hipGraph and replayed (measured: no gain while the
-                       // step is GPU-bound at batch 64; useful when the host is the bottleneck)
+// hipGraph capture + replay of the fused training step (ss_tune("graph", 1)): measured no gain while the step is GPU-bound, and under
+// ROCm 7.2 hipGraphLaunch crashed inside the RUNTIME (hip::Graph::UpdateStreams <- hip::GraphExec::Run, gpurun_out/r02/gdb.txt) when the
+// captured step had one more parallel branch and the process had created other engines before.  Round 3 went through the engine's side
+// of that: every executable graph is destroyed (after a synchronise) BEFORE any stream of its engine (drop_graphs first in ss_destroy
+// and on every geometry / tuning change), a captured graph holds kernel nodes and edges, not the capture streams, and the streams the
+// probe destroys at ss_bind never took part in a capture -- nothing of ours outlives what it refers to; the faulting access is in the
+// runtime's own per-launch stream assignment.  The schedule is therefore NOT part of the product library: it exists in the -DSS_DIAG
+// build only (tools/host_enqueue.py), where g_graph is a variable; here it is the constant 0 and the capture path compiles away.
+#ifdef SS_DIAG
+int g_graph = 0;
+#else
+constexpr int g_graph = 0;
+#endif
 int g_own_streams = 0; // 1: every C-ABI call runs on the ENGINE's own main stream (created back to back with its three branch streams at
                        //    ss_bind), ordered behind the caller's stream on entry and in front of it on exit.  Built to make the step time
                        //    independent of how many streams the process created earlier -- it does not: HIP hands a new stream the
@@ -168,6 +185,11 @@ struct ss_engine {
                                            // all-reduce sums it, so every rank's Adam kernel sees a non-zero value and skips
     void* comm = nullptr;                  // ncclComm_t of ss_comm_init (RCCL, dlopen'd)
     int comm_rank = 0, comm_world = 1;
+    // data-parallel step in flight: gradient ranges are all-reduced on comm_s as soon as their producers are through (dp_bucket)
+    bool dp_on = false;
+    hipStream_t comm_s = nullptr;
+    hipEvent_t ev_comm = nullptr;
+    std::vector<std::pair<long, long>> dp_done;      // [offset, end) ranges already handed to a collective in this step
     bool lockstep = false;                 // data-parallel member: entry points never refuse on the status word (entry_check)
     unsigned* sticky = nullptr;            // engine status word in host-coherent pinned memory (kernels.h SS_STICKY_*): written by
                                            // kernels, read by the host without synchronising; cleared only by ss_clear_abort
@@ -660,6 +682,10 @@ int gemm_on(ss_engine* e, GemmDesc& d, hipStream_t st) {
         GEMM_ON(d, st);                                 \
     } while (0)
 
+// Data parallel: the gradient range [off, off + count) is final once everything enqueued on `producer` so far has run -- hand it to a
+// collective on the communication stream right away.  No-op outside a data-parallel step.
+int dp_bucket(ss_engine* e, long off, long count, hipStream_t producer);
+
 // make `to` wait for everything enqueued on `from` so far
 int fork_join(ss_engine* e, hipStream_t from, hipStream_t to) {
     hipEvent_t ev = e->ev[e->ev_next];
@@ -736,13 +762,13 @@ bool same_queue(hipStream_t a, hipStream_t b, hipEvent_t ea, hipEvent_t eb0, hip
     // poll (a blocking wait may wake up later than the spin lasts): b's kernel finished -- had a's spin finished by then?  On separate
     // queues b is done after a few microseconds and the spin is not.
     bool spin_done = false;
-    for (;;) {
+    for (long polls = 0;; ++polls) {
         const bool a_done = hipEventQuery(ea) == hipSuccess;
         if (hipEventQuery(eb1) == hipSuccess) {
             spin_done = a_done;
             break;
         }
-        if (a_done) {              // the spin ended first: b was held up behind it
+        if (a_done || polls > 20000000L) {              // the spin ended first: b was held up behind it (or the device does not answer: count it as shared)
             spin_done = true;
             break;
         }
@@ -750,13 +776,30 @@ bool same_queue(hipStream_t a, hipStream_t b, hipEvent_t ea, hipEvent_t eb0, hip
     (void)hipStreamSynchronize(a);
     return spin_done;
 }
+// the same measurement, repeated when it says "shared": a co-tenant of the GPU that delays stream b for the length of the spin makes separate
+// queues look shared once; it does not do so three times in a row
+bool same_queue_voted(hipStream_t a, hipStream_t b, hipEvent_t ea, hipEvent_t eb0, hipEvent_t eb1) {
+    for (int i = 0; i < 3; ++i)
+        if (!same_queue(a, b, ea, eb0, eb1)) return false;
+    return true;
+}
 
 // Choose the engine's three branch streams from a pool of fresh streams so that they and `main` sit on four different hardware queues
 // (as far as the device's queue count allows); the rest of the pool is destroyed.
 int pick_streams(ss_engine* e, hipStream_t main) {
     constexpr int POOL = 10;
-    hipStream_t pool[POOL] = {};
-    hipEvent_t ev[3] = {};
+    struct Guard {               // whatever is still in here when the function returns -- early on an error, or at its end -- is destroyed
+        hipStream_t pool[POOL] = {};
+        hipEvent_t ev[3] = {};
+        ~Guard() {
+            for (auto& st : pool)
+                if (st) (void)hipStreamDestroy(st);
+            for (auto& x : ev)
+                if (x) (void)hipEventDestroy(x);
+        }
+    } gd;
+    hipStream_t(&pool)[POOL] = gd.pool;
+    hipEvent_t(&ev)[3] = gd.ev;
     for (auto& x : ev) HIPCHK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
     int least = 0, greatest = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -772,8 +815,8 @@ int pick_streams(ss_engine* e, hipStream_t main) {
     for (int pass = 0; pass < 2 && chosen.size() < 3; ++pass)       // pass 1: accept streams that only differ from the main stream's queue
         for (int i = 0; i < POOL && chosen.size() < 3; ++i) {
             if (!pool[i]) continue;
-            bool clash = same_queue(main, pool[i], ev[0], ev[1], ev[2]);
-            for (size_t k = 0; k < chosen.size() && !clash && pass == 0; ++k) clash = same_queue(chosen[k], pool[i], ev[0], ev[1], ev[2]);
+            bool clash = same_queue_voted(main, pool[i], ev[0], ev[1], ev[2]);
+            for (size_t k = 0; k < chosen.size() && !clash && pass == 0; ++k) clash = same_queue_voted(chosen[k], pool[i], ev[0], ev[1], ev[2]);
             if (!clash) {
                 std::snprintf(buf, sizeof buf, "%scandidate %d%s", chosen.empty() ? "" : ", ", i, pass ? " (shares a queue with another branch)" : "");
                 e->stream_report += buf;
@@ -787,9 +830,6 @@ int pick_streams(ss_engine* e, hipStream_t main) {
             pool[i] = nullptr;
             e->stream_report += " +fallback";
         }
-    for (auto& st : pool)
-        if (st) (void)hipStreamDestroy(st);
-    for (auto& x : ev) (void)hipEventDestroy(x);
     e->side = chosen[0];
     e->side2 = chosen[1];
     e->side3 = chosen[2];
@@ -815,7 +855,16 @@ int prof_begin(ss_engine* e, int klass, hipStream_t st, double flops) {
 void prof_end(ss_engine* e, int i, hipStream_t st) {
     if (i >= 0) (void)hipEventRecord(e->prof_ev[2 * i + 1], st);
 }
-double gemm_flops(const GemmDesc& d) { return 2.0 * d.M * d.N * (double)d.K * (d.batch > 0 ? d.batch : 1); }
+// ALGORITHMIC work of a contraction (ss_profile): halo rows are not work -- a reduction over all B * (T + 4) slab rows counts B * T of
+// them, a flattened row-masked matrix its B * T stored rows (round-2 review: the weight gradients' count was 3 % high)
+double gemm_flops_of(const ss_engine* e, const GemmDesc& d) {
+    double M = (double)d.M * (d.batch > 0 ? d.batch : 1), K = (double)d.K;
+    const long TP = e->curT + 2 * HALO, R = (long)e->curB * TP;
+    if ((d.flags & GEMM_TA) && (d.flags & GEMM_TB) && d.K >= R - 2 * HALO && d.K <= R) K = (double)e->curB * e->curT;
+    if (d.row_period == TP && d.batch <= 1) M = (double)((d.M + 2 * HALO) / TP) * e->curT;
+    return 2.0 * M * d.N * K;
+}
+#define gemm_flops(d) gemm_flops_of(e, d)
 // GEMM launch bracketed as profile class `k`
 #define PGEMM_ON(k, d, st)                                   \
     do {                                                     \
@@ -1421,6 +1470,8 @@ int lstm_late_weights(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t ws) {
         float* am = (persist && g_bwd_f16x2 && lb.amax0 >= 0) ? e->amax + lb.amax0 + l : nullptr;
         const bool bias_in_kernel = persist && !g_deterministic && lb.pd[l * 2].bhh == lb.pd[l * 2].bih + 4L * H && lb.pd[l * 2 + 1].bhh == lb.pd[l * 2 + 1].bih + 4L * H;
         CHK(lstm_weight_grads(e, lb, l, xi, am, bias_in_kernel, ws));
+        // this layer's gradients (both directions: W_ih, W_hh, b_ih, b_hh -- contiguous in the arena) are final
+        if (&lb == &e->ld) CHK(dp_bucket(e, lb.pd[l * 2].wih, lb.pd[l * 2 + 1].bhh + 4L * H - lb.pd[l * 2].wih, ws));
     }
     return 0;
 }
@@ -1661,6 +1712,7 @@ int head_weight_grads(ss_engine* e, hipStream_t st) {
     a.ksplit = pick_ksplit(a.M, a.N, a.K);
     PGEMM_ON(SS_PROF_HEAD, a, st);
     HIPCHK(colsum_acc(e->d_out_slab, e->head_out, (int)R, e->head_out, e->G + e->head_b, st));
+    CHK(dp_bucket(e, e->head_w, e->status_off - e->head_w, st));       // (the status slot behind it rides the step's last bucket)
     return 0;
 }
 
@@ -1773,6 +1825,20 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
     }
     if (early || prio) HIPCHK(hipStreamWaitEvent(s, e->ev_join[0], 0));
     else if (par) CHK(fork_join(e, b2, s));
+    auto dec_late = [&]() -> int {                 // backward_decoder(late): decoder + head weight gradients, behind the decoder chain
+        if (!e->dec_w_pending) return 0;
+        if (g_exp & 1) CHK(fork_join(e, s, e->side));      // experiment: ... and behind the conv trunk's backward as well (the two chains run one after the other)
+        HIPCHK(hipStreamWaitEvent(e->side, e->ev_join[1], 0));
+        CHK(lstm_late_weights(e, e->ld, dec_compact(e) ? Slab{e->ld.xc, e->dec_in_dim} : Slab{e->dec_in, e->dec_in_dim}, e->side));
+        CHK(head_weight_grads(e, e->side));
+        e->side_used = true;
+        e->dec_w_pending = false;
+        return 0;
+    };
+    // Data parallel: the decoder's deferred weight gradients are ENQUEUED first -- the communication stream executes in order, and the
+    // decoder layers' buckets (final first, 80 % of the bytes) must not queue behind the trunk's, which become final late in this phase.
+    // (One GPU: they stay behind the trunk in enqueue order, see prio_order.)
+    if (e->dp_on) CHK(dec_late());
     // conv trunk, last layer first
     for (int i = 2; i >= 0; --i) {
         float* dy = e->d_xf;
@@ -1791,20 +1857,17 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
         }
         Slab x2 = i == 0 ? Slab{e->in_f0, e->f0p} : Slab{e->xf[i - 1] + off2, CE, bim ? bim + off2 : nullptr, e->act_scale + e->c2[i - 1].scale_i};
         CHK(conv_block_bwd(e, e->c2[i], Slab{dy + off2, CE}, x2, i > 0 ? Slab{dxbuf + off2, CE} : Slab{nullptr, 0}, s));
+        if (i > 0) {           // the two wide layers' parameters (weight, bias, GroupNorm affine: contiguous) are final; layer 0 rides the last bucket
+            if (g3) CHK(dp_bucket(e, e->c1[i].w, e->c1[i].be + e->c1[i].Co - e->c1[i].w, s));
+            CHK(dp_bucket(e, e->c2[i].w, e->c2[i].be + e->c2[i].Co - e->c2[i].w, s));
+        }
         if (!training && i > 0) {
             // eval mode has no resampling between layers: the next (lower) layer reads its output gradient from d_xf
             HIPCHK(hipMemcpyAsync(e->d_xf, e->d_act, R * CE * 4, hipMemcpyDeviceToDevice, s));
         }
     }
     // ---- everything that only has to be finished by the end of the step
-    if (e->dec_w_pending) {                        // backward_decoder(late): decoder + head weight gradients, behind the decoder chain
-        if (g_exp & 1) CHK(fork_join(e, s, e->side));      // experiment: ... and behind the conv trunk's backward as well (the two chains run one after the other)
-        HIPCHK(hipStreamWaitEvent(e->side, e->ev_join[1], 0));
-        CHK(lstm_late_weights(e, e->ld, dec_compact(e) ? Slab{e->ld.xc, e->dec_in_dim} : Slab{e->dec_in, e->dec_in_dim}, e->side));
-        CHK(head_weight_grads(e, e->side));
-        e->side_used = true;
-        e->dec_w_pending = false;
-    }
+    CHK(dec_late());
     if (prio) {
         HIPCHK(hipStreamWaitEvent(b3, e->ev_join[0], 0));                   // lstm_2's pre-activation gradients (and the zeroed conv images)
         CHK(lstm_late_weights(e, e->l2, Slab{e->xf[2] + off2, CE, nullptr, e->act_scale + e->c2[2].scale_i}, b3));
@@ -1910,6 +1973,8 @@ void ss_destroy(ss_engine* e) {
         for (auto& ev : e->ev)
             if (ev) (void)hipEventDestroy(ev);
         (void)hipStreamDestroy(e->side);
+        if (e->comm_s) (void)hipStreamDestroy(e->comm_s);
+        if (e->ev_comm) (void)hipEventDestroy(e->ev_comm);
         for (hipStream_t st : {e->side2, e->side3})
             if (st) {
                 (void)hipStreamSynchronize(st);
@@ -2456,6 +2521,8 @@ int ss_tune(const char* key, int value) {
     else if (k == "img" && (value == 0 || value == 1)) g_img = value;
     else if (k == "img_mask" && value >= 0 && value < 2048) g_img_mask = value;
     else if (k == "img_batch" && (value == 0 || value == 1)) g_img_batch = value;
+    else if (k == "dp_model" && value >= 0 && value <= 64) g_dp_model = value;
+    else if (k == "dp_buckets" && (value == 0 || value == 1)) g_dp_buckets = value;
     else if (k == "img_dw_cfg" && value >= -1 && value <= 2) g_img_dw_cfg = value;
     else if (k == "img_dw_wgs" && value >= 32 && value <= 4096) g_img_dw_wgs = value;
     else if (k == "img_cfg" && value >= -1 && value <= 2) g_img_cfg = value;
@@ -2470,7 +2537,9 @@ int ss_tune(const char* key, int value) {
     else if (k == "conv_want" && value >= 0) g_conv_want = value;
     else if (k == "small_lds" && value >= 0 && value <= 2) g_small_lds = value;
     else if (k == "gemm_tr" && value >= 0 && value <= 2) g_gemm_tr = value;
+#ifdef SS_DIAG
     else if (k == "graph" && (value == 0 || value == 1)) g_graph = value;
+#endif
     else if (k == "own_streams" && (value == 0 || value == 1)) g_own_streams = value;
     else if (k == "early_join" && (value == 0 || value == 1)) g_early_join = value;
     else if (k == "conv_par" && (value == 0 || value == 1)) g_conv_par = value;
@@ -2689,6 +2758,8 @@ struct Rccl {
     int (*CommInitRank)(void**, int, NcclId, int) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
 Rccl g_rccl;
@@ -2707,8 +2778,10 @@ int rccl_load() {
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
     r.AllReduce = (decltype(r.AllReduce))dlsym(h, "ncclAllReduce");
+    r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
-    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString) return fail("RCCL: missing symbols");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString || !r.GroupStart || !r.GroupEnd) return fail("RCCL: missing symbols");
     g_rccl = r;
     return 0;
 }
@@ -2718,11 +2791,78 @@ int rccl_load() {
         if (_r != 0) return fail(std::string(#x) + ": " + g_rccl.GetErrorString(_r));       \
     } while (0)
 
+// Stand-in for a collective when a data-parallel run is MODELLED on one GPU (ss_tune("dp_model", ranks)): 32 workgroups (RCCL's
+// channels) stream the range once -- read and write it back, the memory traffic of a reduction -- and then hold their place until the
+// modelled duration has passed.  Model (the conservative one): ring all-reduce, 2 (R - 1) / R of the bytes through
+// one xGMI link of 153 GB/s, plus 25 us of launch / protocol latency.
+__global__ __launch_bounds__(256) void dp_model_kernel(float* __restrict__ p, long n4, long long ticks) {
+    const long long t0 = wall_clock64();                         // constant 100 MHz
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 v = reinterpret_cast<const f32x4*>(p)[i];
+        asm volatile("" : "+v"(v));
+        reinterpret_cast<f32x4*>(p)[i] = v;
+    }
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+double dp_model_us(long bytes, int ranks) { return 25.0 + 2.0 * (ranks - 1) / ranks * (double)bytes / 153e9 * 1e6; }
+
 int allreduce_range(ss_engine* e, long off, long count, hipStream_t st) {
-    if (!e->comm) return fail("no communicator: call ss_comm_init first");
     if (off < 0 || count < 0 || off + count > e->arena) return fail("ss_allreduce_grads: range outside the gradient arena");
     if (count == 0) return 0;
+    if (g_dp_model > 1 && (!e->comm || e->comm_world == 1)) {
+        const long a = (off + 3) & ~3L, b = (off + count) & ~3L;       // whole float4s inside the range
+        hipLaunchKernelGGL(dp_model_kernel, dim3(32), dim3(256), 0, st, e->G + a, b > a ? (b - a) / 4 : 0, (long long)(dp_model_us(count * 4, g_dp_model) * 100.0));
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    if (!e->comm) return fail("no communicator: call ss_comm_init first");
     NCCLCHK(g_rccl.AllReduce(e->G + off, e->G + off, (size_t)count, /*ncclFloat*/ 7, /*ncclSum*/ 0, e->comm, st));
+    return 0;
+}
+
+// see the declaration above fork_join
+int dp_bucket(ss_engine* e, long off, long count, hipStream_t producer) {
+    if (!e->dp_on || !g_dp_buckets || count <= 0) return 0;
+    HIPCHK(hipEventRecord(e->ev_comm, producer));
+    HIPCHK(hipStreamWaitEvent(e->comm_s, e->ev_comm, 0));
+    CHK(allreduce_range(e, off, count, e->comm_s));
+    e->dp_done.push_back({off, off + count});
+    return 0;
+}
+
+// end of a data-parallel backward: everything not yet handed to a collective (layer-0 convolutions, the encoder BLSTMs, Encoder_t, the
+// status slot -- a few MB, final only now), then the main stream waits for the communication stream
+int dp_finish(ss_engine* e, hipStream_t s) {
+    std::sort(e->dp_done.begin(), e->dp_done.end());
+    std::vector<std::pair<long, long>> rest;
+    long at = 0;
+    for (auto& r : e->dp_done) {
+        if (r.first > at) rest.push_back({at, r.first});
+        if (r.second > at) at = r.second;
+    }
+    if (at < e->arena) rest.push_back({at, e->arena});
+    // ONE launch for all of them (ncclGroupStart / End); modelled: one stand-in over their total size
+    HIPCHK(hipEventRecord(e->ev_comm, s));
+    HIPCHK(hipStreamWaitEvent(e->comm_s, e->ev_comm, 0));
+    const bool model = g_dp_model > 1 && (!e->comm || e->comm_world == 1);
+    if (model) {
+        long tot = 0;
+        for (auto& r : rest) tot += r.second - r.first;
+        hipLaunchKernelGGL(dp_model_kernel, dim3(32), dim3(256), 0, e->comm_s, e->G, 0L, (long long)(dp_model_us(tot * 4, g_dp_model) * 100.0));
+        HIPCHK(hipGetLastError());
+    } else {
+        if (rest.size() > 1) NCCLCHK(g_rccl.GroupStart());
+        for (auto& r : rest) CHK(allreduce_range(e, r.first, r.second - r.first, e->comm_s));
+        if (rest.size() > 1) NCCLCHK(g_rccl.GroupEnd());
+    }
+    e->dp_done.clear();
+    HIPCHK(hipEventRecord(e->ev_comm, e->comm_s));
+    HIPCHK(hipStreamWaitEvent(s, e->ev_comm, 0));
+    return 0;
+}
+int dp_streams(ss_engine* e) {
+    if (!e->comm_s) HIPCHK(hipStreamCreateWithFlags(&e->comm_s, hipStreamNonBlocking));
+    if (!e->ev_comm) HIPCHK(hipEventCreateWithFlags(&e->ev_comm, hipEventDisableTiming));
     return 0;
 }
 
@@ -2776,34 +2916,55 @@ int ss_allreduce_grads(ss_engine* e, long offset, long count, void* stream) {
     return allreduce_range(e, offset, count, own.s);
 }
 
+// common part of the data-parallel steps: `body` enqueues forward + loss + the whole backward (no Adam); the gradient arena is reduced
+// in per-layer buckets on the communication stream while the backward is still running (dp_bucket: each of the decoder's layers as
+// its four weight-gradient GEMMs retire, the head, the two wide trunk layers, the rest), Adam with the 1 / world mean folded in
+static int dp_step(ss_engine* e, hipStream_t s, const std::function<int(hipStream_t)>& body) {
+    const int world = (g_dp_model > 1 && (!e->comm || e->comm_world == 1)) ? g_dp_model : e->comm_world;
+    const float gs = 1.0f / (float)world;
+    CHK(dp_streams(e));
+    if (!e->side || !g_overlap || !g_dp_buckets) {        // no branch streams (or round 2's plan asked for): the plain step, then the arena
+        CHK(body(s));
+        if (g_dp_buckets) CHK(allreduce_range(e, 0, e->arena, s));
+        else {
+            const long k = ss_grad_split(e);
+            CHK(allreduce_range(e, k, e->arena - k, s));
+            CHK(allreduce_range(e, 0, k, s));
+        }
+        return adam_enqueue(e, gs, s);
+    }
+    e->dp_done.clear();
+    e->dp_on = true;
+    const int rc = body(s);
+    e->dp_on = false;
+    CHK(rc);
+    CHK(dp_finish(e, s));
+    return adam_enqueue(e, gs, s);                          // the mean is folded into the Adam kernel
+}
+
 int ss_g3_dp_train_step(ss_engine* e, const float* mel, const float* f0, const float* emb, const int* len_org, const float* scales,
                         const int* len_seg, int B, int T, int flags, float* loss, void* stream) {
     if (e->kind != SS_GENERATOR_3) return fail("ss_g3_dp_train_step on a Generator_6 engine");
-    if (!e->comm) return fail("ss_g3_dp_train_step: call ss_comm_init first");
+    if (!e->comm && g_dp_model < 2) return fail("ss_g3_dp_train_step: call ss_comm_init first");
     CHK(apply_bucket(e, T, flags));      // every rank runs the same bucket (speechsplit_amd/buckets.py)
     if (T != e->hp.max_len_pad) return fail("training needs T == max_len_pad (model.py:105,157,370); pass SS_STEP_BUCKET for a length-bucketed batch");
     CHK(entry_check(e));
     Own own(e, stream);
     hipStream_t s = own.s;
     CHK(geometry(e, B, T, s));
-    const long k = ss_grad_split(e);
-    const float gs = 1.0f / (float)e->comm_world;
-    if (!e->side || !g_overlap) {           // no branch streams: the plain step, one collective over the whole arena behind it
-        CHK(g3_step_body(e, mel, f0, emb, len_org, scales, len_seg, B, T, 1.0f, SS_STEP_NO_ADAM, loss, s));
-        CHK(allreduce_range(e, 0, e->arena, s));
-        return adam_enqueue(e, gs, s);
-    }
-    // forward + decoder backward exactly as in the one-GPU step; the decoder's weight-gradient GEMMs are on the side stream
-    CHK(g3_step_body(e, mel, f0, emb, len_org, scales, len_seg, B, T, 1.0f, SS_STEP_NO_ADAM | SS_STEP_SPLIT_BACKWARD | SS_STEP_SPLIT_NO_JOIN, loss, s));
-    // bucket 1 = head + decoder + status slot (80 % of the bytes, final first): reduced ON the side stream, i.e. behind those GEMMs
-    // by stream order and behind the decoder chain by ev_dec[0]; it runs while the encoder backward executes on the main stream
-    HIPCHK(hipStreamWaitEvent(e->side, e->ev_dec[0], 0));
-    e->dec_pending = 0;
-    CHK(allreduce_range(e, k, e->arena - k, e->side));
-    e->side_used = true;                                    // backward_encoder joins the side stream at its end
-    CHK(backward_encoder(e, s));
-    CHK(allreduce_range(e, 0, k, s));                       // bucket 2 = the encoder
-    return adam_enqueue(e, gs, s);                          // the mean is folded into the Adam kernel
+    return dp_step(e, s, [&](hipStream_t st) { return g3_step_body(e, mel, f0, emb, len_org, scales, len_seg, B, T, 1.0f, SS_STEP_NO_ADAM, loss, st); });
+}
+
+int ss_g6_dp_train_step(ss_engine* e, const float* mel, const float* f0_onehot, const int* target_idx, const float* scales, const int* len_seg,
+                        int B, int T, int flags, float* loss, void* stream) {
+    if (e->kind != SS_GENERATOR_6) return fail("ss_g6_dp_train_step on a Generator_3 engine");
+    if (!e->comm && g_dp_model < 2) return fail("ss_g6_dp_train_step: call ss_comm_init first");
+    CHK(entry_check(e));
+    Own own(e, stream);
+    hipStream_t s = own.s;
+    return dp_step(e, s, [&](hipStream_t st) {
+        return ss_g6_train_step(e, mel, f0_onehot, target_idx, scales, len_seg, B, T, 1.0f, (flags & SS_STEP_BUCKET) | SS_STEP_NO_ADAM, loss, (void*)st);
+    });
 }
 
 }  // extern "C"

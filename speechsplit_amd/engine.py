@@ -272,6 +272,16 @@ class Engine:
                                               float(grad_scale), (1 if no_adam else 0) | (16 if bucket else 0), _ptr(self.loss), _stream()))
         return self.loss
 
+    def g6_dp_train_step_native(self, mel, f0_onehot, target_idx, draws, bucket=False):
+        """ss_g6_dp_train_step: Generator_6's data-parallel step with the engine's own RCCL communicator (per-layer buckets on the
+        engine's communication stream), as dp_train_step_native for Generator_3."""
+        B, T, _ = mel.shape
+        mel, f0_onehot, target_idx = self._f(mel), self._f(f0_onehot), self._i(target_idx)
+        sc, ls = self._draws(draws)
+        _capi.check(self.lib.ss_g6_dp_train_step(self.h, _ptr(mel), _ptr(f0_onehot), _ptr(target_idx), _ptr(sc), _ptr(ls), B, T,
+                                                 16 if bucket else 0, _ptr(self.loss), _stream()))
+        return self.loss
+
     # ------------------------------------------------------------------ optimiser / misc
     def adam_step(self, grad_scale=1.0):
         _capi.check(self.lib.ss_adam_step(self.h, float(grad_scale), _stream()))

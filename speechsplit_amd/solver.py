@@ -67,10 +67,9 @@ class Solver(object):
             import torch.distributed as dist
             dist.broadcast(self.eng.params, src=0)   # identical replicas
             self.eng.set_lockstep(True)              # never refuse a step on the status word: check() reports it on every rank at the same iteration
-            if self.GENERATOR is Generator:
-                # the engine's own RCCL communicator: its data-parallel step launches the collectives on the engine's streams and costs
-                # nothing over the one-GPU step, where torch.distributed's path measured +0.5 ms
-                self.eng.comm_init(self.rank, self.world)
+            # the engine's own RCCL communicator: its data-parallel step launches the collectives on the engine's streams and costs
+            # nothing over the one-GPU step, where torch.distributed's path measured +0.5 ms
+            self.eng.comm_init(self.rank, self.world)
 
     def print_network(self, model, name):
         num_params = sum(p.numel() for p in model.parameters())
@@ -234,10 +233,7 @@ class SolverF0(Solver):
         onehot, idx = quantize_f0_torch(f0[:, :, 0])
         bucket = mel.shape[1] != self.hparams.max_len_pad
         if self.world > 1:
-            self.eng.g6_train_step(mel, onehot, idx.to(torch.int32), draws, no_adam=True, bucket=bucket)
-            _dist.reduce_arena(self.eng.grads, self.eng.grad_split)
-            self.eng.adam_step(1.0 / self.world)
-            loss = self.eng.loss
+            loss = self.eng.g6_dp_train_step_native(mel, onehot, idx.to(torch.int32), draws, bucket=bucket)
         else:
             loss = self.eng.g6_train_step(mel, onehot, idx.to(torch.int32), draws, bucket=bucket)
         self.step_count += 1

@@ -186,3 +186,29 @@ def test_shard_helpers():
     assert a.shape == (4, 28) and torch.equal(a, sc[:, 28:]) and torch.equal(b, ls[:, 28:])
     batch = (torch.zeros(8, 3), torch.zeros(8, 2), torch.zeros(8, 1), torch.arange(8))
     assert dist.shard_batch(batch, 0, 4)[3].tolist() == [0, 1]
+
+
+def test_mel_filter_bank_published_properties():
+    """speechsplit_amd.features.mel_filter_bank restates `librosa.filters.mel` (make_spect_f0.py:15) from the published algorithm; librosa is
+    absent here, so parity is UNPINNED and only the published properties are checked: the Slaney mel scale's fixed points, triangular
+    filters between neighbouring band edges, non-negative weights, unit area under every filter ('slaney' norm), peaks in band order."""
+    import numpy as np
+    from speechsplit_amd import features as F
+    assert abs(float(F._hz_to_mel(1000.0)) - 15.0) < 1e-12 and abs(float(F._hz_to_mel(200.0)) - 3.0) < 1e-12
+    assert abs(float(F._hz_to_mel(6400.0)) - 42.0) < 1e-9                      # 27 mels per factor of 6.4 above 1 kHz
+    for f in (90.0, 999.0, 1000.0, 1001.0, 7600.0):
+        assert abs(float(F._mel_to_hz(F._hz_to_mel(f))) - f) < 1e-9 * f
+    w = F.mel_filter_bank()
+    assert w.shape == (80, 513) and w.dtype == np.float32 and float(w.min()) >= 0.0
+    fft_f = np.linspace(0, 8000, 513)
+    edges = F._mel_to_hz(np.linspace(F._hz_to_mel(90.0), F._hz_to_mel(7600.0), 82))
+    peaks = []
+    for i in range(80):
+        nz = np.nonzero(w[i])[0]
+        assert len(nz) >= 1 and fft_f[nz[0]] > edges[i] - 1e-9 and fft_f[nz[-1]] < edges[i + 2] + 1e-9      # support inside its band
+        peaks.append(int(w[i].argmax()))
+        # a triangle of height 2 / width sampled every 15.625 Hz: the area under the continuous filter is 1
+        width = edges[i + 2] - edges[i]
+        assert abs(float(w[i].max()) - 2.0 / width) <= 2.0 / width * (15.625 / min(edges[i + 1] - edges[i], edges[i + 2] - edges[i + 1])) + 1e-6
+    assert peaks == sorted(peaks)
+    assert float(w[:, fft_f < 90.0].max()) == 0.0 and float(w[:, fft_f > 7600.0].max()) == 0.0

@@ -146,6 +146,61 @@ def test_native_rccl_dp_step_on_one_rank(E):
     assert rel(res[1][1], res[0][1]) < 1e-6
 
 
+def test_native_g6_dp_step_and_modelled_collectives(E):
+    """ss_g6_dp_train_step on a one-rank communicator equals the fused Generator_6 step; ss_tune("dp_model", 8) -- every collective
+    replaced by a stand-in kernel of the modelled duration, no communicator -- leaves the gradients alone and folds 1/8 into Adam, for
+    both generators and for both bucket plans (per-layer buckets on the communication stream / round 2's two buckets)."""
+    B, T = 4, 192
+    hp = W.default_hparams(max_len_pad=T)
+    w6 = W.make_weights('G6', hp, 4)
+    mel, f0, emb, lens = synth_batch(51, B, T, 96)
+    qidx = torch.from_numpy(interp_np.quantize_f0(f0[:, :, 0].numpy()))
+    onehot = torch.nn.functional.one_hot(qidx, 257).float()
+    d3 = stack_draws(draws_for(61, B, 3))
+
+    def run6(mode):
+        eng = E.Engine('G6', hp, B, T)
+        eng.load_weights(w6)
+        eng.set_adam(1e-4, 0.9, 0.999, 1e-8, 0)
+        if mode == 'native':
+            eng.comm_init(0, 1)
+        for _ in range(2):
+            if mode == 'plain':
+                loss = eng.g6_train_step(mel, onehot, qidx, d3)
+            elif mode == 'plain8':
+                loss = eng.g6_train_step(mel, onehot, qidx, d3, grad_scale=1.0 / 8)
+            else:
+                loss = eng.g6_dp_train_step_native(mel, onehot, qidx, d3)
+        eng.check()
+        return float(loss), eng.params.clone()
+
+    a, b = run6('plain'), run6('native')
+    assert abs(a[0] - b[0]) <= 1e-6 * a[0] and rel(b[1], a[1]) < 1e-6
+    E.tune('dp_model', 8)
+    try:
+        c, m = run6('plain8'), run6('model')
+        assert abs(c[0] - m[0]) <= 1e-6 * c[0] and rel(m[1], c[1]) < 1e-6
+        # Generator_3, both bucket plans
+        w3 = W.make_weights('G3', hp, 6)
+        d4 = stack_draws(draws_for(28, B, 4))
+        res = []
+        for plan in ('plain8', 1, 0):
+            if plan != 'plain8':
+                E.tune('dp_buckets', plan)
+            eng = E.Engine('G3', hp, B, T)
+            eng.load_weights(w3)
+            eng.set_adam(1e-4, 0.9, 0.999, 1e-8, 0)
+            for _ in range(2):
+                loss = eng.g3_train_step(mel, f0, emb, lens, d4, grad_scale=1.0 / 8) if plan == 'plain8' else eng.dp_train_step_native(mel, f0, emb, lens, d4)
+            eng.check()
+            res.append((float(loss), eng.params.clone()))
+        for r in res[1:]:
+            assert abs(r[0] - res[0][0]) <= 1e-6 * res[0][0] and rel(r[1], res[0][1]) < 1e-6
+    finally:
+        E.tune('dp_model', 0)
+        E.tune('dp_buckets', 1)
+
+
 def test_g6_dp_step_on_a_one_rank_group(E):
     import os
     import torch.distributed as dist

@@ -416,18 +416,20 @@ def test_fused_train_step_against_reference_fixture(E, tag):
 
 
 @pytest.mark.parametrize('case', [(2, 64, 9, 46, True, 1), (4, 128, 9, 61, False, 1), (5, 192, 4, 70, False, 1),
-                                  (4, 128, 9, 61, False, 0), (3, 64, 9, 46, False, 2), (1, 128, 5, 33, False, 1), (17, 64, 2, 80, False, 1)])
+                                  (4, 128, 9, 61, False, 0), (3, 64, 9, 46, False, 0), (1, 128, 5, 33, False, 1), (17, 64, 2, 80, False, 1)])
 def test_fused_train_step_full_gradients(E, case):
     """Every element of all 86 gradients against the oracle's autograd.  The last field selects the decoder recurrence
-    schedule: 1 = persistent kernels (default), 0 = one launch per time step, 2 = per-step launches captured in a hipGraph."""
+    schedule: 1 = persistent kernels (default), 0 = one launch per time step.  (Round 2's third schedule -- the per-step launches
+    captured in a hipGraph -- left the product library in round 3: no gain, and a crash inside the runtime's graph launch; it
+    exists in the -DSS_DIAG build only.)"""
     B, T, wseed, bseed, want_safe, sched = case
     E.tune('persist', 1 if sched == 1 else 0)
-    E.tune('graph', 1 if sched == 2 else 0)
     try:
         _full_gradients(E, B, T, wseed, bseed, want_safe)
     finally:
         E.tune('persist', 1)
-        E.tune('graph', 0)
+    with pytest.raises(RuntimeError, match='unknown key'):
+        E.tune('graph', 1)
 
 
 def _full_gradients(E, B, T, wseed, bseed, want_safe):

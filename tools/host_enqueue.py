@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Host-side cost of enqueuing one training step (no device sync in between) vs. the device time of the step."""
 import os, sys, time, torch
+os.environ.setdefault('SS_DIAG_LIB', '1')      # the hipGraph schedule exists only in the -DSS_DIAG build
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import weights as W
