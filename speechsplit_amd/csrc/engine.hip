@@ -1332,7 +1332,9 @@ int lstm_input_grad(ss_engine* e, LstmBlk& lb, int l, Slab dxi, long r0, long nr
     GemmDesc g{};
     g.A = {lb.gates[l] + r0 * 8L * H, 8L * H, 0, 0, 0};
     g.B = {lb.wcat[l], In, 0, 0, 0};
-    g.b_pre = ((g_presplit & 8) && (g_presplit & 1)) ? lb.wimg(l) : nullptr;       // measured with image format v2: 573 us per step with the image, 532 without (round 3)
+    // (round 2's kernel measured SLOWER with the weight image in format v2 on this transposing-read operand -- 573 us per step with it, 532
+    // without -- so it only gets that image when asked to, presplit bit 3)
+    g.b_pre = ((g_presplit & 8) && (g_presplit & 1)) ? lb.wimg(l) : nullptr;
     g.C = dxi.p + r0 * dxi.ld;
     g.ldc = dxi.ld;
     g.M = (int)nr;
@@ -1366,7 +1368,7 @@ int lstm_input_grad(ss_engine* e, LstmBlk& lb, int l, Slab dxi, long r0, long nr
 // launches go to their branch stream.  A consumer that waits for it is not held up by whatever else shares a hardware queue with
 // `s`: an event recorded later would sit in that queue behind every packet enqueued in between (measured: the conv trunk's
 // backward idled 0.88 ms behind ~36 tiny weight-gradient launches of a sibling stream, profiles/r02/step_timeline_before.txt).
-int lstm_late_weights(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t ws);
+int lstm_late_weights(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t ws, int l_hi = -1, int l_lo = 0);
 
 // late_w: enqueue the recurrence chain and the input gradients only; the caller enqueues the block's weight gradients later
 // (lstm_late_weights) -- after the phase's critical path -- on a stream it has ordered behind this chain.
@@ -1462,10 +1464,10 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
 }
 
 // all layers' weight / bias gradients of a block whose chain ran with deferred weights (the decoder's deferred batch; every block under late_w)
-int lstm_late_weights(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t ws) {
+int lstm_late_weights(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t ws, int l_hi, int l_lo) {
     const int H = lb.H;
     const bool persist = lb.big() && g_persist && lstm_seq_supported(e->curB, H);
-    for (int l = lb.L - 1; l >= 0; --l) {
+    for (int l = l_hi < 0 ? lb.L - 1 : l_hi; l >= l_lo; --l) {       // layers l_hi .. l_lo (default: all, last first)
         Slab xi = l == 0 ? x : Slab{lb.out[l - 1], 2L * H};
         float* am = (persist && g_bwd_f16x2 && lb.amax0 >= 0) ? e->amax + lb.amax0 + l : nullptr;
         const bool bias_in_kernel = persist && !g_deterministic && lb.pd[l * 2].bhh == lb.pd[l * 2].bih + 4L * H && lb.pd[l * 2 + 1].bhh == lb.pd[l * 2 + 1].bih + 4L * H;
@@ -1825,20 +1827,28 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
     }
     if (early || prio) HIPCHK(hipStreamWaitEvent(s, e->ev_join[0], 0));
     else if (par) CHK(fork_join(e, b2, s));
-    auto dec_late = [&]() -> int {                 // backward_decoder(late): decoder + head weight gradients, behind the decoder chain
-        if (!e->dec_w_pending) return 0;
-        if (g_exp & 1) CHK(fork_join(e, s, e->side));      // experiment: ... and behind the conv trunk's backward as well (the two chains run one after the other)
-        HIPCHK(hipStreamWaitEvent(e->side, e->ev_join[1], 0));
-        CHK(lstm_late_weights(e, e->ld, dec_compact(e) ? Slab{e->ld.xc, e->dec_in_dim} : Slab{e->dec_in, e->dec_in_dim}, e->side));
-        CHK(head_weight_grads(e, e->side));
+    // backward_decoder(late): the decoder's (layers l_hi .. l_lo) and, with its layer 0, the head's weight gradients, behind the decoder chain
+    int dec_next = e->dec_w_pending ? e->ld.L - 1 : -1;       // next decoder layer whose weight gradients are still to be enqueued
+    auto dec_late = [&](int l_lo) -> int {
+        if (dec_next < l_lo) return 0;
+        if (dec_next == e->ld.L - 1) {
+            if (g_exp & 1) CHK(fork_join(e, s, e->side));      // experiment: ... and behind the conv trunk's backward as well (the two chains run one after the other)
+            HIPCHK(hipStreamWaitEvent(e->side, e->ev_join[1], 0));
+        }
+        CHK(lstm_late_weights(e, e->ld, dec_compact(e) ? Slab{e->ld.xc, e->dec_in_dim} : Slab{e->dec_in, e->dec_in_dim}, e->side, dec_next, l_lo));
+        dec_next = l_lo - 1;
+        if (l_lo == 0) {
+            CHK(head_weight_grads(e, e->side));
+            e->dec_w_pending = false;
+        }
         e->side_used = true;
-        e->dec_w_pending = false;
         return 0;
     };
-    // Data parallel: the decoder's deferred weight gradients are ENQUEUED first -- the communication stream executes in order, and the
-    // decoder layers' buckets (final first, 80 % of the bytes) must not queue behind the trunk's, which become final late in this phase.
-    // (One GPU: they stay behind the trunk in enqueue order, see prio_order.)
-    if (e->dp_on) CHK(dec_late());
+    // Data parallel: the communication stream executes its collectives in the order they are ENQUEUED, so the buckets are enqueued in the
+    // order they become final -- decoder layer L-1, trunk layer 2, decoder layer L-2, trunk layer 1, the rest of the decoder + head --
+    // instead of every decoder bucket in front of (or behind) every trunk bucket.  (One GPU: the decoder's weight gradients stay behind
+    // the trunk in enqueue order, see prio_order.)
+    if (e->dp_on) CHK(dec_late(e->ld.L - 1));
     // conv trunk, last layer first
     for (int i = 2; i >= 0; --i) {
         float* dy = e->d_xf;
@@ -1851,15 +1861,23 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
         float* dxbuf = training ? e->d_xf : e->d_act;
         // the resampled activations also exist as pre-split images when the forward's gathers wrote them (training, independent trunk chains)
         const float* bim = (training && e->xf_img_valid && i > 0) ? e->xf_img[i - 1] : nullptr;
+        if (i == 0 && g3 && par && !e->dp_on && !g_graph && (g_exp & 2) == 0) CHK(fork_join(e, s, b2));      // tail_par below: the pitch block's stream forks BEFORE the content block is enqueued
         if (g3) {
             Slab x1 = i == 0 ? Slab{e->in_mel, h.dim_freq} : Slab{e->xf[i - 1], CE, bim, e->act_scale + e->c1[i - 1].scale_i};
             CHK(conv_block_bwd(e, e->c1[i], Slab{dy, CE}, x1, i > 0 ? Slab{dxbuf, CE} : Slab{nullptr, 0}, s));
         }
         Slab x2 = i == 0 ? Slab{e->in_f0, e->f0p} : Slab{e->xf[i - 1] + off2, CE, bim ? bim + off2 : nullptr, e->act_scale + e->c2[i - 1].scale_i};
-        CHK(conv_block_bwd(e, e->c2[i], Slab{dy + off2, CE}, x2, i > 0 ? Slab{dxbuf + off2, CE} : Slab{nullptr, 0}, s));
+        // Layer 0 is the step's tail: the decoder's weight gradients are through by then, and each of its two weight-gradient GEMMs alone
+        // fills half the chip's workgroup slots -- the pitch block runs on the second branch stream beside the content block.  (Not under
+        // data parallelism, where that stream carries the collectives.)
+        const bool tail_par = i == 0 && g3 && par && !e->dp_on && !g_graph && (g_exp & 2) == 0;
+        hipStream_t s2 = tail_par ? b2 : s;
+        CHK(conv_block_bwd(e, e->c2[i], Slab{dy + off2, CE}, x2, i > 0 ? Slab{dxbuf + off2, CE} : Slab{nullptr, 0}, s2));
+        if (tail_par) CHK(fork_join(e, b2, s));
         if (i > 0) {           // the two wide layers' parameters (weight, bias, GroupNorm affine: contiguous) are final; layer 0 rides the last bucket
             if (g3) CHK(dp_bucket(e, e->c1[i].w, e->c1[i].be + e->c1[i].Co - e->c1[i].w, s));
             CHK(dp_bucket(e, e->c2[i].w, e->c2[i].be + e->c2[i].Co - e->c2[i].w, s));
+            if (e->dp_on) CHK(dec_late(i == 2 ? (e->ld.L >= 3 ? e->ld.L - 2 : 0) : 0));      // next decoder layer(s) behind this trunk layer's buckets
         }
         if (!training && i > 0) {
             // eval mode has no resampling between layers: the next (lower) layer reads its output gradient from d_xf
@@ -1867,7 +1885,7 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
         }
     }
     // ---- everything that only has to be finished by the end of the step
-    CHK(dec_late());
+    CHK(dec_late(0));
     if (prio) {
         HIPCHK(hipStreamWaitEvent(b3, e->ev_join[0], 0));                   // lstm_2's pre-activation gradients (and the zeroed conv images)
         CHK(lstm_late_weights(e, e->l2, Slab{e->xf[2] + off2, CE, nullptr, e->act_scale + e->c2[2].scale_i}, b3));
@@ -1973,7 +1991,6 @@ void ss_destroy(ss_engine* e) {
         for (auto& ev : e->ev)
             if (ev) (void)hipEventDestroy(ev);
         (void)hipStreamDestroy(e->side);
-        if (e->comm_s) (void)hipStreamDestroy(e->comm_s);
         if (e->ev_comm) (void)hipEventDestroy(e->ev_comm);
         for (hipStream_t st : {e->side2, e->side3})
             if (st) {
@@ -2860,8 +2877,13 @@ int dp_finish(ss_engine* e, hipStream_t s) {
     HIPCHK(hipStreamWaitEvent(s, e->ev_comm, 0));
     return 0;
 }
+// The communication stream is the engine's SECOND BRANCH stream, not a fifth stream: HIP serves a process's streams from four hardware
+// queues, so a fifth one shares a queue with one of the four the engine already runs on -- measured with modelled collectives
+// (gpurun_out/r03/dp: it landed on the MAIN stream's queue, every collective sat in front of the encoder backward's launches and the
+// backward took 1.16 ms longer).  The second branch stream has its own queue (pick_streams) and is idle from the first tenth of the
+// encoder-backward phase on (it carries the pitch BLSTM's backward); whatever it still holds is simply in front of the first bucket.
 int dp_streams(ss_engine* e) {
-    if (!e->comm_s) HIPCHK(hipStreamCreateWithFlags(&e->comm_s, hipStreamNonBlocking));
+    e->comm_s = e->side2;
     if (!e->ev_comm) HIPCHK(hipEventCreateWithFlags(&e->ev_comm, hipEventDisableTiming));
     return 0;
 }
@@ -2923,7 +2945,7 @@ static int dp_step(ss_engine* e, hipStream_t s, const std::function<int(hipStrea
     const int world = (g_dp_model > 1 && (!e->comm || e->comm_world == 1)) ? g_dp_model : e->comm_world;
     const float gs = 1.0f / (float)world;
     CHK(dp_streams(e));
-    if (!e->side || !g_overlap || !g_dp_buckets) {        // no branch streams (or round 2's plan asked for): the plain step, then the arena
+    if (!e->side || !e->side2 || !g_overlap || !g_dp_buckets) {        // no branch streams (or round 2's plan asked for): the plain step, then the arena
         CHK(body(s));
         if (g_dp_buckets) CHK(allreduce_range(e, 0, e->arena, s));
         else {

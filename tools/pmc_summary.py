@@ -6,18 +6,20 @@ HBM-side bytes follow MI355X_MICROARCH.md's gfx950 recipe: read = 2 x FETCH_SIZE
 64 B per 128-B request of a 16-B/lane read), write = WRITE_SIZE x 1024."""
 import collections, csv, glob, json, sys
 
-SHAPES = ['proj NT 8192x4096x1024', 'conv NT 8192x512x2560', 'dX NN 8192x1024x4096', 'dW_ih TN 2048x1024x8448 ks4',
-          'dW_hh TN 2048x512x8447 ks8']
-FLOPS = [2.0 * 8192 * 4096 * 1024, 2.0 * 8192 * 512 * 2560, 2.0 * 8192 * 1024 * 4096, 2.0 * 2048 * 1024 * 8448, 2.0 * 2048 * 512 * 8447]
-CLASSES = ['dec_proj', 'conv_fwd', 'dec_dx', 'dec_dw', 'dec_dw']      # bench.py's kernel classes (ss_profile)
-LAUNCHES = 4
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gemm_pmc import SHAPES as _SH, LAUNCHES      # the launches tools/gemm_pmc.py makes, in order
+
+SHAPES = [s[0] for s in _SH]
+FLOPS = [2.0 * s[3] * s[4] * s[5] for s in _SH]
+CLASSES = [s[1] for s in _SH]      # bench.py's kernel classes (ss_profile)
 
 
 def load(d):
     f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)[0]
     disp = collections.OrderedDict()
     for r in csv.DictReader(open(f)):
-        if 'gemm_' not in r['Kernel_Name'] or 'ss::' not in r['Kernel_Name']:
+        if 'gemm_' not in r['Kernel_Name'] or 'ss::' not in r['Kernel_Name'] or 'splitk' in r['Kernel_Name']:
             continue
         e = disp.setdefault(int(r['Dispatch_Id']), {'kernel': r['Kernel_Name'].replace('void ss::(anonymous namespace)::', '').split('(')[0],
                                                      'us': (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, 'c': {}})
@@ -39,7 +41,7 @@ def main():
                'hbm_read_bytes': rd, 'hbm_write_bytes': wr, 'mfma_busy_pct': busy,
                'lds_bank_conflict_cycles': c.get('SQ_LDS_BANK_CONFLICT'), 'lds_idx_active_cycles': c.get('SQ_LDS_IDX_ACTIVE')}
         out.append(rec)
-        lines.append(f"{name:30s} {rec['kernel']:48s} {rec['us']:7.1f} us {rec['tflops']:6.1f} TF  HBM read {rd / 1e6:6.1f} MB  write {wr / 1e6:5.1f} MB"
+        lines.append(f"{name:72s} {rec['kernel'][:58]:58s} {rec['us']:7.1f} us {rec['tflops']:6.1f} TF  HBM read {rd / 1e6:6.1f} MB  write {wr / 1e6:5.1f} MB"
                      + (f"  MFMA pipe busy {busy:4.1f} %" if busy is not None else ''))
     json.dump(out, open(sys.argv[4] + '.json', 'w'), indent=1)
     with open(sys.argv[4] + '.txt', 'w') as f:

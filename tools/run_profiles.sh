@@ -2,7 +2,7 @@
 # Regenerates everything kept under profiles/<round>/ on a GPU box: gpurun -- 'bash tools/run_profiles.sh r01'
 # (GPU tests first; later steps only run if the earlier ones succeeded)
 set -e -o pipefail
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/$R
 mkdir -p $O
 export TMPDIR=/tmp
@@ -24,8 +24,12 @@ head -12 $O/step_breakdown.txt
 SS_DIAG_LIB=1 timeout -k 10 120 python3 tools/kbench.py seq 2>&1 | grep -v amdgpu.ids > $O/kbench_seq_ablation.txt || true
 SS_DIAG_LIB=1 timeout -k 10 120 python3 tools/kbench.py seqtag 2>&1 | grep -v amdgpu.ids > $O/kbench_seq_handoff.txt || true
 SS_DIAG_LIB=1 timeout -k 10 120 python3 tools/kbench.py gws gabl 2>&1 | grep -v amdgpu.ids > $O/kbench_gemm_forms.txt || true
+timeout -k 10 200 python3 tools/img_bench.py 2>&1 | grep -v amdgpu.ids > $O/img_gemm.txt || true
+SS_DIAG_LIB=1 timeout -k 10 200 python3 tools/img_bench.py diag 2>&1 | grep -v amdgpu.ids > $O/img_gemm_ablation.txt || true
+bash tools/dp_timeline.sh $R/dp 8 > $O/dp_timeline.log 2>&1 || true
+cp $O/dp/dp_timeline_buckets.txt $O/dp/dp_timeline_round2.txt $O/dp/dp_step_timeline_buckets.txt profiles/$R/ 2>/dev/null || true
 timeout -k 10 200 python3 tools/seq_stride_probe.py layouts 2>&1 | grep -v amdgpu.ids > $O/seq_operand_temperature.txt || true
 timeout -k 10 200 python3 tools/f16x2_error.py 2>&1 | grep -v amdgpu.ids > $O/f16x2_error.txt || true
-cp $O/bench_kernel_stats.csv $O/step_breakdown.txt $O/kbench_seq_ablation.txt $O/kbench_seq_handoff.txt $O/kbench_gemm_forms.txt $O/seq_operand_temperature.txt $O/f16x2_error.txt $O/bench_n1.json profiles/$R/ 2>/dev/null || true
+cp $O/img_gemm.txt $O/img_gemm_ablation.txt $O/bench_kernel_stats.csv $O/step_breakdown.txt $O/kbench_seq_ablation.txt $O/kbench_seq_handoff.txt $O/kbench_gemm_forms.txt $O/seq_operand_temperature.txt $O/f16x2_error.txt $O/bench_n1.json profiles/$R/ 2>/dev/null || true
 cp $O/step_timeline.txt profiles/$R/step_timeline.txt
 rm -rf $O/prof/*/*.db
