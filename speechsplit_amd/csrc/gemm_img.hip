@@ -233,50 +233,90 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_img_kernel(const ImgGemmDe
         const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
         return __builtin_bit_cast(f16x8, u32x4{l2[0], l2[1], h2[0], h2[1]});
     };
-    auto compute = [&](int slot) {
+    // ---- the k-loop as a software pipeline over fragment STAGES.  A k-tile of 32 is NQ stages: k16-step s = q / MH, and (for wave tiles
+    // of four 32-row blocks) the upper / lower pair of blocks h = q % MH.  The fragments of stage q + 1 are requested from LDS BEFORE the
+    // MFMAs of stage q are issued -- into the other half of a register double buffer -- so an LDS read has a whole stage of matrix work
+    // (12 MFMAs = 384 cycles) to land in, also across the tile boundary: the boundary (wait for the DMA of tile t + 1, barrier, request
+    // tile t + NSLOT) sits inside the LAST stage of tile t, whose fragments are in registers by then.  (hipcc's own order was
+    // read-everything / s_waitcnt lgkmcnt(0) / multiply, three times per k16-step: 238 us on the 8192 x 4096 x 1024 projection of which
+    // 104 were MFMA time, profiles/r03/img_gemm_ablation.txt.)
+    constexpr int MH = MI >= 4 ? 2 : 1, MIH = MI / MH, NQ = 2 * MH;
+    f16x8 ah[2][MIH], al[2][MIH], bh[2][NI], bl[2][NI];
+    auto load_stage = [&](int slot, int q) {              // q: compile-time after unrolling
         const unsigned char* sa = smem + slot * SLOT;
         const unsigned char* sb = sa + PART_A;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            f16x8 ah[MI], al[MI], bh[NI], bl[NI];
+        const int s = q / MH, h = q % MH, par = q & 1;
+        if (h == 0) {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                bh[ni] = frag(sb, TB, BN, fb[ni], s, 0);
-                bl[ni] = frag(sb, TB, BN, fb[ni], s, 1);
+                bh[s & 1][ni] = frag(sb, TB, BN, fb[ni], s, 0);
+                bl[s & 1][ni] = frag(sb, TB, BN, fb[ni], s, 1);
             }
+        }
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                ah[mi] = frag(sa, TA, BM, fa[mi], s, 0);
-                al[mi] = frag(sa, TA, BM, fa[mi], s, 1);
-            }
-            if (IDIAG(d, 2)) {      // diag 2 (wrong results): no MFMAs -> DMA + fragment-read rate
-                acc[0][0][0] += (float)ah[0][0] + (float)al[MI - 1][1] + (float)bh[NI - 1][2] + (float)bl[0][3];
-                continue;
-            }
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    f32x16 c = acc[mi][ni];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], c, 0, 0, 0);
-                    acc[mi][ni] = c;
-                }
+        for (int i = 0; i < MIH; ++i) {
+            ah[par][i] = frag(sa, TA, BM, fa[h * MIH + i], s, 0);
+            al[par][i] = frag(sa, TA, BM, fa[h * MIH + i], s, 1);
         }
     };
-
-    // ---- the ring: tile t lives in slot t % NSLOT
+    // part 0: the first product (h . l) of every accumulator tile of the stage; part 1: the other two
+    auto mfma_stage = [&](int q, int part) {
+        const int s = q / MH, h = q % MH, par = q & 1;
+        if (IDIAG(d, 2)) {      // diag 2 (wrong results): no MFMAs -> DMA + fragment-read rate
+            if (part == 0) acc[0][0][0] += (float)ah[par][0][0] + (float)al[par][MIH - 1][1] + (float)bh[s & 1][NI - 1][2] + (float)bl[s & 1][0][3];
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < MIH; ++i)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                f32x16 c = acc[h * MIH + i][ni];
+                if (part == 0) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[par][i], bl[s & 1][ni], c, 0, 0, 0);
+                else {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[par][i], bh[s & 1][ni], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[par][i], bh[s & 1][ni], c, 0, 0, 0);
+                }
+                acc[h * MIH + i][ni] = c;
+            }
+    };
+    // boundary in front of tile t (tile t lives in slot t % NSLOT): my LDS reads are through and my DMAs of tile t have landed (with
+    // NSLOT - 2 younger tiles still in flight in the steady state); behind the barrier everyone's have, and nobody reads slot
+    // (t - 1) % NSLOT any more, which is where tile t + NSLOT - 1 goes
+    auto boundary = [&](int t) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (NSLOT > 2 && t + NSLOT - 2 < nk) wait_vm<(NSLOT - 2) * (NA + NB)>();
+        else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + NSLOT - 1 < nk && !IDIAG(d, 1)) issue((t + NSLOT - 1) % NSLOT);
+    };
 #pragma unroll
     for (int t = 0; t < NSLOT - 1; ++t)
         if (t < nk && !IDIAG(d, 1)) issue(t);
+    if (nk > 0) {
+        boundary(0);
+        load_stage(0, 0);
+    }
+    int slot = 0;
     for (int t = 0; t < nk; ++t) {
-        // my DMAs of tile t have landed; with NSLOT - 2 younger tiles still in flight in the steady state
-        if (NSLOT > 2 && t + NSLOT - 2 < nk) wait_vm<(NSLOT - 2) * (NA + NB)>();
-        else wait_vm<0>();
-        __builtin_amdgcn_s_barrier();           // everyone's have; and nobody reads slot (t - 1) % NSLOT any more
-        if (t + NSLOT - 1 < nk && !IDIAG(d, 1)) issue((t + NSLOT - 1) % NSLOT);
-        compute(t % NSLOT);
+        const int nslot = slot + 1 == NSLOT ? 0 : slot + 1;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            // [first products of stage q] [reads of stage q + 1] [rest of stage q]: the wait in front of the first MFMA then covers exactly
+            // the stage's own reads (hipcc waits for lgkmcnt(0) whatever is outstanding), and the next stage's reads have the remaining
+            // eight MFMAs and the next stage's first four to land in.  The order is pinned: hipcc's scheduler sinks LDS reads to their use
+            mfma_stage(q, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 1 < NQ) load_stage(slot, q + 1);
+            else if (t + 1 < nk) {
+                boundary(t + 1);
+                load_stage(nslot, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_stage(q, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        slot = nslot;
     }
 
     // ---- epilogue
