@@ -789,6 +789,18 @@ hipError_t adam_step(float* p, const float* g, float* m, float* v, long n, AdamS
                      const float* status, hipStream_t s) {
     if (n % 4 != 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, s, st, sticky, status);
+    return adam_range(p, g, m, v, n, st, grad_scale, s);
+}
+
+// the update of one range of the arenas under the step state an earlier adam_prepare set (a step may update its ranges as their
+// gradients become final)
+hipError_t adam_prepare(AdamState* st, unsigned* sticky, const float* status, hipStream_t s) {
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, s, st, sticky, status);
+    return hipGetLastError();
+}
+hipError_t adam_range(float* p, const float* g, float* m, float* v, long n, AdamState* st, float grad_scale, hipStream_t s) {
+    if (n % 4 != 0 || (((size_t)p | (size_t)g | (size_t)m | (size_t)v) & 15)) return hipErrorInvalidValue;
+    if (n == 0) return hipSuccess;
     long blocks = (n / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, s, p, g, m, v, n / 4, st, grad_scale);

@@ -22,7 +22,7 @@
 using namespace ss;
 
 namespace ss {
-extern int g_small_lds, g_gemm_tr, g_deterministic;
+extern int g_small_lds, g_small_prio, g_gemm_tr, g_deterministic;
 extern int g_img_cfg;
 extern int g_lstm_nw, g_lstm_g, g_lstm_mode, g_gemm_bk, g_gemm_want, g_gemm_diag, g_seq_prio, g_gemm_mode, g_seq_spin_log2, g_seq_tag, g_seq_wlead, g_gemm_ws;
 int g_fwd_f16x2 = 1;   // 1: forward contractions (operands bounded by construction: mel, one-hot, GroupNorm/ReLU outputs, |h| < 1, weights)
@@ -81,6 +81,7 @@ int g_prio_order = 1;  // 1: within every phase the critical-path launches are E
                        //    queues; when two engine streams share one (other streams in the process, e.g. RCCL's, shift the assignment), enqueue
                        //    order is execution order, and filler work enqueued first would run in front of the critical path.
 int g_probe_queues = 1; // 1: ss_bind measures which candidate streams share a hardware queue and picks branch streams that do not (pick_streams)
+int g_adam_early = 1;   // one-GPU fused steps: the decoder + head range of Adam beside the encoder backward (ss_tune("adam_early"))
 int g_exp = 0;         // bits that switch individual schedule choices back for same-box A/B runs (bench.py --tune exp=N); 0 in production
 int g_conv_par = 1;    // 1: the two conv streams of an Encoder_7 layer (and the layer's resampling plan) run on two engine streams in the forward
 int g_early_join = 1;  // 1: join events of branch streams are recorded right behind the last kernel the consumer needs (lstm_bwd's dx_ready)
@@ -201,6 +202,11 @@ struct ss_engine {
     bool fwd_training = false;
     const float *late_org = nullptr, *late_emb = nullptr;   // fused training step: x_org / emb still to be copied in (done on the Encoder_t branch)
     bool dec_w_pending = false;            // backward_decoder(late): the decoder's + head's weight gradients are still to be enqueued
+    // Early Adam (one GPU, Adam inside the step): the decoder + head range of the arenas (80 % of the bytes) is updated on the side stream
+    // right behind its last weight-gradient GEMM, beside the encoder backward (GEMM-bound, HBM mostly idle), instead of at the step's end
+    bool adam_early = false;               // this step wants it (set by the fused train steps)
+    float adam_early_gs = 1.0f;
+    long adam_early_from = -1;             // >= 0: the range [adam_early_from, arena) has been enqueued, the step state prepared
     bool prezero = false;                  // fused training step: zero the gradient arena on a branch stream during the forward
     bool grads_zeroed = false;             // ... done: backward_decoder must not zero it again
     bool have_fwd = false;
@@ -1840,6 +1846,15 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
         if (l_lo == 0) {
             CHK(head_weight_grads(e, e->side));
             e->dec_w_pending = false;
+            if (e->adam_early && g_adam_early && !e->dp_on && e->Mm && e->Vv) {
+                // every persistent recurrence and the parameter guard ran before the event this stream waited for: the status word is final
+                const long from = ss_grad_split(e);
+                if (from % 4 == 0 && from < e->arena) {
+                    HIPCHK(adam_prepare(e->adam, e->sticky, nullptr, e->side));
+                    HIPCHK(adam_range(e->P + from, e->G + from, e->Mm + from, e->Vv + from, e->arena - from, e->adam, e->adam_early_gs, e->side));
+                    e->adam_early_from = from;
+                }
+            }
         }
         e->side_used = true;
         return 0;
@@ -2116,9 +2131,25 @@ int ss_set_adam(ss_engine* e, double lr, double b1, double b2, double eps, long 
 // (the device-side guard in adam_prepare_kernel is what protects the parameters)
 static int adam_enqueue(ss_engine* e, float grad_scale, hipStream_t s) {
     if (!e->ws || !e->Mm || !e->Vv) return fail("ss_adam_step: Adam arenas are not bound");
+    if (e->adam_early_from >= 0) {         // the decoder + head range went out beside the encoder backward (backward_encoder): the rest, same step state
+        const long n = e->adam_early_from;
+        e->adam_early_from = -1;
+        HIPCHK(adam_range(e->P, e->G, e->Mm, e->Vv, n, e->adam, grad_scale, s));
+        return 0;
+    }
     HIPCHK(adam_step(e->P, e->G, e->Mm, e->Vv, e->arena, e->adam, grad_scale, e->sticky, e->G + e->status_off, s));
     return 0;
 }
+// a fused training step announces that Adam follows its backward inside the same call
+struct AdamEarly {
+    ss_engine* e;
+    AdamEarly(ss_engine* e_, bool on, float gs) : e(e_) {
+        e->adam_early = on;
+        e->adam_early_gs = gs;
+        e->adam_early_from = -1;
+    }
+    ~AdamEarly() { e->adam_early = false; }
+};
 
 int ss_adam_step(ss_engine* e, float grad_scale, void* stream) {
     CHK(entry_check(e));
@@ -2250,7 +2281,10 @@ static int g3_step_body(ss_engine* e, const float* mel, const float* f0, const f
         }
         return 0;
     }
-    CHK(backward_core(e, s));                                                               // solver.py:170-171
+    {
+        AdamEarly ae(e, !(flags & SS_STEP_NO_ADAM), grad_scale);
+        CHK(backward_core(e, s));                                                           // solver.py:170-171
+    }
     if (!(flags & SS_STEP_NO_ADAM)) CHK(adam_enqueue(e, grad_scale, s));                    // solver.py:172
     return 0;
 }
@@ -2364,7 +2398,10 @@ int ss_g6_train_step(ss_engine* e, const float* mel, const float* f0_onehot, con
     const int C = e->head_out;
     HIPCHK(ce_loss(e->out_slab + HALO * C, C, TP * C, target_idx, e->d_out_slab + HALO * C, C, TP * C, B, T, C, 1.0f,
                    e->loss_part, loss, s));
-    CHK(backward_core(e, s));
+    {
+        AdamEarly ae(e, !(flags & SS_STEP_NO_ADAM), grad_scale);
+        CHK(backward_core(e, s));
+    }
     if (!(flags & SS_STEP_NO_ADAM)) CHK(adam_enqueue(e, grad_scale, s));
     return 0;
 }
@@ -2553,6 +2590,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "dx_batched" && value >= 0 && value <= 2) g_dx_batched = value;
     else if (k == "conv_want" && value >= 0) g_conv_want = value;
     else if (k == "small_lds" && value >= 0 && value <= 2) g_small_lds = value;
+    else if (k == "small_prio" && (value == 0 || value == 1)) g_small_prio = value;
     else if (k == "gemm_tr" && value >= 0 && value <= 2) g_gemm_tr = value;
 #ifdef SS_DIAG
     else if (k == "graph" && (value == 0 || value == 1)) g_graph = value;
@@ -2561,6 +2599,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "early_join" && (value == 0 || value == 1)) g_early_join = value;
     else if (k == "conv_par" && (value == 0 || value == 1)) g_conv_par = value;
     else if (k == "exp" && value >= 0) g_exp = value;
+    else if (k == "adam_early" && (value == 0 || value == 1)) g_adam_early = value;
     else if (k == "probe_queues" && (value == 0 || value == 1)) g_probe_queues = value;
     else if (k == "prio_order" && (value == 0 || value == 1)) g_prio_order = value;
     else if (k == "flat_rows" && (value == 0 || value == 1)) g_flat_rows = value;

@@ -114,6 +114,8 @@ struct AdamState {        // device-resident so a captured graph can replay the 
 constexpr unsigned SS_STICKY_ABORT = 1u, SS_STICKY_REMOTE = 2u, SS_STICKY_RANGE = 4u;
 // sticky (nullable) / status (nullable: the gradient arena's status slot, summed over the ranks by the all-reduce): when
 // either is non-zero the update is SKIPPED -- parameters, moments and the step counter stay as they are.
+hipError_t adam_prepare(AdamState* st, unsigned* sticky, const float* status, hipStream_t s);
+hipError_t adam_range(float* p, const float* g, float* m, float* v, long n, AdamState* st, float grad_scale, hipStream_t s);
 hipError_t adam_step(float* p, const float* g, float* m, float* v, long n, AdamState* st, float grad_scale, unsigned* sticky,
                      const float* status, hipStream_t s);
 // *status = (*sticky != 0)   (one thread; enqueued behind the decoder's recurrences, in front of the all-reduce that sums it)

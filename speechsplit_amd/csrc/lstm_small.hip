@@ -16,6 +16,7 @@
 
 namespace ss {
 
+int g_small_prio = 1;    // the small recurrences run at s_setprio 3
 int g_small_lds = 1;     // 1: LDS-staged kernels (single-wave variant where it applies), 2: LDS-staged without the single-wave variant,
                         // 0: always the streaming kernels (A/B experiments)
 
@@ -28,7 +29,8 @@ __global__ __launch_bounds__((4 * H > 64 ? 4 * H : 64)) void lstm_small_fwd_kern
                                                                                    const float* __restrict__ whh_f,
                                                                                    const float* __restrict__ whh_b,
                                                                                    float* __restrict__ out,
-                                                                                   float* __restrict__ csave, int T) {
+                                                                                   float* __restrict__ csave, int T, int prio) {
+    if (prio) __builtin_amdgcn_s_setprio(3);       // latency chains: issue ahead of co-resident GEMM waves (ss_tune("small_prio"))
     __shared__ float hs[H];
     __shared__ float gs[4 * H];
     const int b = blockIdx.x, dir = blockIdx.y, n = threadIdx.x;
@@ -74,7 +76,8 @@ __global__ __launch_bounds__((4 * H > 64 ? 4 * H : 64)) void lstm_small_bwd_kern
                                                                                    const float* __restrict__ whh_f,
                                                                                    const float* __restrict__ whh_b,
                                                                                    const float* __restrict__ d_out,
-                                                                                   const float* __restrict__ csave, int T) {
+                                                                                   const float* __restrict__ csave, int T, int prio) {
+    if (prio) __builtin_amdgcn_s_setprio(3);       // latency chains: issue ahead of co-resident GEMM waves (ss_tune("small_prio"))
     __shared__ float dg[4 * H];
     __shared__ float part[4 * H];
     const int b = blockIdx.x, dir = blockIdx.y, n = threadIdx.x;
@@ -169,7 +172,8 @@ __global__ __launch_bounds__((4 * H > 64 ? 4 * H : 64)) void lstm_small_fwd_lds_
                                                                                        const float* __restrict__ whh_f,
                                                                                        const float* __restrict__ whh_b,
                                                                                        float* __restrict__ out,
-                                                                                       float* __restrict__ csave, int T) {
+                                                                                       float* __restrict__ csave, int T, int prio) {
+    if (prio) __builtin_amdgcn_s_setprio(3);       // latency chains: issue ahead of co-resident GEMM waves (ss_tune("small_prio"))
     constexpr int NT = 4 * H > 64 ? 4 * H : 64;
     extern __shared__ __attribute__((aligned(16))) float dyn[];
     float* xs = dyn;
@@ -220,7 +224,8 @@ __global__ __launch_bounds__((4 * H > 64 ? 4 * H : 64)) void lstm_small_fwd_lds_
 template <int H>
 __global__ __launch_bounds__(64) void lstm_small_fwd_wave_kernel(float* __restrict__ gates, const float* __restrict__ whh_f,
                                                                  const float* __restrict__ whh_b, float* __restrict__ out,
-                                                                 float* __restrict__ csave, int T) {
+                                                                 float* __restrict__ csave, int T, int prio) {
+    if (prio) __builtin_amdgcn_s_setprio(3);       // latency chains: issue ahead of co-resident GEMM waves (ss_tune("small_prio"))
     static_assert(4 * H <= 64, "one wave");
     extern __shared__ __attribute__((aligned(16))) float dyn[];
     float* xs = dyn;
@@ -267,7 +272,8 @@ __global__ __launch_bounds__((4 * H > 64 ? 4 * H : 64)) void lstm_small_bwd_lds_
                                                                                        const float* __restrict__ whh_f,
                                                                                        const float* __restrict__ whh_b,
                                                                                        const float* __restrict__ d_out,
-                                                                                       const float* __restrict__ csave, int T) {
+                                                                                       const float* __restrict__ csave, int T, int prio) {
+    if (prio) __builtin_amdgcn_s_setprio(3);       // latency chains: issue ahead of co-resident GEMM waves (ss_tune("small_prio"))
     constexpr int NT = 4 * H > 64 ? 4 * H : 64;
     extern __shared__ __attribute__((aligned(16))) float dyn[];
     float* ga = dyn;
@@ -362,17 +368,17 @@ hipError_t fwd_t(float* gates, const float* wf, const float* wb, float* out, flo
         if (g_small_lds == 1 && bytes <= LDS_BUDGET) {
             hipError_t e = allow_lds(lstm_small_fwd_wave_kernel<H>, bytes);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((lstm_small_fwd_wave_kernel<H>), dim3(B, 2), dim3(64), bytes, s, gates, wf, wb, out, csave, T);
+            hipLaunchKernelGGL((lstm_small_fwd_wave_kernel<H>), dim3(B, 2), dim3(64), bytes, s, gates, wf, wb, out, csave, T, g_small_prio);
             return hipGetLastError();
         }
     }
     if (g_small_lds && bytes <= LDS_BUDGET) {
         hipError_t e = allow_lds(lstm_small_fwd_lds_kernel<H>, bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((lstm_small_fwd_lds_kernel<H>), dim3(B, 2), dim3(NT), bytes, s, gates, wf, wb, out, csave, T);
+        hipLaunchKernelGGL((lstm_small_fwd_lds_kernel<H>), dim3(B, 2), dim3(NT), bytes, s, gates, wf, wb, out, csave, T, g_small_prio);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL((lstm_small_fwd_kernel<H>), dim3(B, 2), dim3(NT), 0, s, gates, wf, wb, out, csave, T);
+    hipLaunchKernelGGL((lstm_small_fwd_kernel<H>), dim3(B, 2), dim3(NT), 0, s, gates, wf, wb, out, csave, T, g_small_prio);
     return hipGetLastError();
 }
 template <int H>
@@ -383,10 +389,10 @@ hipError_t bwd_t(float* gates, const float* wf, const float* wb, const float* d_
     if (g_small_lds && bytes <= LDS_BUDGET) {
         hipError_t e = allow_lds(lstm_small_bwd_lds_kernel<H>, bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((lstm_small_bwd_lds_kernel<H>), dim3(B, 2), dim3(NT), bytes, s, gates, wf, wb, d_out, csave, T);
+        hipLaunchKernelGGL((lstm_small_bwd_lds_kernel<H>), dim3(B, 2), dim3(NT), bytes, s, gates, wf, wb, d_out, csave, T, g_small_prio);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL((lstm_small_bwd_kernel<H>), dim3(B, 2), dim3(NT), 0, s, gates, wf, wb, d_out, csave, T);
+    hipLaunchKernelGGL((lstm_small_bwd_kernel<H>), dim3(B, 2), dim3(NT), 0, s, gates, wf, wb, d_out, csave, T, g_small_prio);
     return hipGetLastError();
 }
 
