@@ -295,6 +295,13 @@ int ss_profile_read(ss_engine* e, int klass, int* launches, double* total_us, do
  * s_memtime ticks every wave spends per k-loop phase; out24 = [4 waves][split+store, barrier, load issue, fragments+MFMA,
  * barrier, k-tiles (wave 0 only)].  Synchronises the device. */
 int ss_debug_gemm_phases(unsigned long long* out24, int reset);
+/* Placement probe: n_wg workgroups (threads, lds_bytes each) write their (XCC_ID, HW_ID) hardware registers to out_dev[2 * n_wg] in launch
+ * order and stay resident for hold_us microseconds.  (How workgroup indices map to XCDs is what the persistent recurrences' group slots
+ * and the image GEMM's XCD filter rely on: tools/xcd_overlap_probe.py.) */
+/* Placement log of ss_op_gemm_img's last work-queue launch made with ss_tune("img_xcc", mask | 0x100): words [0] tiles handed out,
+ * [1] started flag, then per workgroup of the launch (from word 4) XCD (| 0x100: left without work), tiles taken, first and last tick (100 MHz). */
+int ss_debug_img_wq(unsigned* out_host, int words);
+int ss_debug_xcc_map(int n_wg, int threads, int lds_bytes, int hold_us, unsigned* out_dev, void* stream);
 /* named internal slab of the last call ("enc1.xf2", "dec.out2", ...); layout [B, T+4, C], frame t at row t+2 */
 int ss_debug_buffer(ss_engine* e, const char* name, float** ptr_dev, long* rows, long* cols);
 int ss_debug_names(ss_engine* e, char* buf, int cap);

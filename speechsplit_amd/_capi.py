@@ -77,6 +77,8 @@ SYMBOLS = {
     'ss_profile': (_i, [_vp, C.c_uint]),
     'ss_profile_read': (_i, [_vp, _i, C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     'ss_debug_gemm_phases': (_i, [C.POINTER(C.c_ulonglong), _i]),
+    'ss_debug_xcc_map': (_i, [_i, _i, _i, _i, _vp, _vp]),
+    'ss_debug_img_wq': (_i, [C.POINTER(C.c_uint), _i]),
     'ss_tune': (_i, [C.c_char_p, _i]),
     'ss_debug_buffer': (_i, [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(_l), C.POINTER(_l)]),
     'ss_debug_names': (_i, [_vp, C.c_char_p, _i]),

@@ -59,6 +59,7 @@ struct GemmDesc {
     // split uses when the operand is read as fp32 (amax_* null).  The conv trunk's activations carry one (kernels.h act_scales).
     const float* a_pre_scale;
     const float* b_pre_scale;
+    int queue;              // 1 (engine, image GEMM only): work-queue form -- the launch runs on whatever XCDs have CUs to give (ImgGemmDesc::wq)
 };
 
 // C[b][m][n] (+)= sum_k A(m,k) * B(n,k) (+ bias[n]);  fp32 in, fp32 MFMA accumulate (exact fp32 fma chain)
@@ -92,6 +93,13 @@ struct ImgGemmDesc {
     int cfg;                            // -1: choose; 0: 256 x 256, 1: 128 x 128, 2: 256 x 128
     int diag;                           // SS_DIAG builds only
     int gm, gn, bh, bw;                 // filled by the launcher: tile grid and the 2-D block shape of the tile order
+    // Work-queue form (wq != null): the launch is a fixed number of workgroups that take tiles from the counter wq[0] until it runs
+    // out, and a workgroup that finds itself on an XCD outside `xcc_allow` (bit i = XCD i) leaves at once -- so the contraction runs on
+    // the allowed XCDs only, beside a persistent recurrence that occupies the others (workgroups go to XCDs round-robin by index and a
+    // CU mask cannot empty an XCD, so the partition is made by the kernel itself).  wq: two zeroed words per launch ([1]: an allowed
+    // workgroup has started; a workgroup elsewhere only leaves once it is set, or does the work itself after a bounded wait).
+    unsigned* wq;
+    unsigned xcc_allow;
 };
 bool gemm_img_supported(const ImgGemmDesc& d);
 hipError_t launch_gemm_img(const ImgGemmDesc& d, hipStream_t s);

@@ -81,6 +81,14 @@ int g_prio_order = 1;  // 1: within every phase the critical-path launches are E
                        //    queues; when two engine streams share one (other streams in the process, e.g. RCCL's, shift the assignment), enqueue
                        //    order is execution order, and filler work enqueued first would run in front of the critical path.
 int g_probe_queues = 1; // 1: ss_bind measures which candidate streams share a hardware queue and picks branch streams that do not (pick_streams)
+static unsigned* g_img_wq = nullptr;      // queue words (+ placement log) of the test hook's work-queue launches
+constexpr long IMG_WQ_BYTES = 16 + 16 * 1024;
+int g_xcd_dw = 0;       // decoder W_ih gradients beside the backward recurrences on the XCDs they leave free (B <= 48), see ss_engine::wq_pool.
+                        // Off: measured 4.16 vs 4.09 ms at 32 x 128, 3.57 vs 3.53 at 16 x 128 -- the GEMM does run on the free XCDs beside the
+                        // recurrence, but each recurrence stretches by ~40 us (its operand fetches share HBM with the GEMM's streams), the image
+                        // pass and the split-K reduce land beside the input-gradient GEMM on the critical path, and at B <= 32 the encoder
+                        // backward that loses the work is chain-bound, not throughput-bound (profiles/r03/xcd_overlap.txt)
+int g_img_xcc = 0;      // ss_op_gemm_img (test hook): run the image GEMM in its work-queue form on the XCDs of this mask
 int g_adam_early = 1;   // one-GPU fused steps: the decoder + head range of Adam beside the encoder backward (ss_tune("adam_early"))
 int g_exp = 0;         // bits that switch individual schedule choices back for same-box A/B runs (bench.py --tune exp=N); 0 in production
 int g_conv_par = 1;    // 1: the two conv streams of an Encoder_7 layer (and the layer's resampling plan) run on two engine streams in the forward
@@ -202,6 +210,13 @@ struct ss_engine {
     bool fwd_training = false;
     const float *late_org = nullptr, *late_emb = nullptr;   // fused training step: x_org / emb still to be copied in (done on the Encoder_t branch)
     bool dec_w_pending = false;            // backward_decoder(late): the decoder's + head's weight gradients are still to be enqueued
+    // XCD-aware weight gradients (lstm_bwd, ss_tune("xcd_dw")): where the decoder's persistent backward recurrences leave XCDs free
+    // (B <= 48: 2 * ceil(B / 16) groups, one XCD each), the W_ih gradient of layer l + 1 runs as a work-queue image GEMM BESIDE the
+    // recurrence of layer l -- on the free XCDs, because its 128-144 KB workgroups cannot be dispatched to a CU a recurrence workgroup holds
+    unsigned* wq_pool = nullptr;           // zeroed per backward pass: 4 words per work-queue launch
+    int wq_next = 0;
+    static constexpr int WQ_SLOTS = 16;
+    int dec_ih_done = 0;                   // bit l: decoder layer l's W_ih gradient went out beside a recurrence (lstm_late_weights skips it)
     // Early Adam (one GPU, Adam inside the step): the decoder + head range of the arenas (80 % of the bytes) is updated on the side stream
     // right behind its last weight-gradient GEMM, beside the encoder backward (GEMM-bound, HBM mostly idle), instead of at the step's end
     bool adam_early = false;               // this step wants it (set by the fused train steps)
@@ -540,6 +555,7 @@ long ss_engine::carve(int B, int T, bool assign) {
         stg_loss = (float*)take(256);
     }
     qidx = (int*)take((long)B * TP * 4);
+    wq_pool = (unsigned*)take(WQ_SLOTS * 16);
     for (int i = 0; i < 4; ++i) {
         plan[i].S = hp.max_len_seq / hp.min_len_seg + 1;     // model.py:365
         plan[i].ncand = 2 * hp.max_len_seg;                  // model.py:389
@@ -604,7 +620,7 @@ int pick_ksplit(int M, int N, long K) {
 // contraction has to take round 2's kernels (no images, shape outside what the image kernel supports), < 0 on error.
 int try_img_gemm(ss_engine* e, const GemmDesc& d, hipStream_t st) {
     if (!g_img || !(d.flags & GEMM_F16X2) || (d.flags & GEMM_BF16) || !d.a_pre || !d.b_pre) return 0;
-    if (g_cur_klass >= 0 && !((g_img_mask >> g_cur_klass) & 1)) return 0;
+    if (g_cur_klass >= 0 && !((g_img_mask >> g_cur_klass) & 1) && !d.queue) return 0;
     ImgGemmDesc g{};
     g.A = {d.a_pre, d.A.ld, d.A.bstride, d.A.seglen, d.A.segstride};
     g.B = {d.b_pre, d.B.ld, d.B.bstride, d.B.seglen, d.B.segstride};
@@ -653,7 +669,7 @@ int try_img_gemm(ss_engine* e, const GemmDesc& d, hipStream_t st) {
         g.cfg = (g.M >= 256 && g.N >= 128) ? 2 : 1;
         if (g_img_dw_cfg >= 0) g.cfg = g_img_dw_cfg;
         const long t = g.cfg == 2 ? wgs(256, 128) : (g.cfg == 0 ? wgs(256, 256) : wgs(128, 128));
-        long ks = (g_img_dw_wgs + t / 2) / (t > 0 ? t : 1);
+        long ks = ((d.queue ? 2 * g_img_dw_wgs : g_img_dw_wgs) + t / 2) / (t > 0 ? t : 1);       // work-queue form: twice the tiles (finer hand-over when the recurrence beside it ends)
         if (ks > g.K / 512) ks = g.K / 512;
         if (ks > 16) ks = 16;
         if (ks < 1) ks = 1;
@@ -665,6 +681,13 @@ int try_img_gemm(ss_engine* e, const GemmDesc& d, hipStream_t st) {
         }
     } else {
         g.cfg = wgs(256, 256) >= 256 ? 0 : (wgs(256, 128) >= 224 ? 2 : 1);
+    }
+    if (d.queue && e->wq_pool && e->wq_next < ss_engine::WQ_SLOTS) {
+        // work-queue form on every XCD that will give it a CU; one workgroup per CU (128 / 144 KB of LDS), so that none fits beside a
+        // recurrence workgroup
+        if (g.cfg == 1) g.cfg = 2;
+        g.wq = e->wq_pool + 4 * e->wq_next++;
+        g.xcc_allow = 0xFFu;
     }
     if (!gemm_img_supported(g)) return 0;
     HIPCHK(launch_gemm_img(g, st));
@@ -1176,7 +1199,56 @@ int lstm_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
 
 // d_top: gradient slab of the last layer's output [B,TP,2H]; x: forward input; dx: input-gradient view or null
 // weight / bias gradients of one layer from its finished pre-activation gradient slab (full batch, flat over all rows)
-int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am, bool bias_done, hipStream_t ws) {
+// W_ih gradient of decoder layer l (both directions, one launch) as a work-queue image GEMM, in two calls: lstm_wih_split makes the image
+// of the layer's pre-activation gradients (split_image; as soon as its recurrence is through), lstm_wih_gemm_queued contracts it against
+// the layer input's image (the hidden states of layer l - 1, written by the forward recurrence).  `gate` (nullable): the sync words of the
+// persistent recurrence the launch is meant to run beside -- the GEMM is dispatched once that grid is resident (seq_gate).
+bool lstm_wih_queue_ok(ss_engine* e, LstmBlk& lb, int l, const float* am) {
+    if (!g_img || !am || &lb != &e->ld || l < 1 || l >= 3 || !e->dg_img[l] || e->precision != SS_PRECISION_F32 || !g_bwd_f16x2) return false;
+    if (!lb.out_img_valid || !lb.out_img[l - 1] || !e->wq_pool || e->wq_next >= ss_engine::WQ_SLOTS) return false;
+    return lb.pd[l * 2 + 1].wih > lb.pd[l * 2].wih;
+}
+int lstm_wih_split(ss_engine* e, LstmBlk& lb, int l, const float* am, hipStream_t ws) {
+    const long TP = e->curT + 2 * HALO, R = (long)e->curB * TP;
+    HIPCHK(split_image(lb.gates[l], 8L * lb.H, R, 8 * lb.H, am, 0.f, e->dg_img[l], 8L * lb.H, e->gscale + lb.amax0 + l, ws));
+    return 0;
+}
+int lstm_wih_gemm_queued(ss_engine* e, LstmBlk& lb, int l, const float* am, const unsigned* gate, hipStream_t ws) {
+    const int B = e->curB, T = e->curT, H = lb.H;
+    const long TP = T + 2 * HALO, R = (long)B * TP;
+    const int In = lb.in_of(l);
+    const LstmDir &p0 = lb.pd[l * 2], &p1 = lb.pd[l * 2 + 1];
+    if (gate) HIPCHK(seq_gate(gate, B, H, ws));
+    GemmDesc a{};
+    a.A = {lb.gates[l], 8L * H, 4L * H, 0, 0};
+    a.B = {lb.out[l - 1], 2L * H, 0, 0, 0};
+    a.a_pre = e->dg_img[l];
+    a.a_pre_scale = e->gscale + lb.amax0 + l;
+    a.b_pre = lb.out_img[l - 1];
+    a.C = e->G + p0.wih;
+    a.ldc = In;
+    a.cstride = p1.wih - p0.wih;
+    a.M = 4 * H;
+    a.N = In;
+    a.K = (int)R;
+    a.batch = 2;
+    a.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM | GEMM_F16X2;
+    a.amax_a = am;
+    a.ksplit = 4;                   // > 1: the image path cuts the reduction into partial slabs
+    a.queue = 1;
+    const int pi = prof_begin(e, SS_PROF_DEC_DW, ws, 2.0 * a.M * a.N * (double)B * T * a.batch);
+    g_cur_klass = SS_PROF_DEC_DW;
+    const int r = try_img_gemm(e, a, ws);
+    g_cur_klass = -1;
+    prof_end(e, pi, ws);
+    if (r < 0) return r;
+    if (r == 0) return fail("lstm_wih_gemm_queued: the image GEMM refused a shape the engine planned for it");
+    e->dec_ih_done |= 1 << l;
+    return 0;
+}
+
+// part: 0 everything; 2 everything except the W_ih gradient (it went out through lstm_wih_grad_queued)
+int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am, bool bias_done, hipStream_t ws, int part = 0) {
     const int B = e->curB, T = e->curT, H = lb.H;
     const long TP = T + 2 * HALO, R = (long)B * TP;
     const int In = lb.in_of(l);
@@ -1218,7 +1290,7 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
             a.a_pre_scale = dsc;
             a.b_pre = lb.out_img[l - 1];
         }
-        if (!compact) PGEMM_ON(lb.big() ? SS_PROF_DEC_DW : SS_PROF_ENC_LSTM, a, ws);
+        if (!compact && part != 2) PGEMM_ON(lb.big() ? SS_PROF_DEC_DW : SS_PROF_ENC_LSTM, a, ws);
         GemmDesc h{};
         h.A = {dG + 8L * H, 8L * H, 4L * H - 8L * H, 0, 0};                    // forward: rows 1 .., reverse: rows 0 .. of its own columns
         h.B = {lb.out[l], 2L * H, 2L * H + H, 0, 0};                           // forward: rows 0 .. of h_f, reverse: rows 1 .. of h_b
@@ -1280,7 +1352,7 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
         a.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM | (am ? GEMM_F16X2 : 0);
         a.amax_a = am;                              // gradient slab: measured scale; the layer input is O(1)
         a.ksplit = pick_ksplit(a.M, a.N, a.K);
-        PGEMM_ON(lb.big() ? SS_PROF_DEC_DW : SS_PROF_ENC_LSTM, a, ws);
+        if (part != 2 || compact) PGEMM_ON(lb.big() ? SS_PROF_DEC_DW : SS_PROF_ENC_LSTM, a, ws);
         // dW_hh[n][k] = sum_r dG[r][n] * h_prev[r][k];  h_prev = out one row earlier (fwd) / later (reverse)
         GemmDesc h{};
         h.A = {dir == 0 ? dGd + 8L * H : dGd, 8L * H, 0, 0, 0};
@@ -1387,6 +1459,10 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
     const bool persist = lb.big() && g_persist && lstm_seq_supported(B, H);
     const int nch = (lb.big() && !persist) ? make_chains(e, B, s, ch) : 1;
     if (lb.big() && nch == 2) CHK(fork_join(e, s, ch[1].st));
+    // see ss_engine::wq_pool: only with the weight gradients deferred (their usual schedule), on the decoder, where XCDs stay free
+    const bool xcd = persist && &lb == &e->ld && g_xcd_dw && e->side && g_overlap && (g_defer_dw || late_w) && !g_graph && !g_deterministic &&
+                     lstm_seq_free_xcds(B, H) >= 2;
+    bool xcd_split[4] = {false, false, false, false};
     for (int l = lb.L - 1; l >= 0; --l) {
         Slab xi = l == 0 ? x : Slab{lb.out[l - 1], 2L * H};
         Slab dxi = l == 0 ? dx : Slab{lb.dmid[l & 1], 2L * H};
@@ -1418,6 +1494,19 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
                                     (l == 0 && lb.xf && dx.p == lb.d_xc) ? lb.xf : 0, B, T, H, false, false, s));
                 prof_end(e, pi, s);
                 if (pw) CHK(fork_join(e, e->side3, s));
+                // XCD-aware weight gradients: this recurrence leaves XCDs free, the layer above is through -- its W_ih gradient runs beside it
+                if (xcd) {
+                    if (l + 1 < lb.L && xcd_split[l + 1]) {
+                        const float* am1 = e->amax + lb.amax0 + l + 1;
+                        CHK(lstm_wih_gemm_queued(e, lb, l + 1, am1, lb.sync_b(l), e->side));
+                    }
+                    if (l >= 1 && lstm_wih_queue_ok(e, lb, l, am)) {       // this layer's turn comes beside the next recurrence: its image as soon as it is through
+                        CHK(fork_join(e, s, e->side));
+                        CHK(lstm_wih_split(e, lb, l, am, e->side));
+                        xcd_split[l] = true;
+                        e->side_used = true;
+                    }
+                }
             }
             for (int st = 0; st < T && !persist; ++st)
                 for (int c = 0; c < nch; ++c) {
@@ -1477,7 +1566,7 @@ int lstm_late_weights(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t ws, int l_h
         Slab xi = l == 0 ? x : Slab{lb.out[l - 1], 2L * H};
         float* am = (persist && g_bwd_f16x2 && lb.amax0 >= 0) ? e->amax + lb.amax0 + l : nullptr;
         const bool bias_in_kernel = persist && !g_deterministic && lb.pd[l * 2].bhh == lb.pd[l * 2].bih + 4L * H && lb.pd[l * 2 + 1].bhh == lb.pd[l * 2 + 1].bih + 4L * H;
-        CHK(lstm_weight_grads(e, lb, l, xi, am, bias_in_kernel, ws));
+        CHK(lstm_weight_grads(e, lb, l, xi, am, bias_in_kernel, ws, (&lb == &e->ld && ((e->dec_ih_done >> l) & 1)) ? 2 : 0));
         // this layer's gradients (both directions: W_ih, W_hh, b_ih, b_hh -- contiguous in the arena) are final
         if (&lb == &e->ld) CHK(dp_bucket(e, lb.pd[l * 2].wih, lb.pd[l * 2 + 1].bhh + 4L * H - lb.pd[l * 2].wih, ws));
     }
@@ -1739,10 +1828,13 @@ int backward_decoder(ss_engine* e, hipStream_t s, bool late = false) {
     const bool par = e->side2 && g_overlap;
     hipStream_t b2 = par ? e->side2 : s;
     if (par) CHK(fork_join(e, s, b2));
+    e->dec_ih_done = 0;
+    e->wq_next = 0;
     if (e->ld.big()) {
         if (g_persist && lstm_seq_supported(e->curB, e->ld.H)) {
             // the group counters of every layer and their exchange tiles (tags start at 0)
             HIPCHK(hipMemsetAsync(e->ld.zb, 0, e->ld.zb_bytes, b2));
+            if (e->wq_pool) HIPCHK(hipMemsetAsync(e->wq_pool, 0, ss_engine::WQ_SLOTS * 16, b2));
         } else {
             for (int l = 0; l < e->ld.L; ++l)
                 HIPCHK(lstm_pack_w(e->P + e->ld.pd[l * 2].whh, e->P + e->ld.pd[l * 2 + 1].whh, e->ld.wfrag[l], e->ld.H, 1, b2));
@@ -2507,6 +2599,12 @@ int ss_op_gemm_img(const float* a_img, long lda, const float* b_img, long ldb, f
     d.zeros = zeros;
     d.cfg = cfg;
     d.diag = g_gemm_diag;
+    if (g_img_xcc) {                      // test hook for the work-queue form: ss_tune("img_xcc", mask of allowed XCDs; 255 = queue without a filter)
+        if (!g_img_wq) HIPCHK(hipMalloc((void**)&g_img_wq, IMG_WQ_BYTES));
+        HIPCHK(hipMemsetAsync(g_img_wq, 0, (g_img_xcc & 0x100) ? IMG_WQ_BYTES : 8, S(stream)));
+        d.wq = g_img_wq;
+        d.xcc_allow = (unsigned)g_img_xcc;
+    }
     if (!gemm_img_supported(d)) return fail("ss_op_gemm_img: shape / alignment not supported by the image GEMM");
     HIPCHK(launch_gemm_img(d, S(stream)));
     return 0;
@@ -2544,6 +2642,37 @@ int ss_profile_read(ss_engine* e, int klass, int* launches, double* total_us, do
     if (launches) *launches = n;
     if (total_us) *total_us = us;
     if (total_flops) *total_flops = fl;
+    return 0;
+}
+
+// Where do the workgroups of a launch go?  n_wg workgroups of `threads` threads and lds_bytes of LDS each record (XCC_ID register, HW_ID
+// register) in launch order; each then idles `hold_ticks` (100 MHz) so that the whole grid has to be resident at once.
+__global__ void xcc_map_kernel(unsigned* out, long long hold_ticks) {
+    extern __shared__ unsigned char xcc_map_lds[];
+    if (threadIdx.x == 0) {
+        unsigned x, h;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(h));
+        out[2 * blockIdx.x] = x;
+        out[2 * blockIdx.x + 1] = h;
+        xcc_map_lds[0] = (unsigned char)x;
+    }
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < hold_ticks) __builtin_amdgcn_s_sleep(8);
+}
+int ss_debug_xcc_map(int n_wg, int threads, int lds_bytes, int hold_us, unsigned* out_dev, void* stream) {
+    if (!out_dev || n_wg < 1 || threads < 64 || threads > 1024 || lds_bytes < 0 || lds_bytes > 160 * 1024 || hold_us < 0 || hold_us > 2000)
+        return fail("ss_debug_xcc_map: bad arguments");
+    if (lds_bytes > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)xcc_map_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL(xcc_map_kernel, dim3(n_wg), dim3(threads), lds_bytes, S(stream), out_dev, (long long)hold_us * 100);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int ss_debug_img_wq(unsigned* out_host, int words) {
+    if (!out_host || words < 1 || words * 4L > IMG_WQ_BYTES || !g_img_wq) return fail("ss_debug_img_wq: nothing logged / bad size");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out_host, g_img_wq, words * 4L, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -2600,6 +2729,8 @@ int ss_tune(const char* key, int value) {
     else if (k == "conv_par" && (value == 0 || value == 1)) g_conv_par = value;
     else if (k == "exp" && value >= 0) g_exp = value;
     else if (k == "adam_early" && (value == 0 || value == 1)) g_adam_early = value;
+    else if (k == "xcd_dw" && (value == 0 || value == 1)) g_xcd_dw = value;
+    else if (k == "img_xcc" && value >= 0 && value <= 511) g_img_xcc = value;      // bit 8: keep a placement log (ss_debug_img_wq)
     else if (k == "probe_queues" && (value == 0 || value == 1)) g_probe_queues = value;
     else if (k == "prio_order" && (value == 0 || value == 1)) g_prio_order = value;
     else if (k == "flat_rows" && (value == 0 || value == 1)) g_flat_rows = value;

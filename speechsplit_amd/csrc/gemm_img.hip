@@ -67,9 +67,59 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_img_kernel(const ImgGemmDe
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
 
-    // ---- which tile: XCD-contiguous ranges, 2-D blocks of tiles inside a range
+    // ---- work-queue form: leave if this XCD is not ours (see ImgGemmDesc::wq)
+    __shared__ int s_tile;
+    const int total_tiles = d.gm * d.gn * d.batch * d.ksplit;
+    // placement log of the work-queue form (test hook: xcc_allow bit 8): per workgroup [XCD, tiles taken, first tick, last tick] (100 MHz) behind the two queue words
+    const bool wq_log = d.wq && (d.xcc_allow & 0x100u);
+    unsigned log_tiles = 0, log_xcc = 0, log_t0 = 0;
+    if (wq_log) {
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(log_xcc));
+        log_t0 = (unsigned)wall_clock64();
+    }
+    if (d.wq && (d.xcc_allow & 0xFFu) != 0xFFu) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if ((d.xcc_allow >> (xcc & 15u)) & 1u) {
+            if (tid == 0) __hip_atomic_store(d.wq + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            bool seen = false;
+            for (int spins = 0; spins < 4096 && !seen; ++spins) {            // bounded (~0.1 ms): placement is round-robin, an allowed workgroup starts within a microsecond
+                seen = __hip_atomic_load(d.wq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+                if (!seen) __builtin_amdgcn_s_sleep(2);
+            }
+            if (seen) {
+                if (wq_log && tid == 0) {
+                    unsigned* lg = d.wq + 4 + 4 * blockIdx.x;
+                    lg[0] = (log_xcc & 15u) | 0x100u;       // left without work
+                    lg[1] = 0;
+                    lg[2] = log_t0;
+                    lg[3] = (unsigned)wall_clock64();
+                }
+                return;
+            }
+        }
+    }
+  for (;;) {
+    // ---- which tile: XCD-contiguous ranges, 2-D blocks of tiles inside a range (work-queue form: the next tile of the counter)
     int rem = blockIdx.x;
-    {
+    if (d.wq) {
+        __syncthreads();                    // everyone is through with the previous tile: its LDS slots and s_tile are free
+        if (tid == 0) s_tile = (int)__hip_atomic_fetch_add(d.wq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        rem = __builtin_amdgcn_readfirstlane(s_tile);
+        if (rem >= total_tiles) {
+            if (wq_log && tid == 0) {
+                unsigned* lg = d.wq + 4 + 4 * blockIdx.x;
+                lg[0] = log_xcc & 15u;
+                lg[1] = log_tiles;
+                lg[2] = log_t0;
+                lg[3] = (unsigned)wall_clock64();
+            }
+            return;
+        }
+        ++log_tiles;
+    } else {
         const int total = gridDim.x;
         if ((total & 7) == 0) rem = (rem & 7) * (total >> 3) + (rem >> 3);
     }
@@ -357,6 +407,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_img_kernel(const ImgGemmDe
             }
         }
     }
+    if (!d.wq) return;
+  }
 }
 
 // C[b][m][n] (+)= sum_ks part[b * ksplit + ks][m][n] (+ bias[n]) in a fixed order
@@ -420,7 +472,12 @@ hipError_t launch_one(const ImgGemmDesc& d, int gm, int gn, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((long)gm * gn * d.batch * d.ksplit)), dim3(WGM * WGN * 64), LDS, s, d);
+    long grid = (long)gm * gn * d.batch * d.ksplit;
+    if (d.wq) {                              // work-queue form: what the chip holds at once (every XCD gets an eighth of it), never more than there are tiles
+        const long resident = 256L * (LDS <= 80 * 1024 ? 2 : 1);
+        if (grid > resident) grid = resident;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WGM * WGN * 64), LDS, s, d);
     return hipGetLastError();
 }
 

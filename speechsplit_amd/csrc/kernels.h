@@ -186,6 +186,11 @@ hipError_t lstm_seq_bwd(float* gates, const float* whh_f, const float* whh_b, vo
                         const float* csave, unsigned* sync, unsigned* sticky, float* amax, float* gbias_f, float* gbias_b, float* dgs, int xf,
                         int B, int T, int H, bool zero_state, bool time_major, hipStream_t s);
 
+// seq_gate: the stream goes on once the persistent recurrence that owns `sync` is resident (all groups through round 0), see lstm_seq.hip;
+// lstm_seq_free_xcds: how many of the 8 XCDs such a launch leaves free (0: none, or not a persistent shape)
+hipError_t seq_gate(const unsigned* sync, int B, int H, hipStream_t s);
+int lstm_seq_free_xcds(int B, int H);
+
 // streaming pre-read (results unused) of the slabs a persistent recurrence is about to consume: wide [rows][cw] (gates) and one or two
 // narrow ones [rows][cn] (cell states; output gradient), both ends of the sequence first.  Meant for a side stream, beside the recurrence.
 hipError_t slab_prewarm(const float* wide, int cw, const float* n0, const float* n1, int cn, float* sink, int B, int T, bool time_major, hipStream_t s);

@@ -1033,6 +1033,37 @@ hipError_t lstm_seq_bwd(float* gates, const float* whh_f, const float* whh_b, vo
 }
 
 
+// Gate for work that is meant to run BESIDE a persistent recurrence on the XCDs it leaves free (engine.hip, xcd_dw): one wave waits until every
+// member of every group of the launch that owns `sync` has published round 0 of the group protocol -- i.e. the whole recurrence grid is
+// resident -- and only then lets its stream go on.  A work-queue GEMM dispatched behind it finds the recurrence's CUs taken: its
+// workgroups for those XCDs stay undispatched until the recurrence ends, the others take every tile.  (Dispatched BEFORE the recurrence,
+// its persistent workgroups would hold CUs the recurrence needs.)  Bounded: after ~2 ms the gate opens regardless.
+__global__ __launch_bounds__(64) void seq_gate_kernel(const unsigned* __restrict__ sync, int ngroups, int JT) {
+    const int lane = threadIdx.x;
+    const long long t0 = wall_clock64();
+    for (;;) {
+        bool ok = true;
+        for (int i = lane; i < ngroups * JT; i += 64)
+            ok = ok && __hip_atomic_load(sync + 64 + 32 * (i / JT) + i % JT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        if (__all(ok)) return;
+        if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;       // the launch aborted
+        if (wall_clock64() - t0 > 200000) return;                                                       // 2 ms at 100 MHz
+        __builtin_amdgcn_s_sleep(16);
+    }
+}
+hipError_t seq_gate(const unsigned* sync, int B, int H, hipStream_t s) {
+    const int nbt = (B + 15) / 16;
+    if (!lstm_seq_supported(B, H) || 2 * nbt > 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(seq_gate_kernel, dim3(1), dim3(64), 0, s, sync, 2 * nbt, H / 16);
+    return hipGetLastError();
+}
+// XCDs (of 8) that a persistent recurrence over B utterances leaves free: its 2 * ceil(B / 16) groups take one XCD each
+int lstm_seq_free_xcds(int B, int H) {
+    const int nbt = (B + 15) / 16;
+    if (!lstm_seq_supported(B, H) || 2 * nbt > 8) return 0;
+    return 8 - 2 * nbt;
+}
+
 hipError_t slab_prewarm(const float* wide, int cw, const float* n0, const float* n1, int cn, float* sink, int B, int T, bool time_major, hipStream_t s) {
     if (cw % 4 || cn % 4) return hipErrorInvalidValue;
     const int chunks = ((T + 1) / 2 + PREWARM_R - 1) / PREWARM_R;

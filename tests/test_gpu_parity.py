@@ -747,11 +747,22 @@ def test_solver_validation_path_and_prefetcher(E, tmp_path):
     s.train()                       # one iteration + validation print through the prefetcher
 
 
+@pytest.fixture
+def img_queue(E, request):
+    """ss_tune("img_xcc"): 0 = one workgroup per tile; 255 = work-queue form on every XCD; 0xF0 = work-queue form on XCDs 4-7 only (the
+    workgroups that land on XCDs 0-3 leave: the form that runs beside a persistent recurrence holding those XCDs)."""
+    E.tune('img_xcc', request.param)
+    yield request.param
+    E.tune('img_xcc', 0)
+
+
+@pytest.mark.parametrize('img_queue', [0, 255, 0xF0], indirect=True, ids=['grid', 'queue', 'queue_xcd4to7'])
 @pytest.mark.parametrize('cfg', [0, 1, 2])
 @pytest.mark.parametrize('layout', [(False, False), (False, True), (True, True)])
-def test_image_gemm_against_fp64(E, layout, cfg):
+def test_image_gemm_against_fp64(E, layout, cfg, img_queue):
     """gemm_img.hip (operand images, LDS-DMA ring, deterministic split-K): fp32-grade results against fp64 in every layout and tile
-    configuration, with ragged M / N (multiples of 8 / 4 only), K tails of a reduction-major pair, bias, accumulation and split-K."""
+    configuration, with ragged M / N (multiples of 8 / 4 only), K tails of a reduction-major pair, bias, accumulation and split-K --
+    as a plain grid and in the work-queue form (all XCDs / half of them)."""
     ta, tb = layout
     g = torch.Generator().manual_seed(11 + cfg)
     shapes = [(264, 200, 96, 1), (1000, 520, 1024, 1), (512, 512, 4096, 4), (2048, 1024, 2112, 8)]

@@ -189,3 +189,36 @@ def test_deterministic_mode_is_bit_reproducible(E):
     print(f'[determinism] default mode, {steps} steps: max |param diff| between two runs {float((c[0] - e[0]).abs().max()):.3e}; '
           f'deterministic mode: 0 (bit-identical), loss {a[1]:.8f}')
     assert abs(c[1] - a[1]) <= 2e-2 * a[1]          # same training either way (50 steps amplify the summation-order noise to ~3e-3)
+
+
+def test_xcd_aware_weight_gradients_match_default_schedule(E):
+    """ss_tune("xcd_dw", 1): where the decoder's persistent backward recurrences leave XCDs free (B <= 48) the W_ih gradient of layer l + 1 runs
+    as a work-queue image GEMM beside the recurrence of layer l (gemm_img.hip ImgGemmDesc::wq, lstm_seq.hip seq_gate).  Off by default (no
+    gain measured); the schedule must produce the same gradients as the default one to fp32-grade accuracy."""
+    import numpy as np
+    from oracle import weights as W
+    from oracle.gen_fixtures import draws_for, synth_batch
+    B, T = 32, 128
+    hp = W.default_hparams(max_len_pad=T)
+    eng = E.Engine('G3', hp, B, T)
+    eng.load_weights(W.make_weights('G3', hp, 5))
+    mel, f0, emb, lens = synth_batch(77, B, T, 64)
+    draws = draws_for(78, B, 4)
+    d = (np.stack([x[0] for x in draws]), np.stack([x[1] for x in draws]))
+    grads = []
+    for knob in (0, 1, 0):
+        E.tune('xcd_dw', knob)
+        try:
+            loss = float(eng.g3_train_step(mel, f0, emb, lens, d, no_adam=True))
+            eng.check()
+        finally:
+            E.tune('xcd_dw', 0)
+        grads.append((loss, {n: v.clone() for n, v in eng.grad_views().items()}))
+    assert abs(grads[0][0] - grads[1][0]) <= 1e-6 * abs(grads[0][0])
+    worst = 0.0
+    for n, g in grads[0][1].items():
+        den = float(g.abs().max()) + 1e-30
+        worst = max(worst, float((grads[1][1][n] - g).abs().max()) / den)
+        noise = float((grads[2][1][n] - g).abs().max()) / den      # run-to-run spread of the default schedule (split-K atomics)
+        assert float((grads[1][1][n] - g).abs().max()) / den <= max(2e-5, 4 * noise), (n, worst, noise)
+    print(f'[xcd_dw] worst gradient tensor difference between the schedules: {worst:.2e}')

@@ -2,7 +2,11 @@
 """Summarise one training step from a rocprofv3 --kernel-trace CSV: per-kernel totals, stream overlap, busy time."""
 import collections, csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-idx = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+# a step ends with its LAST adam_kernel launch (with the early decoder-range update a step has two: the final one is the adam_kernel whose
+# next Adam-related launch is the next step's adam_prepare_kernel)
+adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name'] or 'adam_prepare_kernel' in r['Kernel_Name']]
+idx = [i for n, i in enumerate(adam) if 'adam_kernel' in rows[i]['Kernel_Name'] and (n + 1 == len(adam) or 'adam_prepare_kernel' in rows[adam[n + 1]]['Kernel_Name'])]
 step = rows[idx[-2] + 1: idx[-1] + 1]
 t0 = min(int(r['Start_Timestamp']) for r in step)
 t1 = max(int(r['End_Timestamp']) for r in step)

@@ -4,7 +4,10 @@ start offset, duration, queue, name, grid.  Shows what is serial and what overla
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
+# a step ends with its LAST adam_kernel launch (with the early decoder-range update a step has two: the final one is the adam_kernel whose
+# next Adam-related launch is the next step's adam_prepare_kernel)
+adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name'] or 'adam_prepare_kernel' in r['Kernel_Name']]
+idx = [i for n, i in enumerate(adam) if 'adam_kernel' in rows[i]['Kernel_Name'] and (n + 1 == len(adam) or 'adam_prepare_kernel' in rows[adam[n + 1]]['Kernel_Name'])]
 step = rows[idx[-2] + 1: idx[-1] + 1]
 t0 = int(step[0]['Start_Timestamp'])
 qs = {}
