@@ -130,6 +130,15 @@ __device__ __forceinline__ float pow2_scale_of(float m) {
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+// (1 - lam) * a + lam * b with the reference's three roundings (model.py:430: two products, one sum, no fused multiply-add).  HIP's
+// __fmul_rn / __fadd_rn are the plain operators, which hipcc is free to contract into an fma after inlining (-ffp-contract=fast is its
+// default; seen in gn_relu_gather_kernel); the pragma takes the contract flag off these three operations wherever they end up.
+__device__ __forceinline__ float ss_lerp_rn(float ol, float a, float l, float b) {
+#pragma clang fp contract(off)
+    const float p = ol * a;
+    const float q = l * b;
+    return p + q;
+}
 // Four consecutive values -> packed fp16 pieces of 16 x the values, (h0 h1, h2 h3, l0 l1, l2 l3), h = fp16(16 v) to nearest,
 // l = fp16(16 v - h) -- exactly what the GEMM's in-loop split produces with its fixed scale.  ss_store_group puts them into an image.
 __device__ __forceinline__ uint4 ss_split_group(float v0, float v1, float v2, float v3) {

@@ -29,6 +29,12 @@ __device__ __forceinline__ float block_group_sum(float v, float* red, float* out
     return out4[(tid & 15) >> 2];
 }
 
+// The normalised value and the affine output of one element, with the roundings spelled out: the forward kernel, its fused form and the
+// backward's recomputation (which decides the ReLU branch) must produce the same bits, and hipcc contracts / vectorises the plain
+// expression differently from kernel to kernel (measured: last-bit differences between gn_relu_fwd_kernel and the fused kernel)
+__device__ __forceinline__ float gn_h(float x, float mean, float rstd) { return __fmul_rn(__fsub_rn(x, mean), rstd); }
+__device__ __forceinline__ float gn_z(float h, float ga, float be) { return __fmaf_rn(h, ga, be); }
+
 __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const float* __restrict__ x, long x_ld, long x_bs,
                                                           float* __restrict__ y, long y_ld, long y_bs,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -61,8 +67,8 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const float* __restric
         if (it < nit && t < T) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float dlt = v[it][j] - mean;
-                ss += dlt * dlt;
+                const float dlt = __fsub_rn(v[it][j], mean);
+                ss = __fmaf_rn(dlt, dlt, ss);
             }
         }
     }
@@ -83,10 +89,102 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const float* __restric
             f32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float z = (v[it][j] - mean) * rstd * ga[j] + be[j];
+                const float z = gn_z(gn_h(v[it][j], mean, rstd), ga[j], be[j]);
                 o[j] = z > 0.f ? z : 0.f;
             }
             *reinterpret_cast<f32x4*>(yb + (long)t * y_ld) = o;
+        }
+    }
+}
+
+// GroupNorm + ReLU + the random resampling that follows it in a training forward (model.py:164-170 then 199-206), one pass: the
+// (T x 64) tile is normalised in registers exactly as gn_relu_fwd_kernel does, left in LDS (row T stays zero: the halo row the
+// gather's i0 + 1 may touch), and the output rows r < nrows[b] are (1 - lam) * tile[i0] + lam * tile[i0 + 1] with the gather's three
+// roundings (interp.hip interp_gather_kernel: bit-identical results), rows past nrows zero.  The normalised slab itself is never
+// written: nobody but the gather reads it (the backward recomputes from the conv output and the statistics).
+// y / y_img: the resampled slab and its pre-split image AT the first real row and the block's first column; P output rows.
+__global__ __launch_bounds__(256) void gn_relu_gather_kernel(const float* __restrict__ x, long x_ld, long x_bs, float* __restrict__ y, long y_ld,
+                                                             long y_bs, float* __restrict__ y_img, const float* __restrict__ img_scale,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ stats, int T, int C, int P, const int* __restrict__ i0,
+                                                             const float* __restrict__ lam, const int* __restrict__ nrows) {
+    __shared__ float red[256];
+    __shared__ float g4[4];
+    extern __shared__ __attribute__((aligned(16))) float gn_tile[];       // [T + 1][64]
+    const int tid = threadIdx.x, l16 = tid & 15, rg = tid >> 4;
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 64 + l16 * 4;
+    const int nit = (T + 15) >> 4;
+    const float* xb = x + b * x_bs + (long)HALO * x_ld + c;
+    f32x4 v[GN_MAXIT];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < GN_MAXIT; ++it) {
+        const int t = rg + it * 16;
+        if (it < nit && t < T) {
+            v[it] = *reinterpret_cast<const f32x4*>(xb + (long)t * x_ld);
+            s += (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]);
+        } else {
+            v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float inv_n = 1.0f / (16.0f * (float)T);
+    const float mean = block_group_sum(s, red, g4, tid) * inv_n;
+    float ss = 0.f;
+#pragma unroll
+    for (int it = 0; it < GN_MAXIT; ++it) {
+        const int t = rg + it * 16;
+        if (it < nit && t < T) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dlt = __fsub_rn(v[it][j], mean);
+                ss = __fmaf_rn(dlt, dlt, ss);
+            }
+        }
+    }
+    const float var = block_group_sum(ss, red, g4, tid) * inv_n;
+    const float rstd = 1.0f / sqrtf(var + GN_EPS);
+    if (rg == 0 && (l16 & 3) == 0) {
+        const int g = (c >> 4);
+        stats[((long)b * (C >> 4) + g) * 2 + 0] = mean;
+        stats[((long)b * (C >> 4) + g) * 2 + 1] = rstd;
+    }
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(beta + c);
+#pragma unroll
+    for (int it = 0; it < GN_MAXIT; ++it) {
+        const int t = rg + it * 16;
+        if (it < nit && t < T) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float z = gn_z(gn_h(v[it][j], mean, rstd), ga[j], be[j]);
+                o[j] = z > 0.f ? z : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(gn_tile + t * 64 + l16 * 4) = o;
+        }
+    }
+    if (rg == 0) *reinterpret_cast<f32x4*>(gn_tile + T * 64 + l16 * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const int live = nrows[b];
+    const float isc = (y_img && img_scale) ? *img_scale : 16.0f;
+    float* yb = y + b * y_bs + blockIdx.x * 64 + l16 * 4;
+    float* yib = y_img ? y_img + b * y_bs + blockIdx.x * 64 + l16 * 4 : nullptr;
+    for (int r = rg; r < P; r += 16) {
+        f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (r < live) {
+            const int i = i0[(long)b * P + r];
+            const float l = lam[(long)b * P + r];
+            const float ol = __fsub_rn(1.0f, l);
+            const f32x4 a = *reinterpret_cast<const f32x4*>(gn_tile + i * 64 + l16 * 4);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(gn_tile + (i + 1) * 64 + l16 * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = ss_lerp_rn(ol, a[j], l, bb[j]);      // model.py:430, three roundings
+        }
+        *reinterpret_cast<f32x4*>(yb + (long)r * y_ld) = o;
+        if (yib) {
+            if (r < live) ss_store_group(yib + (long)r * y_ld, ss_split_group_s(o[0], o[1], o[2], o[3], isc));
+            else *reinterpret_cast<f32x4*>(yib + (long)r * y_ld) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
 }
@@ -96,7 +194,12 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ stats, float* __restrict__ g_gamma,
                                                           float* __restrict__ g_beta, float* __restrict__ g_bias,
-                                                          unsigned* __restrict__ amax, float* __restrict__ part, int B, int T, int C) {
+                                                          unsigned* __restrict__ amax, float* __restrict__ part, int B, int T, int C,
+                                                          const float* __restrict__ src, long src_ld, long src_bs, int P,
+                                                          const float* __restrict__ lam, const int* __restrict__ start) {
+    // src (nullable): the gradient of the RESAMPLED block output [P rows at src, first real row / first column of the block] -- the adjoint of
+    // the training forward's gather (interp.hip interp_scatter_kernel, same terms in the same order: bit-identical) is then taken on the fly
+    // instead of being read from dy, which is only written
     __shared__ float red[256];
     __shared__ float g4[4];
     __shared__ float colred[3][16][64];
@@ -119,11 +222,33 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
         const int t = rg + it * 16;
         if (it < nit && t < T) {
             const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + (long)t * x_ld);
-            const f32x4 dv = *reinterpret_cast<const f32x4*>(db + (long)t * dy_ld);
+            f32x4 dv;
+            if (src) {
+                const int* st = start + (long)b * (T + 1);
+                const float* lm = lam + (long)b * P;
+                const float* sb = src + b * src_bs + c;
+                const int a0 = st[t], a1 = st[t + 1];
+                const int b0 = t > 0 ? st[t - 1] : 0, b1 = t > 0 ? a0 : 0;
+                dv = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int r = a0; r < a1; ++r) {
+                    const float w = 1.0f - lm[r];
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(sb + (long)r * src_ld);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dv[j] = __builtin_fmaf(w, g[j], dv[j]);
+                }
+                for (int r = b0; r < b1; ++r) {
+                    const float w = lm[r];
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(sb + (long)r * src_ld);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dv[j] = __builtin_fmaf(w, g[j], dv[j]);
+                }
+            } else {
+                dv = *reinterpret_cast<const f32x4*>(db + (long)t * dy_ld);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float h = (xv[j] - mean) * rstd;
-                const float z = h * ga[j] + be[j];
+                const float h = gn_h(xv[j], mean, rstd);
+                const float z = gn_z(h, ga[j], be[j]);
                 const float dz = z > 0.f ? dv[j] : 0.f;
                 dgam[j] += dz * h;
                 dbet[j] += dz;
@@ -203,8 +328,8 @@ __global__ __launch_bounds__(256) void gn_relu_mask_kernel(const float* __restri
         const int g = c >> 4;
         const float mean = stats[((long)b * (C >> 4) + g) * 2 + 0];
         const float rstd = stats[((long)b * (C >> 4) + g) * 2 + 1];
-        const float h = (x[b * x_bs + (long)(t + HALO) * x_ld + c] - mean) * rstd;
-        const float z = h * gamma[c] + beta[c];
+        const float h = gn_h(x[b * x_bs + (long)(t + HALO) * x_ld + c], mean, rstd);
+        const float z = gn_z(h, gamma[c], beta[c]);
         mask[(long)b * n + i] = z > 0.f ? 1.f : 0.f;
     }
 }
@@ -577,13 +702,29 @@ hipError_t gn_relu_fwd(const float* x, long x_ld, long x_bs, float* y, long y_ld
     return hipGetLastError();
 }
 
+hipError_t gn_relu_gather(const float* x, long x_ld, long x_bs, float* y, long y_ld, long y_bs, float* y_img, const float* img_scale,
+                          const float* gamma, const float* beta, float* stats, const InterpPlan& p, int B, int T, int C, hipStream_t s) {
+    if (C % 64 != 0 || T > 16 * GN_MAXIT || p.T != T || y_ld % 4 || y_bs % 4 || (((size_t)y) & 15)) return hipErrorInvalidValue;
+    if (y_img && (y_ld % 8 || y_bs % 8 || (((size_t)y_img) & 31))) y_img = nullptr;             // image format v2: groups of eight
+    const int lds = (T + 1) * 64 * 4;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)gn_relu_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(gn_relu_gather_kernel, dim3(C / 64, B), dim3(256), lds, s, x, x_ld, x_bs, y, y_ld, y_bs, y_img, img_scale, gamma, beta,
+                       stats, T, C, p.P, p.i0, p.lam, p.nrows);
+    return hipGetLastError();
+}
+
 hipError_t gn_relu_bwd(const float* x, long x_ld, long x_bs, float* dy, long dy_ld, long dy_bs, const float* gamma,
                        const float* beta, const float* stats, float* g_gamma, float* g_beta, float* g_bias, float* amax, float* part,
-                       int B, int T, int C, hipStream_t s) {
+                       int B, int T, int C, hipStream_t s, const InterpPlan* scatter, const float* src, long src_ld, long src_bs) {
     if (C % 64 != 0 || T > 16 * GN_MAXIT) return hipErrorInvalidValue;
+    if (scatter && (!src || scatter->T != T || src_ld % 4 || src_bs % 4 || (((size_t)src) & 15))) return hipErrorInvalidValue;
     if (!g_deterministic) part = nullptr;
     hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(C / 64, B), dim3(256), 0, s, x, x_ld, x_bs, dy, dy_ld, dy_bs, gamma, beta,
-                       stats, g_gamma, g_beta, g_bias, reinterpret_cast<unsigned*>(amax), part, B, T, C);
+                       stats, g_gamma, g_beta, g_bias, reinterpret_cast<unsigned*>(amax), part, B, T, C, scatter ? src : nullptr, src_ld, src_bs,
+                       scatter ? scatter->P : 0, scatter ? scatter->lam : nullptr, scatter ? scatter->start : nullptr);
     if (part) hipLaunchKernelGGL(gn_part_reduce_kernel, dim3(cdiv(3 * C, 256)), dim3(256), 0, s, part, B, C, g_gamma, g_beta, g_bias);
     return hipGetLastError();
 }

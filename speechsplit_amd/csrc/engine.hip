@@ -83,6 +83,7 @@ int g_prio_order = 1;  // 1: within every phase the critical-path launches are E
 int g_probe_queues = 1; // 1: ss_bind measures which candidate streams share a hardware queue and picks branch streams that do not (pick_streams)
 static unsigned* g_img_wq = nullptr;      // queue words (+ placement log) of the test hook's work-queue launches
 constexpr long IMG_WQ_BYTES = 16 + 16 * 1024;
+int g_gn_gather = 1;    // training forward of the independent trunk chains: GroupNorm + ReLU + resampling gather in one kernel (gn_relu_gather)
 int g_xcd_dw = 0;       // decoder W_ih gradients beside the backward recurrences on the XCDs they leave free (B <= 48), see ss_engine::wq_pool.
                         // Off: measured 4.16 vs 4.09 ms at 32 x 128, 3.57 vs 3.53 at 16 x 128 -- the GEMM does run on the free XCDs beside the
                         // recurrence, but each recurrence stretches by ~40 us (its operand fetches share HBM with the GEMM's streams), the image
@@ -952,7 +953,10 @@ float* grad_img_of(ss_engine* e, const float* p, long R) {
 }
 
 // y = relu(GN(conv5(x)))   x: slab view (ld), y: slab view
-int conv_block_fwd(ss_engine* e, ConvBlk& cb, Slab x, Slab y, hipStream_t s) {
+// gather (nullable): the resampling plan of the training forward -- GroupNorm + ReLU + gather in one kernel straight into gy / gy_img (the
+// resampled slab and its image at the first real row and the block's first column); y is then not written
+int conv_block_fwd(ss_engine* e, ConvBlk& cb, Slab x, Slab y, hipStream_t s, const InterpPlan* gather = nullptr, float* gy = nullptr, long gy_ld = 0,
+                   float* gy_img = nullptr, hipEvent_t gather_ready = nullptr) {
     const int B = e->curB, T = e->curT;
     const long TP = T + 2 * HALO;
     GemmDesc d{};
@@ -973,18 +977,28 @@ int conv_block_fwd(ss_engine* e, ConvBlk& cb, Slab x, Slab y, hipStream_t s) {
     d.want = g_conv_want;
     flatten_rows(d, B, T);
     PGEMM_FWD_ON(SS_PROF_CONV_FWD, d, s);
+    if (gather) {
+        if (gather_ready) HIPCHK(hipStreamWaitEvent(s, gather_ready, 0));
+        HIPCHK(gn_relu_gather(cb.cout, cb.Co, TP * cb.Co, gy, gy_ld, TP * gy_ld, gy_img, e->act_scale + cb.scale_i, e->P + cb.ga, e->P + cb.be, cb.stats,
+                              *gather, B, T, cb.Co, s));
+        return 0;
+    }
     HIPCHK(gn_relu_fwd(cb.cout, cb.Co, TP * cb.Co, y.p, y.ld, TP * y.ld, e->P + cb.ga, e->P + cb.be, cb.stats, B, T, cb.Co, s));
     return 0;
 }
 
 // dy: gradient of the block output (slab view, overwritten in place with the conv-output gradient);
 // x: the block's forward input; dx: where to put the input gradient (p == nullptr: not needed)
-int conv_block_bwd(ss_engine* e, ConvBlk& cb, Slab dy, Slab x, Slab dx, hipStream_t s) {
+// scatter / src (nullable): the block's output was resampled in the forward (training): src is the gradient of the RESAMPLED output (at its
+// first real row and this block's first column, row stride src_ld); the gather's adjoint is taken inside the GroupNorm backward, which
+// writes dy
+int conv_block_bwd(ss_engine* e, ConvBlk& cb, Slab dy, Slab x, Slab dx, hipStream_t s, const InterpPlan* scatter = nullptr, const float* src = nullptr,
+                   long src_ld = 0) {
     const int B = e->curB, T = e->curT;
     const long TP = T + 2 * HALO, R = (long)B * TP;
     float* am = (g_bwd_f16x2 && cb.amax_i >= 0) ? e->amax + cb.amax_i : nullptr;
     HIPCHK(gn_relu_bwd(cb.cout, cb.Co, TP * cb.Co, dy.p, dy.ld, TP * dy.ld, e->P + cb.ga, e->P + cb.be, cb.stats,
-                       e->G + cb.ga, e->G + cb.be, e->G + cb.b, am, cb.part, B, T, cb.Co, s));
+                       e->G + cb.ga, e->G + cb.be, e->G + cb.b, am, cb.part, B, T, cb.Co, s, scatter, src, src_ld, TP * src_ld));
     // the conv-output gradient as an image for the image GEMM (scale: the power of two for the maximum gn_relu_bwd has just measured)
     const float* dimg = nullptr;
     const float* dsc = nullptr;
@@ -1694,6 +1708,13 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
             const float* im = (e->xf_img_valid && i > 0) ? e->xf_img[i - 1] : nullptr;
             Slab x1 = i == 0 ? Slab{e->in_mel, e->hp.dim_freq} : Slab{e->xf[i - 1], CE, im, e->act_scale + e->c1[i - 1].scale_i};
             Slab x2 = i == 0 ? Slab{e->in_f0, e->f0p} : Slab{e->xf[i - 1] + off2, CE, im ? im + off2 : nullptr, e->act_scale + e->c2[i - 1].scale_i};
+            if (training && g_gn_gather) {       // conv -> [GroupNorm + ReLU + gather] per stack: the normalised slab is never written
+                InterpPlan& pl = e->plan[draw0 + i];
+                float* gi = (e->xf_img_valid && e->xf_img[i]) ? e->xf_img[i] + HALO * CE : nullptr;
+                CHK(conv_block_fwd(e, e->c2[i], x2, Slab{y + off2, CE}, b1, &pl, e->xf[i] + HALO * CE + off2, CE, gi ? gi + off2 : nullptr, i == 0 ? plans : nullptr));
+                CHK(conv_block_fwd(e, e->c1[i], x1, Slab{y, CE}, s, &pl, e->xf[i] + HALO * CE, CE, gi, i == 0 ? plans : nullptr));
+                continue;
+            }
             CHK(conv_block_fwd(e, e->c2[i], x2, Slab{y + off2, CE}, b1));
             CHK(conv_block_fwd(e, e->c1[i], x1, Slab{y, CE}, s));
             if (training) {
@@ -1959,8 +1980,11 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
     // conv trunk, last layer first
     for (int i = 2; i >= 0; --i) {
         float* dy = e->d_xf;
+        // training: the adjoint of the layer's resampling, d_xf -> d_act; fused into each block's GroupNorm backward (g_gn_gather) or as a pass of its own
+        const InterpPlan* sc = (training && g_gn_gather) ? &e->plan[e->enc_plan0 + i] : nullptr;
+        const float* sc_src = e->d_xf + HALO * CE;
         if (training) {
-            HIPCHK(interp_scatter(e->plan[e->enc_plan0 + i], e->d_xf + HALO * CE, CE, TP * CE, e->d_act + HALO * CE, CE, TP * CE, CE, B, s));
+            if (!sc) HIPCHK(interp_scatter(e->plan[e->enc_plan0 + i], e->d_xf + HALO * CE, CE, TP * CE, e->d_act + HALO * CE, CE, TP * CE, CE, B, s));
             dy = e->d_act;
         }
         // input gradients of layer i become d_xf (the gradient of xf[i-1]); dy is consumed before it is overwritten
@@ -1971,7 +1995,7 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
         if (i == 0 && g3 && par && !e->dp_on && !g_graph && (g_exp & 2) == 0) CHK(fork_join(e, s, b2));      // tail_par below: the pitch block's stream forks BEFORE the content block is enqueued
         if (g3) {
             Slab x1 = i == 0 ? Slab{e->in_mel, h.dim_freq} : Slab{e->xf[i - 1], CE, bim, e->act_scale + e->c1[i - 1].scale_i};
-            CHK(conv_block_bwd(e, e->c1[i], Slab{dy, CE}, x1, i > 0 ? Slab{dxbuf, CE} : Slab{nullptr, 0}, s));
+            CHK(conv_block_bwd(e, e->c1[i], Slab{dy, CE}, x1, i > 0 ? Slab{dxbuf, CE} : Slab{nullptr, 0}, s, sc, sc_src, CE));
         }
         Slab x2 = i == 0 ? Slab{e->in_f0, e->f0p} : Slab{e->xf[i - 1] + off2, CE, bim ? bim + off2 : nullptr, e->act_scale + e->c2[i - 1].scale_i};
         // Layer 0 is the step's tail: the decoder's weight gradients are through by then, and each of its two weight-gradient GEMMs alone
@@ -1979,7 +2003,7 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
         // data parallelism, where that stream carries the collectives.)
         const bool tail_par = i == 0 && g3 && par && !e->dp_on && !g_graph && (g_exp & 2) == 0;
         hipStream_t s2 = tail_par ? b2 : s;
-        CHK(conv_block_bwd(e, e->c2[i], Slab{dy + off2, CE}, x2, i > 0 ? Slab{dxbuf + off2, CE} : Slab{nullptr, 0}, s2));
+        CHK(conv_block_bwd(e, e->c2[i], Slab{dy + off2, CE}, x2, i > 0 ? Slab{dxbuf + off2, CE} : Slab{nullptr, 0}, s2, sc, sc_src + off2, CE));
         if (tail_par) CHK(fork_join(e, b2, s));
         if (i > 0) {           // the two wide layers' parameters (weight, bias, GroupNorm affine: contiguous) are final; layer 0 rides the last bucket
             if (g3) CHK(dp_bucket(e, e->c1[i].w, e->c1[i].be + e->c1[i].Co - e->c1[i].w, s));
@@ -2730,6 +2754,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "exp" && value >= 0) g_exp = value;
     else if (k == "adam_early" && (value == 0 || value == 1)) g_adam_early = value;
     else if (k == "xcd_dw" && (value == 0 || value == 1)) g_xcd_dw = value;
+    else if (k == "gn_gather" && (value == 0 || value == 1)) g_gn_gather = value;
     else if (k == "img_xcc" && value >= 0 && value <= 511) g_img_xcc = value;      // bit 8: keep a placement log (ss_debug_img_wq)
     else if (k == "probe_queues" && (value == 0 || value == 1)) g_probe_queues = value;
     else if (k == "prio_order" && (value == 0 || value == 1)) g_prio_order = value;

@@ -92,17 +92,17 @@ __global__ __launch_bounds__(256) void interp_gather_kernel(const float* __restr
         for (int c = 4 * threadIdx.x; c < C; c += 4 * blockDim.x) {
             const float4 a = *reinterpret_cast<const float4*>(xa + c), bb = *reinterpret_cast<const float4*>(xb + c);
             float4 v;
-            v.x = __fadd_rn(__fmul_rn(ol, a.x), __fmul_rn(l, bb.x));      // model.py:430, the same three roundings as below
-            v.y = __fadd_rn(__fmul_rn(ol, a.y), __fmul_rn(l, bb.y));
-            v.z = __fadd_rn(__fmul_rn(ol, a.z), __fmul_rn(l, bb.z));
-            v.w = __fadd_rn(__fmul_rn(ol, a.w), __fmul_rn(l, bb.w));
+            v.x = ss_lerp_rn(ol, a.x, l, bb.x);      // model.py:430, the same three roundings as below
+            v.y = ss_lerp_rn(ol, a.y, l, bb.y);
+            v.z = ss_lerp_rn(ol, a.z, l, bb.z);
+            v.w = ss_lerp_rn(ol, a.w, l, bb.w);
             *reinterpret_cast<float4*>(yr + c) = v;
             ss_store_group(yi + c, ss_split_group_s(v.x, v.y, v.z, v.w, isc));
         }
         return;
     }
     for (int c = threadIdx.x; c < C; c += blockDim.x)
-        yr[c] = __fadd_rn(__fmul_rn(ol, xa[c]), __fmul_rn(l, xb[c]));      // model.py:430
+        yr[c] = ss_lerp_rn(ol, xa[c], l, xb[c]);      // model.py:430
 }
 
 // Outer call of the training step (solver.py:160-163): x = [mel(80) | f0(1)], resample, quantise the f0 channel,
@@ -125,8 +125,8 @@ __global__ __launch_bounds__(128) void interp_quant_kernel(const float* __restri
         const float l = lam[(long)b * P + r];
         const float ol = __fsub_rn(1.0f, l);
         const float* ma = mel + ((long)b * T + i) * CM;
-        for (int c = tid; c < CM; c += 128) ym[c] = __fadd_rn(__fmul_rn(ol, ma[c]), __fmul_rn(l, ma[CM + c]));
-        if (tid == 0) f = __fadd_rn(__fmul_rn(ol, f0[(long)b * T + i]), __fmul_rn(l, f0[(long)b * T + i + 1]));
+        for (int c = tid; c < CM; c += 128) ym[c] = ss_lerp_rn(ol, ma[c], l, ma[CM + c]);
+        if (tid == 0) f = ss_lerp_rn(ol, f0[(long)b * T + i], l, f0[(long)b * T + i + 1]);
     } else {
         for (int c = tid; c < CM; c += 128) ym[c] = 0.f;
     }
@@ -158,8 +158,8 @@ __global__ __launch_bounds__(256) void interp_scatter_kernel(const float* __rest
     float* dxr = dx + b * dx_bs + (long)i * dx_ld;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float acc = 0.f;
-        for (int r = a0; r < a1; ++r) acc += (1.0f - lm[r]) * dyb[r * dy_ld + c];
-        for (int r = b0; r < b1; ++r) acc += lm[r] * dyb[r * dy_ld + c];
+        for (int r = a0; r < a1; ++r) acc = __builtin_fmaf(1.0f - lm[r], dyb[r * dy_ld + c], acc);      // (the fused form in gn_relu_bwd_kernel: same terms, same order, same fma)
+        for (int r = b0; r < b1; ++r) acc = __builtin_fmaf(lm[r], dyb[r * dy_ld + c], acc);
         dxr[c] = acc;
     }
 }

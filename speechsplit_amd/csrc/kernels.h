@@ -38,13 +38,20 @@ hipError_t interp_scatter(const InterpPlan& p, const float* dy, long dy_ld, long
 // GroupNorm(16 channels per group, eps 1e-5, biased variance over 16 x T) + ReLU on rows [HALO, HALO+T) of haloed slabs.
 hipError_t gn_relu_fwd(const float* x, long x_ld, long x_bs, float* y, long y_ld, long y_bs, const float* gamma,
                        const float* beta, float* stats /*[B, C/16, 2] mean, rstd*/, int B, int T, int C, hipStream_t s);
+// the same followed by the training forward's random resampling of the block output (interp_gather), in one pass: y / y_img are the
+// resampled slab and its image AT the first real row and the block's first column (p.P output rows); bit-identical to the two kernels
+hipError_t gn_relu_gather(const float* x, long x_ld, long x_bs, float* y, long y_ld, long y_bs, float* y_img, const float* img_scale,
+                          const float* gamma, const float* beta, float* stats, const InterpPlan& p, int B, int T, int C, hipStream_t s);
 // dy (grad of the ReLU output) is replaced in place by the grad of the GroupNorm input (= conv output).
 // g_gamma / g_beta / g_bias [C]: every utterance's d_gamma, d_beta, d_convbias are ACCUMULATED here (f32 atomics).
 // amax (nullable): receives max |conv-output gradient| written, as for lstm_seq_bwd.
 // part (nullable): [B][3][C] scratch; in deterministic mode the per-utterance sums go there and are added in utterance order.
+// scatter / src (nullable): take the adjoint of the training forward's gather on the fly from src (the gradient of the resampled output, at its
+// first real row and the block's first column) instead of reading dy (interp_scatter fused in; dy is then only written)
 hipError_t gn_relu_bwd(const float* x, long x_ld, long x_bs, float* dy, long dy_ld, long dy_bs, const float* gamma,
                        const float* beta, const float* stats, float* g_gamma, float* g_beta, float* g_bias, float* amax, float* part,
-                       int B, int T, int C, hipStream_t s);
+                       int B, int T, int C, hipStream_t s,
+                       const InterpPlan* scatter = nullptr, const float* src = nullptr, long src_ld = 0, long src_bs = 0);
 // test hook: mask [B, T, C] dense = 1.0f where the block's GroupNorm output is > 0 (the ReLU branch the kernels above take)
 hipError_t gn_relu_mask(const float* x, long x_ld, long x_bs, const float* gamma, const float* beta, const float* stats,
                         float* mask, int B, int T, int C, hipStream_t s);

@@ -222,3 +222,44 @@ def test_xcd_aware_weight_gradients_match_default_schedule(E):
         noise = float((grads[2][1][n] - g).abs().max()) / den      # run-to-run spread of the default schedule (split-K atomics)
         assert float((grads[1][1][n] - g).abs().max()) / den <= max(2e-5, 4 * noise), (n, worst, noise)
     print(f'[xcd_dw] worst gradient tensor difference between the schedules: {worst:.2e}')
+
+
+def test_fused_groupnorm_resampling_is_bit_identical(E):
+    """ss_tune("gn_gather"): GroupNorm + ReLU + the resampling gather in one kernel (forward) and the gather's adjoint inside the GroupNorm
+    backward are the same arithmetic in the same order as the separate kernels: in deterministic mode the output and EVERY gradient bit match."""
+    import numpy as np
+    from oracle import weights as W
+    from oracle.gen_fixtures import draws_for, synth_batch
+    for kind, B, T in (('G3', 5, 128), ('G6', 3, 192)):
+        hp = W.default_hparams(max_len_pad=T)
+        eng = E.Engine(kind, hp, B, T)
+        eng.load_weights(W.make_weights(kind, hp, 6))
+        mel, f0, emb, lens = synth_batch(91, B, T, 64)
+        ncalls = 4 if kind == 'G3' else 3
+        draws = draws_for(92, B, ncalls)
+        d = (np.stack([x[0] for x in draws]), np.stack([x[1] for x in draws]))
+        if kind == 'G6':
+            from oracle import interp_np
+            q = torch.from_numpy(interp_np.quantize_f0(f0[:, :, 0].numpy()))
+            oh = torch.nn.functional.one_hot(q, 257).float()
+        res = []
+        E.tune('deterministic', 1)
+        try:
+            for knob in (0, 1, 0):              # the two separate-kernel runs also show that the comparison itself is bit-reproducible
+                E.tune('gn_gather', knob)
+                if kind == 'G3':
+                    loss = eng.g3_train_step(mel, f0, emb, lens, d, no_adam=True)
+                else:
+                    loss = eng.g6_train_step(mel, oh, q, d, no_adam=True)
+                eng.check()
+                res.append((float(loss), eng.debug_buffer('out', B, T).clone(), {n: v.clone() for n, v in eng.grad_views().items()}))
+        finally:
+            E.tune('gn_gather', 1)
+            E.tune('deterministic', 0)
+        assert res[0][0] == res[2][0] and torch.equal(res[0][1], res[2][1]), (kind, 'the separate-kernel schedule is not bit-reproducible')
+        nd = int((res[0][1] != res[1][1]).sum())
+        assert res[0][0] == res[1][0], (kind, res[0][0], res[1][0])
+        assert nd == 0, (kind, nd, float((res[0][1] - res[1][1]).abs().max()))
+        for n, g in res[0][2].items():
+            assert torch.equal(g, res[2][2][n]), (kind, n, 'not reproducible')
+            assert torch.equal(g, res[1][2][n]), (kind, n, float((g - res[1][2][n]).abs().max()), float(g.abs().max()))
