@@ -451,6 +451,18 @@ __global__ __launch_bounds__(256) void conv_unpack_grad_kernel(const float* __re
     }
 }
 
+// the same for several blocks in one launch (blockIdx.y = block): the one-GPU step unpacks every conv weight gradient at the end of the backward
+__global__ __launch_bounds__(256) void conv_unpack_grads_kernel(ConvUnpackTable tb) {
+    const ConvUnpackTask t = tb.t[blockIdx.y];
+    const long n = (long)t.Co * t.Ci * 5;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int k = (int)(i % 5);
+        const int ci = (int)((i / 5) % t.Ci);
+        const int co = (int)(i / (5L * t.Ci));
+        t.g[i] = t.gp[((long)co * 5 + k) * t.Cp + ci];
+    }
+}
+
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int R, int C, float* __restrict__ out) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
@@ -786,6 +798,13 @@ hipError_t conv_unpack_grad(const float* gp, int Co, int Ci, int Cp, float* g, h
     int gr = cdiv((long)Co * Ci * 5, 256);
     if (gr > 2048) gr = 2048;
     hipLaunchKernelGGL(conv_unpack_grad_kernel, dim3(gr), dim3(256), 0, s, gp, Co, Ci, Cp, g);
+    return hipGetLastError();
+}
+
+hipError_t conv_unpack_grads(const ConvUnpackTable& tb, hipStream_t s) {
+    if (tb.n <= 0) return hipSuccess;
+    if (tb.n > CONV_UNPACK_MAX) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(conv_unpack_grads_kernel, dim3(512, tb.n), dim3(256), 0, s, tb);
     return hipGetLastError();
 }
 

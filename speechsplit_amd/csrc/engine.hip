@@ -83,6 +83,7 @@ int g_prio_order = 1;  // 1: within every phase the critical-path launches are E
 int g_probe_queues = 1; // 1: ss_bind measures which candidate streams share a hardware queue and picks branch streams that do not (pick_streams)
 static unsigned* g_img_wq = nullptr;      // queue words (+ placement log) of the test hook's work-queue launches
 constexpr long IMG_WQ_BYTES = 16 + 16 * 1024;
+int g_unpack_later = 1; // one-GPU step: the conv weight gradients' re-layouts in one launch at the end of the backward
 int g_gn_gather = 1;    // training forward of the independent trunk chains: GroupNorm + ReLU + resampling gather in one kernel (gn_relu_gather)
 int g_xcd_dw = 0;       // decoder W_ih gradients beside the backward recurrences on the XCDs they leave free (B <= 48), see ss_engine::wq_pool.
                         // Off: measured 4.16 vs 4.09 ms at 32 x 128, 3.57 vs 3.53 at 16 x 128 -- the GEMM does run on the free XCDs beside the
@@ -211,6 +212,8 @@ struct ss_engine {
     bool fwd_training = false;
     const float *late_org = nullptr, *late_emb = nullptr;   // fused training step: x_org / emb still to be copied in (done on the Encoder_t branch)
     bool dec_w_pending = false;            // backward_decoder(late): the decoder's + head's weight gradients are still to be enqueued
+    ConvUnpackTable unpack{};              // conv weight gradients waiting for their re-layout (conv_block_bwd)
+    bool unpack_later = false;
     // XCD-aware weight gradients (lstm_bwd, ss_tune("xcd_dw")): where the decoder's persistent backward recurrences leave XCDs free
     // (B <= 48: 2 * ceil(B / 16) groups, one XCD each), the W_ih gradient of layer l + 1 runs as a work-queue image GEMM BESIDE the
     // recurrence of layer l -- on the free XCDs, because its 128-144 KB workgroups cannot be dispatched to a CU a recurrence workgroup holds
@@ -1029,8 +1032,12 @@ int conv_block_bwd(ss_engine* e, ConvBlk& cb, Slab dy, Slab x, Slab dx, hipStrea
     d.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM | (am ? GEMM_F16X2 : 0);
     d.amax_a = am;                                  // gradient operand: measured scale; the block input is O(1)
     d.ksplit = pick_ksplit(d.M, d.N, d.K);
-    PGEMM_ON(SS_PROF_CONV_DW, d, s);
-    HIPCHK(conv_unpack_grad(cb.gp, cb.Co, cb.Ci, cb.Cp, e->G + cb.w, s));
+    if (!(g_exp & 8)) PGEMM_ON(SS_PROF_CONV_DW, d, s);       // (exp & 8, what-if, WRONG gradients: without the conv weight-gradient GEMMs)
+    // packed [Co][5][Cp] -> the parameter's [Co][Ci][5]: nobody reads it before the optimiser (or, data parallel, the layer's bucket), so the
+    // one-GPU step collects the blocks and unpacks them all in one launch at the end of the backward (backward_encoder) instead of seven
+    // small launches on the trunk's dependent chain
+    if (e->unpack_later && e->unpack.n < CONV_UNPACK_MAX) e->unpack.t[e->unpack.n++] = {cb.gp, e->G + cb.w, cb.Co, cb.Ci, cb.Cp};
+    else HIPCHK(conv_unpack_grad(cb.gp, cb.Co, cb.Ci, cb.Cp, e->G + cb.w, s));
     if (dx.p) {
         GemmDesc g{};
         g.A = {dy.p, dy.ld, TP * dy.ld, cb.Co, dy.ld};
@@ -1263,6 +1270,7 @@ int lstm_wih_gemm_queued(ss_engine* e, LstmBlk& lb, int l, const float* am, cons
 
 // part: 0 everything; 2 everything except the W_ih gradient (it went out through lstm_wih_grad_queued)
 int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am, bool bias_done, hipStream_t ws, int part = 0) {
+    if ((g_exp & 4) && lb.big()) return 0;       // what-if (WRONG gradients): the step without the decoder's weight-gradient GEMMs
     const int B = e->curB, T = e->curT, H = lb.H;
     const long TP = T + 2 * HALO, R = (long)B * TP;
     const int In = lb.in_of(l);
@@ -1897,6 +1905,12 @@ int backward_decoder(ss_engine* e, hipStream_t s, bool late = false) {
 // everything below the decoder input: code gradients, encoder BLSTMs, conv trunks.  Touches only gradient-arena
 // offsets below the decoder's, so a data-parallel caller can all-reduce the decoder range meanwhile.
 int backward_encoder(ss_engine* e, hipStream_t s) {
+    e->unpack.n = 0;
+    e->unpack_later = !e->dp_on && !g_graph && g_unpack_later;       // (data parallel: a trunk layer's bucket leaves right behind its block)
+    struct UnpackOff {
+        ss_engine* e;
+        ~UnpackOff() { e->unpack_later = false; }
+    } unpack_off{e};
     const int B = e->curB, T = e->curT;
     const long TP = T + 2 * HALO, R = (long)B * TP;
     const int CE = e->CE;
@@ -2030,6 +2044,10 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
     }
     if (par) CHK(fork_join(e, b3, s));
     CHK(join_side(e, s));
+    if (e->unpack.n) {
+        HIPCHK(conv_unpack_grads(e->unpack, s));
+        e->unpack.n = 0;
+    }
     return 0;
 }
 
@@ -2755,6 +2773,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "adam_early" && (value == 0 || value == 1)) g_adam_early = value;
     else if (k == "xcd_dw" && (value == 0 || value == 1)) g_xcd_dw = value;
     else if (k == "gn_gather" && (value == 0 || value == 1)) g_gn_gather = value;
+    else if (k == "unpack_later" && (value == 0 || value == 1)) g_unpack_later = value;
     else if (k == "img_xcc" && value >= 0 && value <= 511) g_img_xcc = value;      // bit 8: keep a placement log (ss_debug_img_wq)
     else if (k == "probe_queues" && (value == 0 || value == 1)) g_probe_queues = value;
     else if (k == "prio_order" && (value == 0 || value == 1)) g_prio_order = value;

@@ -69,6 +69,17 @@ hipError_t collate(const float* mel_cat, const float* f0_cat, const float* emb_t
 hipError_t conv_pack(const float* w, int Co, int Ci, int Cp, float* wf, float* wb, float* wf_img, float* wb_img, hipStream_t s);
 // packed weight grad [Co][5][Cp] -> grad arena [Co][Ci][5] (overwrite)
 hipError_t conv_unpack_grad(const float* gp, int Co, int Ci, int Cp, float* g, hipStream_t s);
+constexpr int CONV_UNPACK_MAX = 8;
+struct ConvUnpackTask {
+    const float* gp;      // packed gradient [Co][5][Cp]
+    float* g;             // parameter gradient [Co][Ci][5]
+    int Co, Ci, Cp;
+};
+struct ConvUnpackTable {
+    ConvUnpackTask t[CONV_UNPACK_MAX];
+    int n;
+};
+hipError_t conv_unpack_grads(const ConvUnpackTable& tb, hipStream_t s);      // several blocks, one launch
 hipError_t transpose2d(const float* in, int R, int C, float* out, hipStream_t s);   // out[c][r] = in[r][c]
 // out[i] = a[i] + b[i]
 hipError_t add_vec(const float* a, const float* b, float* out, int n, hipStream_t s);
