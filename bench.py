@@ -293,12 +293,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(steps, warmup, profile):
+    def timed(steps, warmup, profile, every=1):
         for _ in range(warmup):
             step()
         barrier()
         if profile:
-            eng.profile(profile)
+            eng.profile(profile, every)
         f0_ = frames_done[0]
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -315,13 +315,17 @@ def main():
         return dt
 
     # survey pass (untimed): every kernel class bracketed, to find the class with the most GPU time; the timed region then
-    # carries brackets on that class and on the recurrences only (all 71 brackets per step cost 4.5 %, these < 1 %)
+    # carries brackets on that class and on the recurrences only, and only in every PROF_EVERY-th step: a bracket costs 4-8 us of
+    # stream time (the launch behind it waits for the one in front to retire), all 71 per step +4.5 %, these 18 +2.9 % if every
+    # step carried them (5.44 vs 5.29 ms measured in one call) -- sampled, under 0.6 %
+    PROF_EVERY = 5
     top, survey = None, None
     if not args.no_profile:
         timed(6, 2, True)
         survey = (eng.profile_read(), 6)
         top = dominant_class(survey[0])
-    dt = timed(args.steps, args.warmup, None if args.no_profile else [top, 'rec_fwd', 'rec_bwd'])
+    dt = timed(args.steps, args.warmup, None if args.no_profile else [top, 'rec_fwd', 'rec_bwd'], PROF_EVERY)
+    bracketed = (args.steps + PROF_EVERY - 1) // PROF_EVERY      # steps of the timed region that carried the brackets
     eng.check()                  # outside the timed region: no persistent kernel reported a bounded-wait expiry
     ms = dt / args.steps * 1e3
     value = B * world / (dt / args.steps)
@@ -329,7 +333,9 @@ def main():
 
     if rank == 0:
         print(f'[bench] gpu: {ms:.3f} ms/step, {value:.1f} utt/s on {world} GPU(s)', file=sys.stderr, flush=True)
-        roof, classes, recur = kernel_report(eng, args.steps, ms, args.precision, top, survey, T if stream is None else mean_T) if top else (None, None, None)
+        roof, classes, recur = kernel_report(eng, bracketed, ms, args.precision, top, survey, T if stream is None else mean_T) if top else (None, None, None)
+        if roof:
+            roof['bracketed_steps'] = f'{bracketed} of the {args.steps} timed steps (every {PROF_EVERY}th: a bracket holds the next launch back by 4-8 us)'
         print(f'[bench] roofline: {roof}', file=sys.stderr, flush=True)
     alt = None
     if not args.no_extras and args.precision == 'f32' and kind == 'G3' and args.workload == 'fixed':

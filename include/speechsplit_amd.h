@@ -274,8 +274,10 @@ int ss_tune(const char* key, int value);
 int ss_set_precision(ss_engine* e, int precision);
 /* Live timing of the step's kernels inside a caller's own timed region.  ss_profile(e, mask) makes the engine bracket every
  * launch of the classes whose bit (1u << class) is set with hipEvents on the stream the launch goes to (a non-zero mask clears
- * the record, 0 stops recording; at most 8192 launches are kept).  A bracket costs ~4 us of stream time: all 71 per step are
- * +4.5 % on the step, the dominant class + the recurrences (18 per step) are below 1 %.  ss_profile_read synchronises on the recorded events of one class and returns their count, their summed duration
+ * the record, 0 stops recording; at most 8192 launches are kept).  A bracket costs 4-8 us of stream time (the launch behind it cannot
+ * start before the one in front has retired and signalled): all 71 per step are +4.5 % on the step, the dominant class + the recurrences
+ * (18 per step) +2.9 % (round 3; the step has become shorter, the brackets have not).  ss_profile_sample(e, n) therefore brackets only
+ * every n-th training step (n = 1: every step; the count starts again with every ss_profile call).  ss_profile_read synchronises on the recorded events of one class and returns their count, their summed duration
  * and their summed algorithmic FLOPs (2*M*N*K per GEMM; 2 * 2 directions * B * T * 4H * H per recurrence launch). */
 #define SS_PROF_DEC_PROJ 0  /* decoder input projection, layers >= 1 (NT, M = B*T, N = 8H, K = 2H) */
 #define SS_PROF_DEC_PROJ0 1 /* decoder input projection, layer 0 (K = 164 / 66) */
@@ -290,6 +292,7 @@ int ss_set_precision(ss_engine* e, int precision);
 #define SS_PROF_HEAD 10     /* LinearNorm head forward / gradients */
 #define SS_PROF_CLASSES 11
 int ss_profile(ss_engine* e, unsigned class_mask);
+int ss_profile_sample(ss_engine* e, int every_nth_step);
 int ss_profile_read(ss_engine* e, int klass, int* launches, double* total_us, double* total_flops);
 /* timing experiment: with ss_tune("gemm_diag", 16) the 128x128 NT bf16x3 GEMM accumulates, for its first 64 workgroups, the
  * s_memtime ticks every wave spends per k-loop phase; out24 = [4 waves][split+store, barrier, load issue, fragments+MFMA,

@@ -301,6 +301,8 @@ struct ss_engine {
     std::vector<ProfRec> prof_rec;
     int prof_n = 0;
     unsigned prof_mask = 0;               // bit k set: launches of class k are bracketed
+    int prof_every = 1, prof_ctr = 0;     // ss_profile_sample: brackets only in every prof_every-th training step
+    bool prof_live = true;                // this step is one of them
 
     long carve(int B, int T, bool assign);
 };
@@ -672,7 +674,7 @@ int try_img_gemm(ss_engine* e, const GemmDesc& d, hipStream_t st) {
     if (d.ksplit > 1 && !g.row_period) {
         g.cfg = (g.M >= 256 && g.N >= 128) ? 2 : 1;
         if (g_img_dw_cfg >= 0) g.cfg = g_img_dw_cfg;
-        const long t = g.cfg == 2 ? wgs(256, 128) : (g.cfg == 0 ? wgs(256, 256) : wgs(128, 128));
+        const long t = (g.cfg == 2 || g.cfg == 3) ? wgs(256, 128) : (g.cfg == 0 ? wgs(256, 256) : wgs(128, 128));
         long ks = ((d.queue ? 2 * g_img_dw_wgs : g_img_dw_wgs) + t / 2) / (t > 0 ? t : 1);       // work-queue form: twice the tiles (finer hand-over when the recurrence beside it ends)
         if (ks > g.K / 512) ks = g.K / 512;
         if (ks > 16) ks = 16;
@@ -870,9 +872,15 @@ int pick_streams(ss_engine* e, hipStream_t main) {
     return 0;
 }
 
+// a training step begins: is it one of the bracketed ones (ss_profile_sample)?
+void prof_tick(ss_engine* e) {
+    e->prof_live = e->prof_every <= 1 || (e->prof_ctr % e->prof_every) == 0;
+    ++e->prof_ctr;
+}
+
 // ss_profile: bracket one launch with hipEvents on the stream it is launched on
 int prof_begin(ss_engine* e, int klass, hipStream_t st, double flops) {
-    if (!((e->prof_mask >> klass) & 1u) || g_graph || e->prof_n >= ss_engine::PROF_CAP) return -1;
+    if (!((e->prof_mask >> klass) & 1u) || !e->prof_live || g_graph || e->prof_n >= ss_engine::PROF_CAP) return -1;
     const int i = e->prof_n;
     while ((int)e->prof_ev.size() < 2 * (i + 1)) {
         hipEvent_t ev;
@@ -1271,6 +1279,7 @@ int lstm_wih_gemm_queued(ss_engine* e, LstmBlk& lb, int l, const float* am, cons
 // part: 0 everything; 2 everything except the W_ih gradient (it went out through lstm_wih_grad_queued)
 int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am, bool bias_done, hipStream_t ws, int part = 0) {
     if ((g_exp & 4) && lb.big()) return 0;       // what-if (WRONG gradients): the step without the decoder's weight-gradient GEMMs
+    if ((g_exp & 16) && !lb.big()) return 0;     // what-if (WRONG gradients): without the encoder BLSTMs' weight-gradient launches
     const int B = e->curB, T = e->curT, H = lb.H;
     const long TP = T + 2 * HALO, R = (long)B * TP;
     const int In = lb.in_of(l);
@@ -2382,6 +2391,7 @@ static int g3_step_body(ss_engine* e, const float* mel, const float* f0, const f
                         hipStream_t s) {
     const ss_hparams& h = e->hp;
     const long TP = T + 2 * HALO;
+    prof_tick(e);
     // solver.py:160-163: resample [mel | f0] with the utterance lengths, re-quantise the f0 channel
     HIPCHK(interp_plan(e->plan[0], scales, len_seg, len_org, 0, B, s));
     HIPCHK(interp_quant(e->plan[0], mel, f0, h.dim_freq, e->in_mel + HALO * h.dim_freq, h.dim_freq, TP * h.dim_freq,
@@ -2527,6 +2537,7 @@ int ss_g6_train_step(ss_engine* e, const float* mel, const float* f0_onehot, con
     CHK(apply_bucket(e, T, flags));
     Own own(e, stream);
     hipStream_t s = own.s;
+    prof_tick(e);
     CHK(ss_g6_forward(e, mel, f0_onehot, scales, len_seg, B, T, 1, nullptr, (void*)s));
     const long TP = T + 2 * HALO;
     const int C = e->head_out;
@@ -2664,6 +2675,16 @@ int ss_profile(ss_engine* e, unsigned class_mask) {
     if (!e) return fail("ss_profile: null engine");
     if (class_mask) e->prof_n = 0;
     e->prof_mask = class_mask;
+    e->prof_ctr = 0;
+    e->prof_live = true;
+    return 0;
+}
+
+int ss_profile_sample(ss_engine* e, int every_nth_step) {
+    if (!e || every_nth_step < 1) return fail("ss_profile_sample: needs an engine and n >= 1");
+    e->prof_every = every_nth_step;
+    e->prof_ctr = 0;
+    e->prof_live = true;
     return 0;
 }
 
@@ -2748,7 +2769,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "img_batch" && (value == 0 || value == 1)) g_img_batch = value;
     else if (k == "dp_model" && value >= 0 && value <= 64) g_dp_model = value;
     else if (k == "dp_buckets" && (value == 0 || value == 1)) g_dp_buckets = value;
-    else if (k == "img_dw_cfg" && value >= -1 && value <= 2) g_img_dw_cfg = value;
+    else if (k == "img_dw_cfg" && value >= -1 && value <= 3) g_img_dw_cfg = value;
     else if (k == "img_dw_wgs" && value >= 32 && value <= 4096) g_img_dw_wgs = value;
     else if (k == "img_cfg" && value >= -1 && value <= 2) g_img_cfg = value;
     else if (k == "dw_wgs" && value >= 64 && value <= 4096) g_dw_wgs = value;

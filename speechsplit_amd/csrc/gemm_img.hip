@@ -498,6 +498,7 @@ hipError_t launch_layout(ImgGemmDesc& d, int cfg, hipStream_t s) {
         }
     if (cfg == 0) return launch_one<128, 64, 2, 4, TA, TB, 2>(d, d.gm, d.gn, s);
     if (cfg == 1) return launch_one<64, 64, 2, 2, TA, TB, 2>(d, d.gm, d.gn, s);
+    if (cfg == 3) return launch_one<64, 64, 4, 2, TA, TB, 2>(d, d.gm, d.gn, s);       // 256 x 128 on two slots: 96 KB, leaves a CU room for a 48 KB neighbour
     return launch_one<64, 64, 4, 2, TA, TB, 3>(d, d.gm, d.gn, s);
 }
 
@@ -528,7 +529,7 @@ hipError_t launch_gemm_img(const ImgGemmDesc& din, hipStream_t s) {
     const bool ta = d.flags & GEMM_TA, tb = d.flags & GEMM_TB;
     int cfg = d.cfg;
     if (g_img_cfg >= 0) cfg = g_img_cfg;
-    if (cfg < 0 || cfg > 2) {
+    if (cfg < 0 || cfg > 3) {
         // the largest tile that still gives every CU a workgroup
         auto wgs = [&](int bm, int bn) { return (long)cdiv(d.M, bm) * cdiv(d.N, bn) * d.batch * d.ksplit; };
         cfg = wgs(256, 256) >= 256 ? 0 : (wgs(256, 128) >= 256 ? 2 : 1);

@@ -353,9 +353,10 @@ class Engine:
     PROF_CLASSES = ('dec_proj', 'dec_proj0', 'dec_dw', 'dec_dx', 'conv_fwd', 'conv_dw', 'conv_dx', 'rec_fwd', 'rec_bwd',
                     'enc_lstm', 'head')
 
-    def profile(self, classes):
+    def profile(self, classes, every=1):
         """ss_profile: bracket the launches of the named classes (True: all; False / empty: stop) with hipEvents; starting
-        clears the record."""
+        clears the record.  every = n: only every n-th training step is bracketed (ss_profile_sample)."""
+        _capi.check(self.lib.ss_profile_sample(self.h, int(every)))
         if classes is True:
             mask = (1 << len(self.PROF_CLASSES)) - 1
         elif not classes:
