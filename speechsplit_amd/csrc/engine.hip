@@ -212,6 +212,7 @@ struct ss_engine {
     bool fwd_training = false;
     const float *late_org = nullptr, *late_emb = nullptr;   // fused training step: x_org / emb still to be copied in (done on the Encoder_t branch)
     bool dec_w_pending = false;            // backward_decoder(late): the decoder's + head's weight gradients are still to be enqueued
+    bool dp_dir_buckets = false;           // lstm_weight_grads handed each direction of the layer to a collective itself
     ConvUnpackTable unpack{};              // conv weight gradients waiting for their re-layout (conv_block_bwd)
     bool unpack_later = false;
     // XCD-aware weight gradients (lstm_bwd, ss_tune("xcd_dw")): where the decoder's persistent backward recurrences leave XCDs free
@@ -1359,6 +1360,10 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
             c.amax_a = am;
             c.ksplit = pick_ksplit(c.M, c.N, c.K);
             PGEMM_ON(SS_PROF_DEC_DW, c, ws);
+            if (&lb == &e->ld && e->dp_on && part == 0 && pd.bhh + 4L * H > pd.wih) {      // data parallel: half a layer per collective (see below)
+                CHK(dp_bucket(e, pd.wih, pd.bhh + 4L * H - pd.wih, ws));
+                e->dp_dir_buckets = true;
+            }
         }
         return 0;
     }
@@ -1406,6 +1411,13 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
         if (!bias_done) {     // the persistent backward kernel accumulates both bias gradients itself
             HIPCHK(colsum_acc(dGd, 8L * H, (int)R, 4 * H, e->G + pd.bih, ws));
             HIPCHK(hipMemcpyAsync(e->G + pd.bhh, e->G + pd.bih, 4L * H * 4, hipMemcpyDeviceToDevice, ws));
+        }
+        // data parallel: this direction's parameters (W_ih, W_hh, b_ih, b_hh: contiguous in the arena) are final -- half a layer per
+        // collective keeps the communication stream busy 140 us earlier than a bucket per layer (modelled N = 8: the last collective ends
+        // closer to the backward's end)
+        if (&lb == &e->ld && e->dp_on && part == 0 && pd.bhh + 4L * H > pd.wih) {
+            CHK(dp_bucket(e, pd.wih, pd.bhh + 4L * H - pd.wih, ws));
+            e->dp_dir_buckets = true;
         }
     }
     return 0;
@@ -1597,9 +1609,11 @@ int lstm_late_weights(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t ws, int l_h
         Slab xi = l == 0 ? x : Slab{lb.out[l - 1], 2L * H};
         float* am = (persist && g_bwd_f16x2 && lb.amax0 >= 0) ? e->amax + lb.amax0 + l : nullptr;
         const bool bias_in_kernel = persist && !g_deterministic && lb.pd[l * 2].bhh == lb.pd[l * 2].bih + 4L * H && lb.pd[l * 2 + 1].bhh == lb.pd[l * 2 + 1].bih + 4L * H;
+        e->dp_dir_buckets = false;
         CHK(lstm_weight_grads(e, lb, l, xi, am, bias_in_kernel, ws, (&lb == &e->ld && ((e->dec_ih_done >> l) & 1)) ? 2 : 0));
-        // this layer's gradients (both directions: W_ih, W_hh, b_ih, b_hh -- contiguous in the arena) are final
-        if (&lb == &e->ld) CHK(dp_bucket(e, lb.pd[l * 2].wih, lb.pd[l * 2 + 1].bhh + 4L * H - lb.pd[l * 2].wih, ws));
+        // this layer's gradients (both directions: W_ih, W_hh, b_ih, b_hh -- contiguous in the arena) are final (unless each direction has
+        // already gone out on its own)
+        if (&lb == &e->ld && !e->dp_dir_buckets) CHK(dp_bucket(e, lb.pd[l * 2].wih, lb.pd[l * 2 + 1].bhh + 4L * H - lb.pd[l * 2].wih, ws));
     }
     return 0;
 }
