@@ -615,7 +615,7 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
     // the memory wave's two mailboxes: the cell threads' operands of a step (gi, gf, gg, go, d_out, c, c_prev) and their da
     // ring of OPD + 1 steps, filled by LDS-DMA: slot = step % (OPD + 1), then float (utterance * 28 + operand * 4) * 4 + unit
     constexpr int OPD = 4;                                                          // steps between an operand request and its use
-    const int WLEAD = ((prio >> 22) & 31) ? (prio >> 22) & 31 : 8;                  // ... and between a warm-up read and that request
+    const int WLEAD = ((prio >> 22) & 31) ? (prio >> 22) & 31 : 3;                  // ... and between a warm-up read and that request (round 3, in the step: 3 -> 5.28 ms, 8 (round 2's) -> 5.34, 12 -> 5.35; 64 x 192: 7.82 vs 7.91)
     __shared__ __attribute__((aligned(16))) float ops[OPD + 1][7 * 64 * 4];
     __shared__ __attribute__((aligned(16))) float warm_sink[6 * 64 * 4];            // where the warm-up reads land (never read)
     __shared__ __attribute__((aligned(16))) float da_st[4][16][16];                 // [gate][utterance][unit]
