@@ -2785,7 +2785,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "dp_buckets" && (value == 0 || value == 1)) g_dp_buckets = value;
     else if (k == "img_dw_cfg" && value >= -1 && value <= 3) g_img_dw_cfg = value;
     else if (k == "img_dw_wgs" && value >= 32 && value <= 4096) g_img_dw_wgs = value;
-    else if (k == "img_cfg" && value >= -1 && value <= 2) g_img_cfg = value;
+    else if (k == "img_cfg" && value >= -1 && value <= 3) g_img_cfg = value;
     else if (k == "dw_wgs" && value >= 64 && value <= 4096) g_dw_wgs = value;
     else if (k == "trunk_indep" && (value == 0 || value == 1)) g_trunk_indep = value;
     else if (k == "branch_low" && (value == 0 || value == 1)) g_branch_low = value;
