@@ -3089,6 +3089,9 @@ int allreduce_range(ss_engine* e, long off, long count, hipStream_t st) {
 // see the declaration above fork_join
 int dp_bucket(ss_engine* e, long off, long count, hipStream_t producer) {
     if (!e->dp_on || !g_dp_buckets || count <= 0) return 0;
+    if (off < 0 || off + count > e->arena) return fail("dp_bucket: range outside the gradient arena");
+    for (auto& r : e->dp_done)          // a range reduced twice would be summed twice: at world 1 nobody would notice, so it is checked here
+        if (off < r.second && r.first < off + count) return fail("dp_bucket: gradient range handed to a collective twice");
     HIPCHK(hipEventRecord(e->ev_comm, producer));
     HIPCHK(hipStreamWaitEvent(e->comm_s, e->ev_comm, 0));
     CHK(allreduce_range(e, off, count, e->comm_s));
