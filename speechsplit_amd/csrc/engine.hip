@@ -42,6 +42,7 @@ int g_img_mask = (1 << SS_PROF_DEC_PROJ) | (1 << SS_PROF_CONV_FWD) | (1 << SS_PR
 int g_img_batch = 1;       // image GEMM: the decoder's weight gradients of both directions in one launch per matrix
 int g_img_dw_cfg = -1;     // experiment: tile configuration of the split-K (weight-gradient) image GEMMs (-1: the rule in try_img_gemm)
 int g_img_dw_wgs = 256;    // ... and the number of workgroups their split aims at
+int g_dp_emulate = 0;      // with dp_model = N: the stand-in collectives multiply their range by N (the sum of N identical ranks), see dp_scale_kernel
 int g_dp_model = 0;        // > 1: MODEL a data-parallel run of that many ranks on one GPU: every collective is replaced by a stand-in kernel of
                            // the modelled duration (tools/dp_timeline.sh); no communicator needed
 int g_dp_buckets = 1;      // 1: per-layer gradient buckets on the communication stream; 0: round 2's two buckets
@@ -2807,6 +2808,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "exp" && value >= 0) g_exp = value;
     else if (k == "adam_early" && (value == 0 || value == 1)) g_adam_early = value;
     else if (k == "xcd_dw" && (value == 0 || value == 1)) g_xcd_dw = value;
+    else if (k == "dp_emulate" && (value == 0 || value == 1)) g_dp_emulate = value;
     else if (k == "gn_gather" && (value == 0 || value == 1)) g_gn_gather = value;
     else if (k == "unpack_later" && (value == 0 || value == 1)) g_unpack_later = value;
     else if (k == "img_xcc" && value >= 0 && value <= 511) g_img_xcc = value;      // bit 8: keep a placement log (ss_debug_img_wq)
@@ -3070,12 +3072,24 @@ __global__ __launch_bounds__(256) void dp_model_kernel(float* __restrict__ p, lo
     }
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
 }
+// ss_tune("dp_emulate", 1) with dp_model = N: the stand-in MULTIPLIES its range by N -- the sum N identical ranks would produce.  With the
+// 1 / N of the Adam step behind it every element must come out as in the one-GPU step: an element reduced twice, or never, shows in the
+// first moment (tests/test_gpu_buckets_dp.py).  At world 1 a real all-reduce is the identity, so nothing else on one GPU checks that the
+// bucket schedule covers the arena exactly once.
+__global__ __launch_bounds__(256) void dp_scale_kernel(float* __restrict__ p, long n, float mul) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] *= mul;
+}
 double dp_model_us(long bytes, int ranks) { return 25.0 + 2.0 * (ranks - 1) / ranks * (double)bytes / 153e9 * 1e6; }
 
 int allreduce_range(ss_engine* e, long off, long count, hipStream_t st) {
     if (off < 0 || count < 0 || off + count > e->arena) return fail("ss_allreduce_grads: range outside the gradient arena");
     if (count == 0) return 0;
     if (g_dp_model > 1 && (!e->comm || e->comm_world == 1)) {
+        if (g_dp_emulate) {
+            hipLaunchKernelGGL(dp_scale_kernel, dim3(256), dim3(256), 0, st, e->G + off, count, (float)g_dp_model);
+            HIPCHK(hipGetLastError());
+            return 0;
+        }
         const long a = (off + 3) & ~3L, b = (off + count) & ~3L;       // whole float4s inside the range
         hipLaunchKernelGGL(dp_model_kernel, dim3(32), dim3(256), 0, st, e->G + a, b > a ? (b - a) / 4 : 0, (long long)(dp_model_us(count * 4, g_dp_model) * 100.0));
         HIPCHK(hipGetLastError());
@@ -3114,7 +3128,9 @@ int dp_finish(ss_engine* e, hipStream_t s) {
     HIPCHK(hipEventRecord(e->ev_comm, s));
     HIPCHK(hipStreamWaitEvent(e->comm_s, e->ev_comm, 0));
     const bool model = g_dp_model > 1 && (!e->comm || e->comm_world == 1);
-    if (model) {
+    if (model && g_dp_emulate) {
+        for (auto& r : rest) CHK(allreduce_range(e, r.first, r.second - r.first, e->comm_s));
+    } else if (model) {
         long tot = 0;
         for (auto& r : rest) tot += r.second - r.first;
         hipLaunchKernelGGL(dp_model_kernel, dim3(32), dim3(256), 0, e->comm_s, e->G, 0L, (long long)(dp_model_us(tot * 4, g_dp_model) * 100.0));

@@ -270,3 +270,45 @@ def test_generator6_trainer_and_per_rank_batcher(E, tmp_path):
         parts.append(DL.DeviceBatcher(hp, corpus, rank=r, world=2).assemble(idx))
     for k in range(4):
         assert torch.equal(torch.cat([parts[0][k], parts[1][k]]), whole[k])
+
+
+@pytest.mark.parametrize('kind', ['G3', 'G6'])
+def test_bucket_schedule_reduces_every_gradient_exactly_once(E, kind):
+    """At world 1 an all-reduce is the identity, so nothing above notices a gradient range that is handed to a collective twice or never.
+    ss_tune("dp_model", 2) + ("dp_emulate", 1): every stand-in collective MULTIPLIES its range by 2 -- the sum of two identical ranks --
+    and the Adam step behind it carries 1/2: each element's first moment must then equal the one-GPU step's (Adam's update itself is
+    invariant to the gradient's scale, the moments are not: 0.1 * g where the element was reduced once, 0.2 * g twice, 0.05 * g never)."""
+    B, T = 4, 128 if kind == 'G3' else 192
+    hp = W.default_hparams(max_len_pad=T)
+    w = W.make_weights(kind, hp, 6)
+    mel, f0, emb, lens = synth_batch(27, B, T, 64)
+    d = stack_draws(draws_for(28, B, 4 if kind == 'G3' else 3))
+    qidx = torch.from_numpy(interp_np.quantize_f0(f0[:, :, 0].numpy()))
+    onehot = torch.nn.functional.one_hot(qidx, 257).float()
+    res = []
+    E.tune('deterministic', 1)
+    try:
+        for emulate in (False, True):
+            eng = E.Engine(kind, hp, B, T)
+            eng.load_weights(w)
+            eng.set_adam(1e-4, 0.9, 0.999, 1e-8, 0)
+            if emulate:
+                E.tune('dp_model', 2)
+                E.tune('dp_emulate', 1)
+                if kind == 'G3':
+                    eng.dp_train_step_native(mel, f0, emb, lens, d)
+                else:
+                    eng.g6_dp_train_step_native(mel, onehot, qidx, d)
+            elif kind == 'G3':
+                eng.g3_train_step(mel, f0, emb, lens, d)
+            else:
+                eng.g6_train_step(mel, onehot, qidx, d)
+            eng.check()
+            res.append({n: v.clone() for n, v in eng.views(eng.adam_m).items()})
+    finally:
+        E.tune('dp_emulate', 0)
+        E.tune('dp_model', 0)
+        E.tune('deterministic', 0)
+    for n, m in res[0].items():
+        den = float(m.abs().max()) + 1e-30
+        assert float((res[1][n] - m).abs().max()) <= 1e-5 * den, (kind, n)
