@@ -1042,7 +1042,13 @@ int conv_block_bwd(ss_engine* e, ConvBlk& cb, Slab dy, Slab x, Slab dx, hipStrea
     d.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM | (am ? GEMM_F16X2 : 0);
     d.amax_a = am;                                  // gradient operand: measured scale; the block input is O(1)
     d.ksplit = pick_ksplit(d.M, d.N, d.K);
-    if (!(g_exp & 8)) PGEMM_ON(SS_PROF_CONV_DW, d, s);       // (exp & 8, what-if, WRONG gradients: without the conv weight-gradient GEMMs)
+#ifdef SS_DIAG
+    if (g_exp & 8) goto conv_dw_done;            // what-if timing run (WRONG gradients): without the conv weight-gradient GEMMs
+#endif
+    PGEMM_ON(SS_PROF_CONV_DW, d, s);
+#ifdef SS_DIAG
+conv_dw_done:
+#endif
     // packed [Co][5][Cp] -> the parameter's [Co][Ci][5]: nobody reads it before the optimiser (or, data parallel, the layer's bucket), so the
     // one-GPU step collects the blocks and unpacks them all in one launch at the end of the backward (backward_encoder) instead of seven
     // small launches on the trunk's dependent chain
@@ -1280,8 +1286,10 @@ int lstm_wih_gemm_queued(ss_engine* e, LstmBlk& lb, int l, const float* am, cons
 
 // part: 0 everything; 2 everything except the W_ih gradient (it went out through lstm_wih_grad_queued)
 int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am, bool bias_done, hipStream_t ws, int part = 0) {
-    if ((g_exp & 4) && lb.big()) return 0;       // what-if (WRONG gradients): the step without the decoder's weight-gradient GEMMs
-    if ((g_exp & 16) && !lb.big()) return 0;     // what-if (WRONG gradients): without the encoder BLSTMs' weight-gradient launches
+#ifdef SS_DIAG      // what-if timing runs (WRONG gradients; -DSS_DIAG library only): the step without the decoder's / the encoder BLSTMs' weight-gradient launches
+    if ((g_exp & 4) && lb.big()) return 0;
+    if ((g_exp & 16) && !lb.big()) return 0;
+#endif
     const int B = e->curB, T = e->curT, H = lb.H;
     const long TP = T + 2 * HALO, R = (long)B * TP;
     const int In = lb.in_of(l);
