@@ -160,7 +160,7 @@ def kernel_report(eng, steps, ms_step, precision, top, survey, T):
     return roof, classes, recur
 
 
-def solver_loop(B, T, iters=40, warm=8):
+def solver_loop(B, T, iters=120, warm=8):
     """Loader-to-loss: Solver.train() as main.py runs it, batches cropped / clipped / padded on the GPU from an HBM-resident
     synthetic corpus (data_loader.get_device_loader), host draws per step, H2D staging, log line every 10 iterations."""
     import contextlib
