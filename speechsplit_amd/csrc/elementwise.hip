@@ -217,6 +217,15 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
     f32x4 xh[GN_MAXIT], dh[GN_MAXIT];
     f32x4 dgam = {0.f, 0.f, 0.f, 0.f}, dbet = {0.f, 0.f, 0.f, 0.f};
     float s1 = 0.f, s2 = 0.f;
+    // the utterance's inverse map and weights first, into LDS: each row's source rows then cost one global load each instead of a chain
+    // of three dependent ones (start -> lam -> data), eight rows per thread in a row
+    __shared__ int s_start[16 * GN_MAXIT + 2];
+    __shared__ float s_lam[16 * GN_MAXIT + 2];
+    if (src) {
+        for (int i = tid; i <= T; i += 256) s_start[i] = start[(long)b * (T + 1) + i];
+        for (int i = tid; i < P && i < 16 * GN_MAXIT + 2; i += 256) s_lam[i] = lam[(long)b * P + i];
+        __syncthreads();
+    }
 #pragma unroll
     for (int it = 0; it < GN_MAXIT; ++it) {
         const int t = rg + it * 16;
@@ -224,8 +233,8 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
             const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + (long)t * x_ld);
             f32x4 dv;
             if (src) {
-                const int* st = start + (long)b * (T + 1);
-                const float* lm = lam + (long)b * P;
+                const int* st = s_start;
+                const float* lm = s_lam;
                 const float* sb = src + b * src_bs + c;
                 const int a0 = st[t], a1 = st[t + 1];
                 const int b0 = t > 0 ? st[t - 1] : 0, b1 = t > 0 ? a0 : 0;
@@ -732,7 +741,7 @@ hipError_t gn_relu_bwd(const float* x, long x_ld, long x_bs, float* dy, long dy_
                        const float* beta, const float* stats, float* g_gamma, float* g_beta, float* g_bias, float* amax, float* part,
                        int B, int T, int C, hipStream_t s, const InterpPlan* scatter, const float* src, long src_ld, long src_bs) {
     if (C % 64 != 0 || T > 16 * GN_MAXIT) return hipErrorInvalidValue;
-    if (scatter && (!src || scatter->T != T || src_ld % 4 || src_bs % 4 || (((size_t)src) & 15))) return hipErrorInvalidValue;
+    if (scatter && (!src || scatter->T != T || scatter->P > 16 * GN_MAXIT + 2 || src_ld % 4 || src_bs % 4 || (((size_t)src) & 15))) return hipErrorInvalidValue;
     if (!g_deterministic) part = nullptr;
     hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(C / 64, B), dim3(256), 0, s, x, x_ld, x_bs, dy, dy_ld, dy_bs, gamma, beta,
                        stats, g_gamma, g_beta, g_bias, reinterpret_cast<unsigned*>(amax), part, B, T, C, scatter ? src : nullptr, src_ld, src_bs,
