@@ -103,7 +103,8 @@ __global__ __launch_bounds__(256) void gn_relu_fwd_kernel(const float* __restric
 // roundings (interp.hip interp_gather_kernel: bit-identical results), rows past nrows zero.  The normalised slab itself is never
 // written: nobody but the gather reads it (the backward recomputes from the conv output and the statistics).
 // y / y_img: the resampled slab and its pre-split image AT the first real row and the block's first column; P output rows.
-__global__ __launch_bounds__(256) void gn_relu_gather_kernel(const float* __restrict__ x, long x_ld, long x_bs, float* __restrict__ y, long y_ld,
+template <int MAXIT>
+__global__ __launch_bounds__(256, MAXIT <= 8 ? 5 : 4) void gn_relu_gather_kernel(const float* __restrict__ x, long x_ld, long x_bs, float* __restrict__ y, long y_ld,
                                                              long y_bs, float* __restrict__ y_img, const float* __restrict__ img_scale,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ stats, int T, int C, int P, const int* __restrict__ i0,
@@ -116,10 +117,10 @@ __global__ __launch_bounds__(256) void gn_relu_gather_kernel(const float* __rest
     const int c = blockIdx.x * 64 + l16 * 4;
     const int nit = (T + 15) >> 4;
     const float* xb = x + b * x_bs + (long)HALO * x_ld + c;
-    f32x4 v[GN_MAXIT];
+    f32x4 v[MAXIT];
     float s = 0.f;
 #pragma unroll
-    for (int it = 0; it < GN_MAXIT; ++it) {
+    for (int it = 0; it < MAXIT; ++it) {
         const int t = rg + it * 16;
         if (it < nit && t < T) {
             v[it] = *reinterpret_cast<const f32x4*>(xb + (long)t * x_ld);
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void gn_relu_gather_kernel(const float* __rest
     const float mean = block_group_sum(s, red, g4, tid) * inv_n;
     float ss = 0.f;
 #pragma unroll
-    for (int it = 0; it < GN_MAXIT; ++it) {
+    for (int it = 0; it < MAXIT; ++it) {
         const int t = rg + it * 16;
         if (it < nit && t < T) {
 #pragma unroll
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256) void gn_relu_gather_kernel(const float* __rest
     const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
     const f32x4 be = *reinterpret_cast<const f32x4*>(beta + c);
 #pragma unroll
-    for (int it = 0; it < GN_MAXIT; ++it) {
+    for (int it = 0; it < MAXIT; ++it) {
         const int t = rg + it * 16;
         if (it < nit && t < T) {
             f32x4 o;
@@ -189,7 +190,10 @@ __global__ __launch_bounds__(256) void gn_relu_gather_kernel(const float* __rest
     }
 }
 
-__global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restrict__ x, long x_ld, long x_bs,
+// MAXIT: row iterations per thread the registers are sized for (16 rows per iteration): 12 for T <= 192 -- the (T x 64) tile of normalised
+// values and gradients then takes 96 registers instead of 128 and three waves share a SIMD instead of two
+template <int MAXIT>
+__global__ __launch_bounds__(256, MAXIT <= 12 ? 3 : 2) void gn_relu_bwd_kernel(const float* __restrict__ x, long x_ld, long x_bs,
                                                           float* __restrict__ dy, long dy_ld, long dy_bs,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ stats, float* __restrict__ g_gamma,
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
     const f32x4 be = *reinterpret_cast<const f32x4*>(beta + c);
     const float* xb = x + b * x_bs + (long)HALO * x_ld + c;
     float* db = dy + b * dy_bs + (long)HALO * dy_ld + c;
-    f32x4 xh[GN_MAXIT], dh[GN_MAXIT];
+    f32x4 xh[MAXIT], dh[MAXIT];
     f32x4 dgam = {0.f, 0.f, 0.f, 0.f}, dbet = {0.f, 0.f, 0.f, 0.f};
     float s1 = 0.f, s2 = 0.f;
     // the utterance's inverse map and weights first, into LDS: each row's source rows then cost one global load each instead of a chain
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
         __syncthreads();
     }
 #pragma unroll
-    for (int it = 0; it < GN_MAXIT; ++it) {
+    for (int it = 0; it < MAXIT; ++it) {
         const int t = rg + it * 16;
         if (it < nit && t < T) {
             const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + (long)t * x_ld);
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_kernel(const float* __restric
     f32x4 dbias = {0.f, 0.f, 0.f, 0.f};
     float amx = 0.f;
 #pragma unroll
-    for (int it = 0; it < GN_MAXIT; ++it) {
+    for (int it = 0; it < MAXIT; ++it) {
         const int t = rg + it * 16;
         if (it < nit && t < T) {
             f32x4 o;
@@ -728,11 +732,12 @@ hipError_t gn_relu_gather(const float* x, long x_ld, long x_bs, float* y, long y
     if (C % 64 != 0 || T > 16 * GN_MAXIT || p.T != T || y_ld % 4 || y_bs % 4 || (((size_t)y) & 15)) return hipErrorInvalidValue;
     if (y_img && (y_ld % 8 || y_bs % 8 || (((size_t)y_img) & 31))) y_img = nullptr;             // image format v2: groups of eight
     const int lds = (T + 1) * 64 * 4;
+    auto kern = T <= 128 ? gn_relu_gather_kernel<8> : (T <= 192 ? gn_relu_gather_kernel<12> : gn_relu_gather_kernel<GN_MAXIT>);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gn_relu_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(gn_relu_gather_kernel, dim3(C / 64, B), dim3(256), lds, s, x, x_ld, x_bs, y, y_ld, y_bs, y_img, img_scale, gamma, beta,
+    hipLaunchKernelGGL(kern, dim3(C / 64, B), dim3(256), lds, s, x, x_ld, x_bs, y, y_ld, y_bs, y_img, img_scale, gamma, beta,
                        stats, T, C, p.P, p.i0, p.lam, p.nrows);
     return hipGetLastError();
 }
@@ -743,7 +748,9 @@ hipError_t gn_relu_bwd(const float* x, long x_ld, long x_bs, float* dy, long dy_
     if (C % 64 != 0 || T > 16 * GN_MAXIT) return hipErrorInvalidValue;
     if (scatter && (!src || scatter->T != T || scatter->P > 16 * GN_MAXIT + 2 || src_ld % 4 || src_bs % 4 || (((size_t)src) & 15))) return hipErrorInvalidValue;
     if (!g_deterministic) part = nullptr;
-    hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(C / 64, B), dim3(256), 0, s, x, x_ld, x_bs, dy, dy_ld, dy_bs, gamma, beta,
+    // (an 8-iteration instantiation for T <= 128 makes hipcc hoist every source-row load: 418 registers unbounded, spills when bounded)
+    auto kern = T <= 192 ? gn_relu_bwd_kernel<12> : gn_relu_bwd_kernel<GN_MAXIT>;
+    hipLaunchKernelGGL(kern, dim3(C / 64, B), dim3(256), 0, s, x, x_ld, x_bs, dy, dy_ld, dy_bs, gamma, beta,
                        stats, g_gamma, g_beta, g_bias, reinterpret_cast<unsigned*>(amax), part, B, T, C, scatter ? src : nullptr, src_ld, src_bs,
                        scatter ? scatter->P : 0, scatter ? scatter->lam : nullptr, scatter ? scatter->start : nullptr);
     if (part) hipLaunchKernelGGL(gn_part_reduce_kernel, dim3(cdiv(3 * C, 256)), dim3(256), 0, s, part, B, C, g_gamma, g_beta, g_bias);
