@@ -27,6 +27,7 @@ def main():
     ap.add_argument('--frames', type=int, default=128)
     ap.add_argument('--model', default='G3')
     ap.add_argument('--precision', default='f32')
+    ap.add_argument('--lr', type=float, default=1e-4, help='what-if runs with wrong gradients: a tiny rate keeps the weights sane')
     ap.add_argument('--base', default='')
     ap.add_argument('settings', nargs='+')
     a = ap.parse_args()
@@ -38,7 +39,7 @@ def main():
     hp = HP.default_hparams(max_len_pad=T, batch_size=B)
     eng = Engine(kind, hp, B, T, device=dev)
     eng.load_weights(M.init_weights(kind, hp, 0))
-    eng.set_adam(1e-4, 0.9, 0.999, 1e-8, 0)
+    eng.set_adam(a.lr, 0.9, 0.999, 1e-8, 0)
     eng.set_precision(a.precision)
     mel, f0, emb, lens = synth(B, T, 1000, dev)
     ncalls = 4 if kind == 'G3' else 3
