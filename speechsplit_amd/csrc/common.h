@@ -59,6 +59,9 @@ struct GemmDesc {
     // split uses when the operand is read as fp32 (amax_* null).  The conv trunk's activations carry one (kernels.h act_scales).
     const float* a_pre_scale;
     const float* b_pre_scale;
+    // ksplit > 1 (bf16x3 / fp16x2 kernel): batch * ksplit * M * N floats of scratch -- the partial results go there with plain stores and
+    // splitk_reduce adds them into C in a fixed order, instead of meeting in C through fp32 atomics (1.3 TB/s chip-wide, arrival order).  Null: atomics.
+    float* part;
     int queue;              // 1 (engine, image GEMM only): work-queue form -- the launch runs on whatever XCDs have CUs to give (ImgGemmDesc::wq)
 };
 
@@ -103,6 +106,9 @@ struct ImgGemmDesc {
 };
 bool gemm_img_supported(const ImgGemmDesc& d);
 hipError_t launch_gemm_img(const ImgGemmDesc& d, hipStream_t s);
+// C[b][m][n] (+)= sum over ks (in order) of part[b * ksplit + ks][m][n] (+ bias[n]); rm_T > 0: logical row m lives at (m / rm_T) * rm_TP + m % rm_T
+hipError_t splitk_reduce(const float* part, int ksplit, int M, int N, int batch, float* C, long ldc, long cstride, const float* bias, bool accumulate,
+                         int rm_T, int rm_TP, hipStream_t s);
 // fp32 [rows][cols] -> image (cols % 8 == 0).  Scale: pow2_scale_of(*amax) when amax is given (device word), else fixed_scale; written to
 // *scale_out (nullable) for the GEMM's epilogue
 hipError_t split_image(const float* src, long ld, long rows, int cols, const float* amax, float fixed_scale, float* img, long ldi, float* scale_out,

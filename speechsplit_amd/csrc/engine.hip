@@ -84,6 +84,7 @@ int g_prio_order = 1;  // 1: within every phase the critical-path launches are E
 int g_probe_queues = 1; // 1: ss_bind measures which candidate streams share a hardware queue and picks branch streams that do not (pick_streams)
 static unsigned* g_img_wq = nullptr;      // queue words (+ placement log) of the test hook's work-queue launches
 constexpr long IMG_WQ_BYTES = 16 + 16 * 1024;
+int g_part_splitk = 1;  // split-K weight gradients of the in-loop-split kernel through partial slabs + an ordered reduce instead of fp32 atomics
 int g_unpack_later = 1; // one-GPU step: the conv weight gradients' re-layouts in one launch at the end of the backward
 int g_gn_gather = 1;    // training forward of the independent trunk chains: GroupNorm + ReLU + resampling gather in one kernel (gn_relu_gather)
 int g_xcd_dw = 0;       // decoder W_ih gradients beside the backward recurrences on the XCDs they leave free (B <= 48), see ss_engine::wq_pool.
@@ -707,7 +708,19 @@ int gemm_on(ss_engine* e, GemmDesc& d, hipStream_t st) {
     if (e->precision == SS_PRECISION_BF16) d.flags |= GEMM_BF16;
     const int r = try_img_gemm(e, d, st);
     if (r < 0) return r;
-    if (r == 0) HIPCHK(launch_gemm(d, st));
+    if (r == 0) {
+        // split-K weight gradients: partial slabs + ordered reduce instead of fp32 atomics (ss_tune("part_splitk")), scratch from the step's bump allocator
+        if (g_part_splitk && d.ksplit > 1 && (d.flags & GEMM_TA) && (d.flags & GEMM_TB) && (d.flags & GEMM_ACCUM) && !d.row_period && !d.bias && d.N % 4 == 0 &&
+            e->part && !g_deterministic) {
+            int ks = d.ksplit;
+            const long need = (long)ks * d.M * d.N * (d.batch < 1 ? 1 : d.batch);
+            if (e->part_off + need <= e->part_cap) {
+                d.part = e->part + e->part_off;
+                e->part_off += (need + 63) & ~63L;
+            }
+        }
+        HIPCHK(launch_gemm(d, st));
+    }
     return 0;
 }
 #define GEMM(d) GEMM_ON(d, s)
@@ -2819,6 +2832,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "dp_emulate" && (value == 0 || value == 1)) g_dp_emulate = value;
     else if (k == "gn_gather" && (value == 0 || value == 1)) g_gn_gather = value;
     else if (k == "unpack_later" && (value == 0 || value == 1)) g_unpack_later = value;
+    else if (k == "part_splitk" && (value == 0 || value == 1)) g_part_splitk = value;
     else if (k == "img_xcc" && value >= 0 && value <= 511) g_img_xcc = value;      // bit 8: keep a placement log (ss_debug_img_wq)
     else if (k == "probe_queues" && (value == 0 || value == 1)) g_probe_queues = value;
     else if (k == "prio_order" && (value == 0 || value == 1)) g_prio_order = value;

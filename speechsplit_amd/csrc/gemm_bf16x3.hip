@@ -435,7 +435,8 @@ __global__ __launch_bounds__(WS ? 512 : 256, (NPL == 2 && !WS && !PROBE) ? 3 : 1
                 }
                 float* c = Cb + (long)m * d.ldc + n;
                 const float v = acc[mi][ni][r] * unscale + bv;
-                if (d.ksplit > 1) atomicAdd(c, v);
+                if (d.ksplit > 1 && d.part) d.part[((long)bz * d.M + m) * d.N + n] = v;      // partial slab of (batch, k-slice) bz: plain stores, added in order by splitk_reduce
+                else if (d.ksplit > 1) atomicAdd(c, v);
                 else if (d.flags & GEMM_ACCUM) *c += v;
                 else *c = v;
             }
@@ -528,12 +529,17 @@ hipError_t gemm_phase_probe(unsigned long long out[24], bool reset) {
 }
 
 // called by launch_gemm (gemm_f32.hip) for 16-byte-aligned operands
-hipError_t launch_gemm_bf16x3(const GemmDesc& d, hipStream_t s) {
+hipError_t launch_gemm_bf16x3(const GemmDesc& din, hipStream_t s) {
+    GemmDesc d = din;
+    if (d.ksplit < 2 || d.row_period || d.N % 4 || d.bias) d.part = nullptr;      // partial slabs: plain split-K contractions only (the weight gradients)
     const bool ta = d.flags & GEMM_TA, tb = d.flags & GEMM_TB;
-    if (!ta && !tb) return launch_layout<false, false>(d, s);
-    if (!ta && tb) return launch_layout<false, true>(d, s);
-    if (ta && tb) return launch_layout<true, true>(d, s);
-    return hipErrorInvalidValue;
+    hipError_t e;
+    if (!ta && !tb) e = launch_layout<false, false>(d, s);
+    else if (!ta && tb) e = launch_layout<false, true>(d, s);
+    else if (ta && tb) e = launch_layout<true, true>(d, s);
+    else return hipErrorInvalidValue;
+    if (e == hipSuccess && d.part) e = splitk_reduce(d.part, d.ksplit, d.M, d.N, d.batch, d.C, d.ldc, d.cstride, nullptr, true, 0, 0, s);
+    return e;
 }
 
 }  // namespace ss

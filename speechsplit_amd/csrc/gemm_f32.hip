@@ -341,6 +341,7 @@ hipError_t launch_gemm(const GemmDesc& din, hipStream_t s) {
     const bool vec = vec_ok(d.A) && vec_ok(d.B);
     const bool seg_ok = (d.A.seglen == 0 || d.A.seglen >= 32) && (d.B.seglen == 0 || d.B.seglen >= 32);   // one wrap per k-tile
     if (vec && seg_ok && g_gemm_mode == 1) return launch_gemm_bf16x3(d, s);
+    d.part = nullptr;              // the fp32-MFMA kernel's split-K meets in C through atomics
     const bool ta = d.flags & GEMM_TA, tb = d.flags & GEMM_TB;
     if (!ta && !tb) return launch_layout<false, false>(d, vec, s);
     if (!ta && tb) return launch_layout<false, true>(d, vec, s);

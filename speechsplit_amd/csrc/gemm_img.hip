@@ -540,15 +540,19 @@ hipError_t launch_gemm_img(const ImgGemmDesc& din, hipStream_t s) {
     else if (ta && tb) e = launch_layout<true, true>(d, cfg, s);
     else e = launch_layout<true, false>(d, cfg, s);
     if (e != hipSuccess) return e;
-    if (d.ksplit > 1) {
-        const long n4 = (long)d.M * d.N / 4;
-        int g = cdiv(n4, 256);
-        if (g > 2048) g = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g, d.batch), dim3(256), 0, s, d.part, d.ksplit, d.M, d.N, d.C, d.ldc, d.cstride, d.bias,
-                           (d.flags & GEMM_ACCUM) ? 1 : 0, d.rm_T, d.rm_TP);
-        e = hipGetLastError();
-    }
+    if (d.ksplit > 1) e = splitk_reduce(d.part, d.ksplit, d.M, d.N, d.batch, d.C, d.ldc, d.cstride, d.bias, (d.flags & GEMM_ACCUM) != 0, d.rm_T, d.rm_TP, s);
     return e;
+}
+
+hipError_t splitk_reduce(const float* part, int ksplit, int M, int N, int batch, float* C, long ldc, long cstride, const float* bias, bool accumulate,
+                         int rm_T, int rm_TP, hipStream_t s) {
+    if (N % 4 || ksplit < 1 || batch < 1) return hipErrorInvalidValue;
+    const long n4 = (long)M * N / 4;
+    int g = cdiv(n4, 256);
+    if (g > 2048) g = 2048;
+    if (g < 1) return hipSuccess;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g, batch), dim3(256), 0, s, part, ksplit, M, N, C, ldc, cstride, bias, accumulate ? 1 : 0, rm_T, rm_TP);
+    return hipGetLastError();
 }
 
 hipError_t split_image(const float* src, long ld, long rows, int cols, const float* amax, float fixed_scale, float* img, long ldi, float* scale_out,
