@@ -6,6 +6,7 @@
 namespace ss {
 
 extern int g_deterministic;
+int g_gn_part = 0;       // GroupNorm backward: per-utterance affine / bias gradient sums to scratch + ordered reduce instead of f32 atomics (ss_tune("gn_part"))
 
 namespace {
 
@@ -747,7 +748,7 @@ hipError_t gn_relu_bwd(const float* x, long x_ld, long x_bs, float* dy, long dy_
                        int B, int T, int C, hipStream_t s, const InterpPlan* scatter, const float* src, long src_ld, long src_bs) {
     if (C % 64 != 0 || T > 16 * GN_MAXIT) return hipErrorInvalidValue;
     if (scatter && (!src || scatter->T != T || scatter->P > 16 * GN_MAXIT + 2 || src_ld % 4 || src_bs % 4 || (((size_t)src) & 15))) return hipErrorInvalidValue;
-    if (!g_deterministic) part = nullptr;
+    if (!g_deterministic && !g_gn_part) part = nullptr;
     // (an 8-iteration instantiation for T <= 128 makes hipcc hoist every source-row load: 418 registers unbounded, spills when bounded)
     auto kern = T <= 192 ? gn_relu_bwd_kernel<12> : gn_relu_bwd_kernel<GN_MAXIT>;
     hipLaunchKernelGGL(kern, dim3(C / 64, B), dim3(256), 0, s, x, x_ld, x_bs, dy, dy_ld, dy_bs, gamma, beta,

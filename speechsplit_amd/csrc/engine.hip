@@ -22,7 +22,7 @@
 using namespace ss;
 
 namespace ss {
-extern int g_small_lds, g_small_prio, g_gemm_tr, g_deterministic;
+extern int g_small_lds, g_small_prio, g_gemm_tr, g_deterministic, g_gn_part;
 extern int g_img_cfg;
 extern int g_lstm_nw, g_lstm_g, g_lstm_mode, g_gemm_bk, g_gemm_want, g_gemm_diag, g_seq_prio, g_gemm_mode, g_seq_spin_log2, g_seq_tag, g_seq_wlead, g_gemm_ws;
 int g_fwd_f16x2 = 1;   // 1: forward contractions (operands bounded by construction: mel, one-hot, GroupNorm/ReLU outputs, |h| < 1, weights)
@@ -2833,6 +2833,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "gn_gather" && (value == 0 || value == 1)) g_gn_gather = value;
     else if (k == "unpack_later" && (value == 0 || value == 1)) g_unpack_later = value;
     else if (k == "part_splitk" && (value == 0 || value == 1)) g_part_splitk = value;
+    else if (k == "gn_part" && (value == 0 || value == 1)) g_gn_part = value;
     else if (k == "img_xcc" && value >= 0 && value <= 511) g_img_xcc = value;      // bit 8: keep a placement log (ss_debug_img_wq)
     else if (k == "probe_queues" && (value == 0 || value == 1)) g_probe_queues = value;
     else if (k == "prio_order" && (value == 0 || value == 1)) g_prio_order = value;
