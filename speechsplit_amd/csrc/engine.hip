@@ -710,8 +710,9 @@ int gemm_on(ss_engine* e, GemmDesc& d, hipStream_t st) {
     if (r < 0) return r;
     if (r == 0) {
         // split-K weight gradients: partial slabs + ordered reduce instead of fp32 atomics (ss_tune("part_splitk")), scratch from the step's bump allocator
+        // (not for the encoder BLSTMs' tiny matrices: a one-block reduce over 32 slices is 17 us of latency, their atomics are nothing)
         if (g_part_splitk && d.ksplit > 1 && (d.flags & GEMM_TA) && (d.flags & GEMM_TB) && (d.flags & GEMM_ACCUM) && !d.row_period && !d.bias && d.N % 4 == 0 &&
-            e->part && !g_deterministic) {
+            (long)d.M * d.N >= 65536 && e->part && !g_deterministic) {
             int ks = d.ksplit;
             const long need = (long)ks * d.M * d.N * (d.batch < 1 ? 1 : d.batch);
             if (e->part_off + need <= e->part_cap) {
