@@ -231,6 +231,7 @@ struct ss_engine {
     long adam_early_from = -1;             // >= 0: the range [adam_early_from, arena) has been enqueued, the step state prepared
     bool prezero = false;                  // fused training step: zero the gradient arena on a branch stream during the forward
     bool grads_zeroed = false;             // ... done: backward_decoder must not zero it again
+    bool bwd_sync_zeroed = false;          // the same for the backward recurrences' sync words / exchange tiles and the work-queue words
     bool have_fwd = false;
     int enc_plan0 = 0;                     // plan[] index of the first encoder InterpLnr call of the last forward
 
@@ -1683,6 +1684,7 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
     const bool par = e->side && e->side2 && g_overlap;
     hipStream_t b1 = par ? e->side : s, b2 = par ? e->side2 : s;
     e->grads_zeroed = false;               // set again below when this forward belongs to a fused training step
+    e->bwd_sync_zeroed = false;
     if (g3) CHK(conv_pack_all(e, e->c1[0], s));
     CHK(conv_pack_all(e, e->c2[0], s));
     CHK(act_scales_all(e, s));             // before every branch forks: the scale words of the conv blocks' outputs
@@ -1737,6 +1739,13 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
             HIPCHK(hipMemsetAsync(e->G, 0, e->arena * 4, b2));
             HIPCHK(hipMemsetAsync(e->amax, 0, 16 * 4, b2));
             e->grads_zeroed = true;
+            // the backward recurrences' group words and exchange tiles (nothing in the forward touches them): zeroed here, the backward
+            // needs no fork / memset / join between the head's gradient and its first recurrence (two event hops on the critical path)
+            if (e->ld.big() && g_persist && lstm_seq_supported(e->curB, e->ld.H) && !(g_exp & 32)) {      // (exp & 32: A/B switch, both schedules are correct)
+                HIPCHK(hipMemsetAsync(e->ld.zb, 0, e->ld.zb_bytes, b2));
+                if (e->wq_pool) HIPCHK(hipMemsetAsync(e->wq_pool, 0, ss_engine::WQ_SLOTS * 16, b2));
+                e->bwd_sync_zeroed = true;
+            }
         }
         // fp16 x 2 products scale WEIGHTS by a fixed 16 (forward and gradient contractions alike, and the persistent recurrences' W_hh):
         // fine up to |w| < 4094.  Activations carry their own scale (act_scales_all) and gradients their measured one, so the only thing
@@ -1900,12 +1909,15 @@ int backward_decoder(ss_engine* e, hipStream_t s, bool late = false) {
     }
     e->grads_zeroed = false;
     // fragment-major W_hh^T of the decoder recurrences (overwrites the forward layout, no longer needed), beside the head
-    const bool par = e->side2 && g_overlap;
+    const bool persist_dec = e->ld.big() && g_persist && lstm_seq_supported(e->curB, e->ld.H);
+    const bool prezeroed = e->bwd_sync_zeroed && persist_dec;       // the fused step's forward has done it on its branch stream
+    e->bwd_sync_zeroed = false;
+    const bool par = e->side2 && g_overlap && !prezeroed;
     hipStream_t b2 = par ? e->side2 : s;
     if (par) CHK(fork_join(e, s, b2));
     e->dec_ih_done = 0;
     e->wq_next = 0;
-    if (e->ld.big()) {
+    if (e->ld.big() && !prezeroed) {
         if (g_persist && lstm_seq_supported(e->curB, e->ld.H)) {
             // the group counters of every layer and their exchange tiles (tags start at 0)
             HIPCHK(hipMemsetAsync(e->ld.zb, 0, e->ld.zb_bytes, b2));
