@@ -6,6 +6,8 @@ R=${1:-r03}
 O=gpurun_out/$R
 mkdir -p $O
 export TMPDIR=/tmp
+# the ablation benches need the -DSS_DIAG library; build it HERE before the gpurun call (make -C speechsplit_amd/csrc diag), not on the box
+test -f speechsplit_amd/lib/libspeechsplit_hip_diag.so || { echo 'libspeechsplit_hip_diag.so is missing: make -C speechsplit_amd/csrc diag'; exit 1; }
 timeout -k 10 1100 python -u -m pytest tests -m gpu -x -q -s > $O/pytest_gpu.txt 2>&1 || { tail -30 $O/pytest_gpu.txt; exit 1; }
 tail -3 $O/pytest_gpu.txt
 # counter passes first: bench.py reads the HBM traffic of its roofline kernel from profiles/<round>/gemm_pmc.json
