@@ -24,7 +24,7 @@ using namespace ss;
 namespace ss {
 extern int g_small_lds, g_small_prio, g_gemm_tr, g_deterministic, g_gn_part;
 extern int g_img_cfg;
-extern int g_lstm_nw, g_lstm_g, g_lstm_mode, g_gemm_bk, g_gemm_want, g_gemm_diag, g_seq_prio, g_gemm_mode, g_seq_spin_log2, g_seq_tag, g_seq_wlead, g_gemm_ws;
+extern int g_lstm_nw, g_lstm_g, g_lstm_mode, g_gemm_bk, g_gemm_want, g_gemm_diag, g_seq_prio, g_gemm_mode, g_seq_spin_log2, g_seq_tag, g_seq_wlead, g_seq_var, g_gemm_ws;
 int g_fwd_f16x2 = 1;   // 1: forward contractions (operands bounded by construction: mel, one-hot, GroupNorm/ReLU outputs, |h| < 1, weights)
                        //    use the fp16 x 2 split (3 MFMAs) instead of bf16 x 3 (6 MFMAs); gradients keep bf16 x 3 (their range is not bounded)
 int g_bwd_f16x2 = 1;   // 1: the decoder's and the conv trunk's gradient GEMMs also use fp16 x 2: the gradient operand is scaled by the power
@@ -2809,6 +2809,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "seq_tag" && (value == 0 || value == 1)) g_seq_tag = value;
     else if (k == "op_time_major" && (value == 0 || value == 1)) g_op_time_major = value;
     else if (k == "seq_wlead" && value >= 0 && value < 32) g_seq_wlead = value;
+    else if (k == "seq_var" && value >= 0 && value < 16) g_seq_var = value;
     else if (k == "prewarm" && value >= 0 && value <= 3) g_prewarm = value;
     else if (k == "batch_dirs" && value >= 0 && value <= 2) g_batch_dirs = value;
     else if (k == "compact0" && (value == 0 || value == 1)) g_compact0 = value;

@@ -52,6 +52,10 @@ namespace ss {
 int g_seq_prio = 1;    // 1: persistent recurrence waves run at s_setprio 3
 int g_seq_tag = 1;     // forward recurrence: the hand-off payload carries its own step tag (no flag round trip, see "Tagged payload" below) where
                        // every group sits on one XCD; 0: always the flag line per group.  (The backward is always tagged.)
+int g_seq_var = 2;     // backward kernel, warm-up reads: 2 one dword per 128-byte line (ONE load instruction per step: a line comes into the L2 whole
+                       // whichever of its bytes is asked for), 4 one dword per 64 bytes (two instructions), 0 round 2's six 1 KB reads.  What the
+                       // warm-up costs is its return traffic through the CU's one vector-memory path, which the polls share: 6 KB -> 192 bytes per
+                       // step takes the isolated step from 3.05 to 2.78 us (64 x 128), the training step 5.23 -> 5.21 ms (all shapes -0.02..-0.04)
 int g_seq_wlead = 0;   // backward kernel: steps between a warm-up read and the operand request it serves (0: the kernel's default)
 int g_seq_spin_log2 = 18;   // bounded wait of the group hand-off: 2^18 polls ~ tens of ms.  ss_tune("seq_spin_log2", 4) makes the
                             // first wait of a launch expire, which is how the tests exercise the abort path on hardware
@@ -615,7 +619,9 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
     // the memory wave's two mailboxes: the cell threads' operands of a step (gi, gf, gg, go, d_out, c, c_prev) and their da
     // ring of OPD + 1 steps, filled by LDS-DMA: slot = step % (OPD + 1), then float (utterance * 28 + operand * 4) * 4 + unit
     constexpr int OPD = 4;                                                          // steps between an operand request and its use
-    const int WLEAD = ((prio >> 22) & 31) ? (prio >> 22) & 31 : 3;                  // ... and between a warm-up read and that request (round 3, in the step: 3 -> 5.28 ms, 8 (round 2's) -> 5.34, 12 -> 5.35; 64 x 192: 7.82 vs 7.91)
+    const int WLEAD = ((prio >> 22) & 31) == 31 ? 0 : (((prio >> 22) & 31) ? (prio >> 22) & 31 : 3);                  // ... and between a warm-up read and that request (round 3, in the step: 3 -> 5.28 ms, 8 (round 2's) -> 5.34, 12 -> 5.35; 64 x 192: 7.82 vs 7.91)
+    const int svar = (prio >> 27) & 15;
+    const int wmode = (svar & 2) ? 1 : ((svar & 4) ? 2 : 0);
     __shared__ __attribute__((aligned(16))) float ops[OPD + 1][7 * 64 * 4];
     __shared__ __attribute__((aligned(16))) float warm_sink[6 * 64 * 4];            // where the warm-up reads land (never read)
     __shared__ __attribute__((aligned(16))) float da_st[4][16][16];                 // [gate][utterance][unit]
@@ -697,6 +703,23 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
                     const int sw = st + WLEAD < T ? st + WLEAD : T - 1;
                     const int tw = tau_of(sw);
                     constexpr int PER_U = 24 * H / 1024, NG = 16 * H / 1024, ND = 20 * H / 1024;      // 1 KB chunks per utterance: gates, then d_out, then c
+                    auto chunk = [&](int c) -> const float* {
+                        const int u = c / PER_U, k = c % PER_U;
+                        const int bu = bt * 16 + u < B ? bt * 16 + u : B - 1;
+                        return k < NG ? gates + row_of(bu, tw) * (8 * H) + dir * 4 * H + k * 256
+                                      : (k < ND ? d_out + row_of(bu, tw) * (2 * H) + dir * H + (k - NG) * 256 : csave + row_of(bu, tw) * (2 * H) + dir * H + (k - ND) * 256);
+                    };
+                    if (wmode == 1) {                  // a line comes into the L2 whole whichever of its bytes is asked for: lane -> (chunk lane / 8, line lane % 8)
+                        if (lane < 48) __builtin_amdgcn_global_load_lds((const void*)(chunk(jt * 6 + (lane >> 3)) + 32 * (lane & 7)), (lds_t)warm_sink, 4, 0, 0);
+                    } else if (wmode == 2) {           // ... one dword per 64 bytes
+                        if (lane < 48) {
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) {
+                                const int pc = 48 * i + lane;
+                                __builtin_amdgcn_global_load_lds((const void*)(chunk(jt * 6 + (pc >> 4)) + 16 * (pc & 15)), (lds_t)(warm_sink + 64 * i), 4, 0, 0);
+                            }
+                        }
+                    } else
 #pragma unroll
                     for (int i = 0; i < 6; ++i) {
                         const int c = jt * 6 + i, u = c / PER_U, k = c % PER_U;
@@ -716,6 +739,8 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
                 if (!(diag & 4)) {
                     request(st + OPD);                 // its slot held step st - 1: read before that step's second barrier
                     if (diag & 64) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(7 * OPD) : "memory");      // in order: everything up to step st has landed
+                    else if (wmode == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * OPD) : "memory");
+                    else if (wmode == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(9 * OPD) : "memory");
                     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(13 * OPD) : "memory");
                 }
                 if (!barriers_to_products(st)) {
@@ -986,7 +1011,7 @@ long lstm_seq_xbytes(int B, int H, bool backward) {
 }
 
 static int seq_slots(int nbt) { return 2 * nbt <= 8 ? 8 : 2 * nbt; }       // group slots per member index (see the kernels)
-static int seq_prio_arg(bool time_major) { return (g_seq_prio & 0xFFFF) | ((g_seq_spin_log2 & 31) << 16) | (time_major ? 1 << 21 : 0) | ((g_seq_wlead & 31) << 22); }
+static int seq_prio_arg(bool time_major) { return (g_seq_prio & 0xFFFF) | ((g_seq_spin_log2 & 31) << 16) | (time_major ? 1 << 21 : 0) | ((g_seq_wlead & 31) << 22) | ((g_seq_var & 15) << 27); }
 
 hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, float* out, float* csave,
                         unsigned* sync, unsigned* sticky, const float* xc, int xf, float* out_img, int B, int T, int H, bool zero_state,

@@ -415,6 +415,63 @@ def bench_seqtag(B=64, T=128, H=512):
         f'dgates max diff {float((res[0][1] - res[1][1]).abs().max()):.2e} (max |dgates| {float(res[0][1].abs().max()):.2e})')
 
 
+def bench_seqvar(B=64, T=128, H=512, variants=(0, 2, 4)):
+    """backward recurrence, memory-wave variants (ss_tune("seq_var")), interleaved rounds in one process; results compared bit for bit"""
+    dev = 'cuda'
+    g = torch.Generator(device='cpu').manual_seed(0)
+    xproj = (torch.randn(B, T, 2, 4 * H, generator=g) * 0.5).to(dev)
+    whh = (torch.rand(2, 4 * H, H, generator=g) * 2 - 1).to(dev) / H ** 0.5
+    d_out = (torch.randn(B, T, 2 * H, generator=g) * 0.1).to(dev)
+    scratch = torch.zeros(max(8 * H * H + 16 * B * H + 2 * B * H + 1024, 2 * ((B + 15) // 16) * (H // 16) ** 2 * 1024 + 4096), device=dev)
+    gates = torch.zeros(B, T + 4, 8 * H, device=dev)
+    gates[:, 2:2 + T] = xproj.reshape(B, T, 8 * H)
+    out = torch.zeros(B, T + 4, 2 * H, device=dev)
+    cs = torch.zeros(B, T + 4, 2 * H, device=dev)
+    dpad = torch.zeros(B, T + 4, 2 * H, device=dev)
+    dpad[:, 2:2 + T] = d_out
+    _capi.check(lib.ss_op_lstm_fwd(P(gates), P(whh[0]), P(whh[1]), P(out), P(cs), P(scratch), scratch.numel(), B, T, H, S()))
+    ga_keep = gates.clone()
+    flush = torch.empty(160 << 20, device=dev)          # 640 MB: larger than the memory-side cache
+
+    def copy_only():
+        gates.copy_(ga_keep)
+
+    def bwd():
+        gates.copy_(ga_keep)
+        _capi.check(lib.ss_op_lstm_bwd(P(gates), P(whh[0]), P(whh[1]), P(dpad), P(cs), P(scratch), scratch.numel(), B, T, H, S()))
+
+    def cold_bwd():
+        gates.copy_(ga_keep)
+        flush.zero_()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _capi.check(lib.ss_op_lstm_bwd(P(gates), P(whh[0]), P(whh[1]), P(dpad), P(cs), P(scratch), scratch.numel(), B, T, H, S()))
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3
+    ref = None
+    warm = {v: [] for v in variants}
+    cold = {v: [] for v in variants}
+    for rnd in range(4):
+        for v in (variants if rnd % 2 == 0 else variants[::-1]):
+            tune('seq_var', v)
+            tb = timeit(bwd, iters=9)[0] - timeit(copy_only, iters=9)[0]
+            bwd()
+            r = gates.clone()
+            if ref is None:
+                ref = r
+            elif not torch.equal(r, ref):
+                say(f'   seq_var {v}: RESULT DIFFERS, max diff {float((r - ref).abs().max()):.3e}')
+            if rnd:
+                warm[v].append(tb)
+                cold[v].append(sorted(cold_bwd() for _ in range(5))[2])
+    tune('seq_var', 0)
+    for v in variants:
+        w, c = sorted(warm[v]), sorted(cold[v])
+        say(f'B{B} T{T} H{H} seq_var {v:2d}: bwd warm {w[1]:.0f} us ({w[1] / T:.2f}/step; {w[0]:.0f}..{w[-1]:.0f})   cold {c[1]:.0f} us ({c[1] / T:.2f}/step; {c[0]:.0f}..{c[-1]:.0f})')
+
+
 if __name__ == '__main__':
     want = sys.argv[1:] or ['lstm', 'gemm', 'step']
     say('====', ' '.join(want), torch.cuda.get_device_name(0))
@@ -426,6 +483,8 @@ if __name__ == '__main__':
         bench_seqtag(B=48, T=192)
     if 'seq' in want:
         bench_seq()
+    if 'seqvar' in want:
+        bench_seqvar()
     if 'modes' in want:
         bench_lstm_modes()
     if 'gemm' in want:
