@@ -628,6 +628,31 @@ def test_persistent_blstm_layer_against_torch(E, case):
         E.tune('seq_tag', 1)
 
 
+@pytest.mark.parametrize('shape', [(64, 128, 512), (33, 19, 256)], ids=['b64_t128_h512', 'b33_t19_h256'])
+def test_backward_recurrence_warmup_forms_are_bit_identical(E, shape):
+    """The backward recurrence's warm-up reads only move lines into the L2 (ss_tune("seq_var"): 2 one dword per 128-byte line -- the default --,
+    4 one per 64 bytes, 0 whole 1 KB runs): whichever form runs, every result of the layer is the same bit for bit."""
+    B, T, H = shape
+    In = 64
+    g = torch.Generator().manual_seed(7 + B)
+    x = torch.randn(B, T, In, generator=g).cuda()
+    d_out = (torch.randn(B, T, 2 * H, generator=g) * 0.1).cuda()
+    w = lambda *sz: ((torch.rand(*sz, generator=g) * 2 - 1) / H ** 0.5).cuda()
+    wih, whh = (w(4 * H, In), w(4 * H, In)), (w(4 * H, H), w(4 * H, H))
+    bih, bhh = (w(4 * H), w(4 * H)), (w(4 * H), w(4 * H))
+    res = {}
+    try:
+        for form in (2, 0, 4):
+            E.tune('seq_var', form)
+            y, dx, grads = E.blstm_layer(x, wih, whh, bih, bhh, d_out)
+            res[form] = [y.clone(), dx.clone()] + [t.clone() for d in grads for t in d]
+    finally:
+        E.tune('seq_var', 2)
+    for form in (0, 4):
+        for a, b in zip(res[2], res[form]):
+            assert torch.equal(a, b), form
+
+
 def test_batch_beyond_one_workgroup_per_cu(E):
     """128 utterances per GPU do not fit the persistent recurrence (one workgroup per CU): the decoder falls back to one
     launch per time step.  Its gradients must equal the mean over two 64-utterance shards, which run the persistent kernels."""
