@@ -242,7 +242,8 @@ int ss_debug_relu_mask(ss_engine* e, const char* block, float* mask_dev, void* s
  * contractions), "seq_spin_log2" 0..24 (log2 of the persistent kernels' bounded wait; 0 makes it expire at once -- how the
  * tests exercise the abort path), "deterministic" 0|1, "seq_tag" 0|1 (forward persistent recurrence: step tag in the hand-off
  * payload where every group sits on one XCD | always the flag line), "seq_wlead" 0..31 (backward persistent recurrence: steps
- * between a warm-up read and the operand request it serves, 0 = the kernel's default), "gemm_ws" 0|1|2 (wave-specialised form of
+ * between a warm-up read and the operand request it serves, 0 = the kernel's default), "seq_var" 0|2|4 (... form of those warm-up
+ * reads: whole 1 KB runs | one dword per 128-byte line (default) | one per 64 bytes; results bit-identical), "gemm_ws" 0|1|2 (wave-specialised form of
  * the 128 x 128 fp16 x 2 GEMM: never | where it measured faster in isolation | always), "img" 0|1 and "img_mask" (bit = SS_PROF_* class: which contractions run on the image GEMM, csrc/gemm_img.hip; default decoder projections, conv forward, conv input gradients), "dp_model" 0|2..64 and "dp_buckets" 0|1 (data-parallel schedule, see ss_g3_dp_train_step), "presplit" 0..15 (operand images for the fp16 x 2 GEMMs: bit 0 weights, bit 1 decoder hidden states, bit 2 trunk
  * activations), "compact0" 0|1 (decoder layer 0 on one row per block of repeated input frames), "trunk_indep" 0|1, "batch_dirs" 0..2,
  * "prewarm" 0..3 (streaming pre-read of a decoder layer's operand slabs on a side stream beside its
