@@ -20,11 +20,11 @@ __device__ __forceinline__ float block_group_sum(float v, float* red, float* out
     red[tid] = v;
     __syncthreads();
     if (tid < 4) {
-        float s = 0.f;
+        double s = 0.0;             // the 64 partial sums of a group in float64 (round 4): the statistics scale every activation of the block
         for (int rg = 0; rg < 16; ++rg)
 #pragma unroll
-            for (int l = 0; l < 4; ++l) s += red[rg * 16 + tid * 4 + l];
-        out4[tid] = s;
+            for (int l = 0; l < 4; ++l) s += (double)red[rg * 16 + tid * 4 + l];
+        out4[tid] = (float)s;
     }
     __syncthreads();
     return out4[(tid & 15) >> 2];
@@ -349,43 +349,89 @@ __global__ __launch_bounds__(256) void gn_relu_mask_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------ column sums
-// grid = (ceil(C/64), chunks); block 256 = 64 columns x 4 row lanes
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, long ld, int R, int C, int rows_per_chunk,
-                                                     float* __restrict__ out) {
-    __shared__ float red[4][64];
+// Bias-type gradients (LSTM biases, the head's bias): out[c] += sum over R rows of in[r][c].  At a trained state these are heavily
+// cancelling sums (the head's is sum_r (softmax - onehot)); fp32 chains over thousands of rows met through arrival-order atomics put them
+// 8x further from exact than PyTorch's cascade sum (round-3 review).  Now: float64 accumulation throughout and a FIXED order --
+// grid = (ceil(cols / 64), chunks), block 256 = 64 columns x 4 row lanes; a block adds its rows per lane, the four lanes in order, and
+// writes the chunk's float64 partial to scratch; the LAST block of a column block to arrive (self-resetting counter) adds the chunks'
+// partials in chunk order and accumulates into the outputs.  Deterministic whatever the arrival order.  chunks == 1: no scratch, no counter.
+// Column c < C goes to o0 (and o1 if given), C <= c < 2C (two-direction form) to o2 / o3.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, long ld, int R, int C, int ncols, int rows_per_chunk,
+                                                     double* __restrict__ part, unsigned* __restrict__ ctr, float* __restrict__ o0,
+                                                     float* __restrict__ o1, float* __restrict__ o2, float* __restrict__ o3) {
+    __shared__ double red[4][64];
+    __shared__ int s_last;
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
+    const int chunks = gridDim.y;
     const int r0 = blockIdx.y * rows_per_chunk;
     int r1 = r0 + rows_per_chunk;
     if (r1 > R) r1 = R;
-    float s = 0.f;
-    if (c < C)
-        for (int r = r0 + rl; r < r1; r += 4) s += in[(long)r * ld + c];
+    double s = 0.0;
+    if (c < ncols) {
+        const float* p = in + c;
+        int r = r0 + rl;
+        for (; r + 12 < r1; r += 16) {            // four independent loads in flight per thread
+            const float v0 = p[(long)r * ld], v1 = p[(long)(r + 4) * ld], v2 = p[(long)(r + 8) * ld], v3 = p[(long)(r + 12) * ld];
+            s += (double)v0;
+            s += (double)v1;
+            s += (double)v2;
+            s += (double)v3;
+        }
+        for (; r < r1; r += 4) s += (double)p[(long)r * ld];
+    }
     red[rl][cl] = s;
     __syncthreads();
-    if (rl == 0 && c < C) atomicAdd(out + c, (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
-}
-
-// both directions' bias gradients of one BLSTM layer in one launch: column c of the [R][2 x C] gradient slab goes to (b_ih, b_hh) of
-// direction c / C (the two biases of a direction have the same gradient)
-__global__ __launch_bounds__(256) void colsum_bias_kernel(const float* __restrict__ in, long ld, int R, int C, int rows_per_chunk,
-                                                          float* __restrict__ bih0, float* __restrict__ bhh0, float* __restrict__ bih1,
-                                                          float* __restrict__ bhh1) {
-    __shared__ float red[4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    const int r0 = blockIdx.y * rows_per_chunk;
-    int r1 = r0 + rows_per_chunk;
-    if (r1 > R) r1 = R;
-    float s = 0.f;
-    if (c < 2 * C)
-        for (int r = r0 + rl; r < r1; r += 4) s += in[(long)r * ld + c];
-    red[rl][cl] = s;
-    __syncthreads();
-    if (rl == 0 && c < 2 * C) {
-        const float t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
-        atomicAdd((c < C ? bih0 : bih1) + (c < C ? c : c - C), t);
-        atomicAdd((c < C ? bhh0 : bhh1) + (c < C ? c : c - C), t);
+    double tot = 0.0;
+    if (rl == 0) tot = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
+    if (chunks > 1) {
+        // Cross-workgroup hand-over WITHOUT fences: a release / acquire fence at agent scope writes back / invalidates the XCD's whole L2 --
+        // measured: 500 workgroups doing that took 0.6 ms and slowed the GEMMs running beside them by 15 %.  Instead the partials are stored
+        // write-through (sc1), acknowledged (vmcnt) before the arrival counter is bumped, and read back with sc1 loads (as the persistent
+        // recurrences exchange their payload, lstm_seq.hip).
+        if (rl == 0) __hip_atomic_store(part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 64 + cl, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(ctr + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(chunks - 1);
+        __syncthreads();
+        if (!s_last) return;
+        double t4 = 0.0;                            // row lane rl adds chunks rl, rl + 4, ... in order (eight loads in flight); the four lanes meet in order
+        const double* pp = part + (long)blockIdx.x * 64 + cl;
+        const long cs = (long)gridDim.x * 64;       // doubles between consecutive chunks
+        int k = rl;
+        for (; k + 28 < chunks; k += 32) {
+            double v[8];
+            asm volatile(
+                "global_load_dwordx2 %0, %8, off sc1\n\t"
+                "global_load_dwordx2 %1, %9, off sc1\n\t"
+                "global_load_dwordx2 %2, %10, off sc1\n\t"
+                "global_load_dwordx2 %3, %11, off sc1\n\t"
+                "global_load_dwordx2 %4, %12, off sc1\n\t"
+                "global_load_dwordx2 %5, %13, off sc1\n\t"
+                "global_load_dwordx2 %6, %14, off sc1\n\t"
+                "global_load_dwordx2 %7, %15, off sc1\n\t"
+                "s_waitcnt vmcnt(0)"
+                : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                : "v"(pp + k * cs), "v"(pp + (k + 4) * cs), "v"(pp + (k + 8) * cs), "v"(pp + (k + 12) * cs), "v"(pp + (k + 16) * cs), "v"(pp + (k + 20) * cs),
+                  "v"(pp + (k + 24) * cs), "v"(pp + (k + 28) * cs)
+                : "memory");
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t4 += v[i];
+        }
+        for (; k < chunks; k += 4) t4 += __hip_atomic_load(pp + k * cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        red[rl][cl] = t4;
+        __syncthreads();
+        if (rl == 0) tot = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
+        if (threadIdx.x == 0) __hip_atomic_store(ctr + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next call
+    }
+    if (rl == 0 && c < ncols) {
+        const float t = (float)tot;
+        float* a = c < C ? o0 : o2;
+        float* b = c < C ? o1 : o3;
+        const int cc = c < C ? c : c - C;
+        a[cc] += t;
+        if (b) b[cc] += t;
     }
 }
 
@@ -766,24 +812,29 @@ hipError_t gn_relu_mask(const float* x, long x_ld, long x_bs, const float* gamma
     return hipGetLastError();
 }
 
-hipError_t colsum_acc(const float* in, long ld, int R, int C, float* out, hipStream_t s) {
-    const int cblocks = cdiv(C, 64);
-    int chunks = g_deterministic ? 1 : cdiv(1024, cblocks);      // several chunks per column meet through atomics
+// scratch (nullable): >= colsum_scratch_doubles(cols) float64 words and, in ctr, cdiv(cols, 64) zeroed counters nobody else uses while the
+// launch is in flight (they are zero again when it retires); without scratch every column block is ONE workgroup (slower, same sums)
+long colsum_scratch_doubles(int cols) {
+    const int cblocks = cdiv(cols, 64);
+    return (long)(cdiv(1024, cblocks) + 1) * cblocks * 64;
+}
+static hipError_t colsum_launch(const float* in, long ld, int R, int C, int ncols, double* part, unsigned* ctr, float* o0, float* o1, float* o2, float* o3,
+                                hipStream_t s) {
+    const int cblocks = cdiv(ncols, 64);
+    int chunks = (part && ctr) ? cdiv(1024, cblocks) : 1;
     if (chunks > cdiv(R, 16)) chunks = cdiv(R, 16);
     if (chunks < 1) chunks = 1;
     const int rpc = cdiv(R, chunks);
-    hipLaunchKernelGGL(colsum_kernel, dim3(cblocks, cdiv(R, rpc)), dim3(256), 0, s, in, ld, R, C, rpc, out);
+    chunks = cdiv(R, rpc);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cblocks, chunks), dim3(256), 0, s, in, ld, R, C, ncols, rpc, part, ctr, o0, o1, o2, o3);
     return hipGetLastError();
 }
-
-hipError_t colsum_bias(const float* in, long ld, int R, int C, float* bih0, float* bhh0, float* bih1, float* bhh1, hipStream_t s) {
-    const int cblocks = cdiv(2 * C, 64);
-    int chunks = g_deterministic ? 1 : cdiv(1024, cblocks);
-    if (chunks > cdiv(R, 16)) chunks = cdiv(R, 16);
-    if (chunks < 1) chunks = 1;
-    const int rpc = cdiv(R, chunks);
-    hipLaunchKernelGGL(colsum_bias_kernel, dim3(cblocks, cdiv(R, rpc)), dim3(256), 0, s, in, ld, R, C, rpc, bih0, bhh0, bih1, bhh1);
-    return hipGetLastError();
+hipError_t colsum_acc(const float* in, long ld, int R, int C, float* out, double* part, unsigned* ctr, hipStream_t s) {
+    return colsum_launch(in, ld, R, C, C, part, ctr, out, nullptr, nullptr, nullptr, s);
+}
+hipError_t colsum_bias(const float* in, long ld, int R, int C, float* bih0, float* bhh0, float* bih1, float* bhh1, double* part, unsigned* ctr,
+                       hipStream_t s) {
+    return colsum_launch(in, ld, R, C, 2 * C, part, ctr, bih0, bhh0, bih1, bhh1, s);
 }
 
 hipError_t copy_rows(const float* src, long s_ld, long s_bs, float* dst, long d_ld, long d_bs, int B, int T, int C,

@@ -221,6 +221,10 @@ struct ss_engine {
     // (B <= 48: 2 * ceil(B / 16) groups, one XCD each), the W_ih gradient of layer l + 1 runs as a work-queue image GEMM BESIDE the
     // recurrence of layer l -- on the free XCDs, because its 128-144 KB workgroups cannot be dispatched to a CU a recurrence workgroup holds
     unsigned* wq_pool = nullptr;           // zeroed per backward pass: 4 words per work-queue launch
+    // column sums (bias gradients): float64 chunk partials from the step's scratch (part) + a ring of arrival counters, zero at rest
+    unsigned* colsum_ctr = nullptr;
+    static constexpr int COLSUM_CTRS = 2048;
+    int colsum_next = 0;
     int wq_next = 0;
     static constexpr int WQ_SLOTS = 16;
     int dec_ih_done = 0;                   // bit l: decoder layer l's W_ih gradient went out beside a recurrence (lstm_late_weights skips it)
@@ -566,6 +570,7 @@ long ss_engine::carve(int B, int T, bool assign) {
     }
     qidx = (int*)take((long)B * TP * 4);
     wq_pool = (unsigned*)take(WQ_SLOTS * 16);
+    colsum_ctr = (unsigned*)take(COLSUM_CTRS * 4);
     for (int i = 0; i < 4; ++i) {
         plan[i].S = hp.max_len_seq / hp.min_len_seg + 1;     // model.py:365
         plan[i].ncand = 2 * hp.max_len_seg;                  // model.py:389
@@ -702,6 +707,23 @@ int try_img_gemm(ss_engine* e, const GemmDesc& d, hipStream_t st) {
     if (!gemm_img_supported(g)) return 0;
     HIPCHK(launch_gemm_img(g, st));
     return 1;
+}
+
+// scratch of one column-sum launch (kernels.h colsum_acc): float64 partials from the step's bump allocator, counters from the ring
+// (self-resetting; a launch's counters are not handed out again before COLSUM_CTRS / 64 later launches); false: none left, the launch
+// runs with one workgroup per column block
+bool colsum_scratch(ss_engine* e, int cols, double** part, unsigned** ctr) {
+    *part = nullptr;
+    *ctr = nullptr;
+    const long need = 2 * colsum_scratch_doubles(cols);          // in floats
+    const int nb = cdiv(cols, 64);
+    if (!e->part || !e->colsum_ctr || nb > ss_engine::COLSUM_CTRS || e->part_off + need > e->part_cap) return false;
+    *part = (double*)(e->part + e->part_off);                    // part_off is kept at multiples of 64 floats
+    e->part_off += (need + 63) & ~63L;
+    if (e->colsum_next + nb > ss_engine::COLSUM_CTRS) e->colsum_next = 0;
+    *ctr = e->colsum_ctr + e->colsum_next;
+    e->colsum_next += nb;
+    return true;
 }
 
 // every contraction of the engine honours its precision mode (ss_set_precision)
@@ -1366,7 +1388,12 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
         h.amax_a = am;
         h.ksplit = pick_ksplit(h.M, h.N, h.K);
         PGEMM_ON(lb.big() ? SS_PROF_DEC_DW : SS_PROF_ENC_LSTM, h, ws);
-        if (!bias_done) HIPCHK(colsum_bias(dG, 8L * H, (int)R, 4 * H, e->G + p0.bih, e->G + p0.bhh, e->G + p1.bih, e->G + p1.bhh, ws));
+        if (!bias_done) {
+            double* cpart;
+            unsigned* cctr;
+            colsum_scratch(e, 8 * H, &cpart, &cctr);
+            HIPCHK(colsum_bias(dG, 8L * H, (int)R, 4 * H, e->G + p0.bih, e->G + p0.bhh, e->G + p1.bih, e->G + p1.bhh, cpart, cctr, ws));
+        }
         if (!compact) return 0;
         // compact layer 0: dW_hh went out batched above, dW_ih comes from the block sums below, per direction
         for (int dir = 0; dir < 2; ++dir) {
@@ -1433,7 +1460,10 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
         h.ksplit = pick_ksplit(h.M, h.N, h.K);
         PGEMM_ON(lb.big() ? SS_PROF_DEC_DW : SS_PROF_ENC_LSTM, h, ws);
         if (!bias_done) {     // the persistent backward kernel accumulates both bias gradients itself
-            HIPCHK(colsum_acc(dGd, 8L * H, (int)R, 4 * H, e->G + pd.bih, ws));
+            double* cpart;
+            unsigned* cctr;
+            colsum_scratch(e, 4 * H, &cpart, &cctr);
+            HIPCHK(colsum_acc(dGd, 8L * H, (int)R, 4 * H, e->G + pd.bih, cpart, cctr, ws));
             HIPCHK(hipMemcpyAsync(e->G + pd.bhh, e->G + pd.bih, 4L * H * 4, hipMemcpyDeviceToDevice, ws));
         }
         // data parallel: this direction's parameters (W_ih, W_hh, b_ih, b_hh: contiguous in the arena) are final -- half a layer per
@@ -1892,7 +1922,12 @@ int head_weight_grads(ss_engine* e, hipStream_t st) {
     a.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM;
     a.ksplit = pick_ksplit(a.M, a.N, a.K);
     PGEMM_ON(SS_PROF_HEAD, a, st);
-    HIPCHK(colsum_acc(e->d_out_slab, e->head_out, (int)R, e->head_out, e->G + e->head_b, st));
+    {
+        double* cpart;
+        unsigned* cctr;
+        colsum_scratch(e, e->head_out, &cpart, &cctr);
+        HIPCHK(colsum_acc(e->d_out_slab, e->head_out, (int)R, e->head_out, e->G + e->head_b, cpart, cctr, st));
+    }
     CHK(dp_bucket(e, e->head_w, e->status_off - e->head_w, st));       // (the status slot behind it rides the step's last bucket)
     return 0;
 }
@@ -3173,9 +3208,19 @@ int dp_finish(ss_engine* e, hipStream_t s) {
         hipLaunchKernelGGL(dp_model_kernel, dim3(32), dim3(256), 0, e->comm_s, e->G, 0L, (long long)(dp_model_us(tot * 4, g_dp_model) * 100.0));
         HIPCHK(hipGetLastError());
     } else {
-        if (rest.size() > 1) NCCLCHK(g_rccl.GroupStart());
-        for (auto& r : rest) CHK(allreduce_range(e, r.first, r.second - r.first, e->comm_s));
-        if (rest.size() > 1) NCCLCHK(g_rccl.GroupEnd());
+        // an open group must be closed whatever happens inside it: a failing member would otherwise leave every later RCCL call of the
+        // process queued in a group that never ends
+        const bool grouped = rest.size() > 1;
+        if (grouped) NCCLCHK(g_rccl.GroupStart());
+        int rc = 0;
+        for (auto& r : rest)
+            if ((rc = allreduce_range(e, r.first, r.second - r.first, e->comm_s)) != 0) break;
+        if (grouped) {
+            const std::string first_err = rc ? g_err : std::string();
+            const int ge = g_rccl.GroupEnd();
+            if (rc) return fail(first_err);
+            NCCLCHK(ge);
+        } else if (rc) return rc;
     }
     e->dp_done.clear();
     HIPCHK(hipEventRecord(e->ev_comm, e->comm_s));

@@ -18,6 +18,11 @@
 //     of the fp32-atomic traffic round 2's kernels paid (MI355X_MICROARCH.md, Global float atomics: 1.3 TB/s chip-wide);
 //   * tile order: every XCD gets a contiguous range of the launch whose co-resident workgroups form 2-D blocks of tiles, so the
 //     32 CUs of an XCD share a handful of row and column panels in its 4 MB L2.
+// Single-piece form (template flag P1, ImgGemmDesc::bf16; round 4, the 16-bit data path of BASELINE configs 3-5): the operands are plain
+// bf16 tensors -- a slab that is stored in bf16 IS its own image -- with the geometry in elements as before and 2 bytes per element.  The
+// same 128 bytes per tile row and k-tile now hold 64 k-values (eight 16-byte fragments), a reduction-major k-row BX x 2 bytes; one
+// v_mfma_f32_32x32x16_bf16 per k16-step and accumulator tile instead of three f16 ones, no scales.  Same DMA geometry, same swizzles, same
+// ring; per MFMA 1.5x the LDS bytes of the fp16 x 2 form.
 // Tile configurations (launch_gemm_img picks): 256 x 256 (8 waves of 128 x 64, 2 slots, 128 KB, one workgroup per CU),
 // 256 x 128 (8 waves of 64 x 64, 3 slots, 144 KB), 128 x 128 (4 waves of 64 x 64, 2 slots, 64 KB: two workgroups per CU).
 #include "common.h"
@@ -30,6 +35,7 @@ int g_img_cfg = -1;       // experiment: force a tile configuration (-1: launch_
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -53,10 +59,13 @@ __device__ __forceinline__ long seg_off(const ImgOperand& op, int x) {
     return (long)sg * op.segstride + (x - sg * op.seglen);
 }
 
-template <int WTM, int WTN, int WGM, int WGN, bool TA, bool TB, int NSLOT>
+template <int WTM, int WTN, int WGM, int WGN, bool TA, bool TB, int NSLOT, bool P1>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm_img_kernel(const ImgGemmDesc d) {
     constexpr int BM = WTM * WGM, BN = WTN * WGN, NW = WGM * WGN;
     constexpr int MI = WTM / 32, NI = WTN / 32;
+    constexpr int EB = P1 ? 2 : 4;              // bytes per element of the image geometry
+    constexpr int KT = P1 ? 64 : 32;            // k-values per k-tile (128 bytes of a K-contiguous row either way)
+    constexpr int KS = KT / 16;                 // k16-steps per k-tile
     constexpr int PART_A = BM * 128, PART_B = BN * 128, SLOT = PART_A + PART_B;
     constexpr int NA = BM / 8 / NW, NB = BN / 8 / NW;            // DMA wave-instructions per wave and k-tile
     static_assert(NA >= 1 && NB >= 1, "tile too small for the wave count");
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_img_kernel(const ImgGemmDe
     }
     const int batch = z / d.ksplit, ks = z - batch * d.ksplit;
     const int m0 = by * BM, n0 = bx * BN;
-    const int ktiles = (d.K + 31) >> 5;
+    const int ktiles = (d.K + KT - 1) / KT;
     const int per = (ktiles + d.ksplit - 1) / d.ksplit;
     const int kt0 = ks * per;
     int kt1 = kt0 + per;
@@ -143,8 +152,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_img_kernel(const ImgGemmDe
     const int nk = kt1 > kt0 ? kt1 - kt0 : 0;
 
     // ---- LDS-DMA addressing: per lane a 32-bit byte offset from a wave-uniform base; the base advances by one k-tile per issue
-    const unsigned char* a_base = (const unsigned char*)d.A.p + ((long)batch * d.A.bstride) * 4;
-    const unsigned char* b_base = (const unsigned char*)d.B.p + ((long)batch * d.B.bstride) * 4;
+    const unsigned char* a_base = (const unsigned char*)d.A.p + ((long)batch * d.A.bstride) * EB;
+    const unsigned char* b_base = (const unsigned char*)d.B.p + ((long)batch * d.B.bstride) * EB;
     unsigned voa[NA], vob[NB];
     auto setup = [&](const ImgOperand& op, bool T, int BX, int x0, int X, int i, bool remap) -> unsigned {
         if (!T) {            // rows 8i .. 8i+7 of the tile, lane -> (row, LDS chunk slot); the slot holds logical chunk slot ^ swizzle
@@ -153,15 +162,15 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_img_kernel(const ImgGemmDe
             int g = x0 + row;
             g = g < X ? g : X - 1;
             if (remap) g = (g / d.rm_T) * d.rm_TP + g % d.rm_T;        // logical row -> slab row (halo rows skipped)
-            return (unsigned)((long)g * op.ld * 4 + c * 16);
+            return (unsigned)((long)g * op.ld * EB + c * 16);
         }
-        const int RB = BX * 4;                                     // bytes per k-row: hi half, lo half
+        const int RB = BX * EB;                                    // bytes per k-row: hi half, lo half (single-piece: the bf16 row)
         const int w0 = (i * 1024) % RB + lane * 16;
         const int kr = (i * 1024) / RB + w0 / RB, w = w0 % RB;
-        const int plane = w / (BX * 2), ch = (w % (BX * 2)) >> 4;
+        const int plane = P1 ? 0 : w / (BX * 2), ch = (P1 ? w : w % (BX * 2)) >> 4;
         int x = x0 + ((ch ^ ((kr & 3) << 2)) << 3);
         x = x < X ? x : X - 8;                                      // X % 8 == 0 (launcher)
-        return (unsigned)(((long)kr * op.ld + seg_off(op, x)) * 4 + plane * 16);
+        return (unsigned)(((long)kr * op.ld + seg_off(op, x)) * EB + plane * 16);
     };
 #pragma unroll
     for (int j = 0; j < NA; ++j) voa[j] = setup(d.A, TA, BM, m0, d.M, j * NW + wave, !TA && d.rm_T > 0);
@@ -171,15 +180,15 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_img_kernel(const ImgGemmDe
     long a_ko, b_ko;
     int a_w = 0, b_w = 0;
     {
-        const int k0 = kt0 * 32;
-        if (TA) a_ko = (long)k0 * d.A.ld * 4;
+        const int k0 = kt0 * KT;
+        if (TA) a_ko = (long)k0 * d.A.ld * EB;
         else {
-            a_ko = seg_off(d.A, k0) * 4;
+            a_ko = seg_off(d.A, k0) * EB;
             a_w = d.A.seglen ? k0 % d.A.seglen : 0;
         }
-        if (TB) b_ko = (long)k0 * d.B.ld * 4;
+        if (TB) b_ko = (long)k0 * d.B.ld * EB;
         else {
-            b_ko = seg_off(d.B, k0) * 4;
+            b_ko = seg_off(d.B, k0) * EB;
             b_w = d.B.seglen ? k0 % d.B.seglen : 0;
         }
     }
@@ -187,8 +196,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_img_kernel(const ImgGemmDe
     auto issue = [&](int slot) {
         unsigned char* sb = smem + slot * SLOT;
         // reduction-major operands whose K is not a multiple of 32: rows past K come from a block of zeros (A) / are clamped (B)
-        const int kabs = (kt0 + issued) * 32;
-        const bool tail = TA && TB && kabs + 32 > d.K;          // (a K-contiguous operand needs K % 32 == 0: gemm_img_supported)
+        const int kabs = (kt0 + issued) * KT;
+        const bool tail = TA && TB && kabs + KT > d.K;          // (a K-contiguous operand needs K % KT == 0: gemm_img_supported)
         if (!tail) {
 #pragma unroll
             for (int j = 0; j < NA; ++j)
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_img_kernel(const ImgGemmDe
             for (int j = 0; j < NA; ++j) {
                 const unsigned char* p = a_base + a_ko + voa[j];
                 if (TA) {
-                    const int kr = ((j * NW + wave) * 1024) / (BM * 4) + ((BM * 4 < 1024) ? (lane * 16) / (BM * 4) : 0);
+                    const int kr = ((j * NW + wave) * 1024) / (BM * EB) + ((BM * EB < 1024) ? (lane * 16) / (BM * EB) : 0);
                     if (kabs + kr >= d.K) p = (const unsigned char*)d.zeros + lane * 16;
                 }
                 __builtin_amdgcn_global_load_lds((const void*)p, (lds_vp)(sb + (j * NW + wave) * 1024), 16, 0, 0);
@@ -210,32 +219,32 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_img_kernel(const ImgGemmDe
             for (int j = 0; j < NB; ++j) {
                 const unsigned char* p = b_base + b_ko + vob[j];
                 if (TB) {
-                    const int kr = ((j * NW + wave) * 1024) / (BN * 4) + ((BN * 4 < 1024) ? (lane * 16) / (BN * 4) : 0);
-                    if (kabs + kr >= d.K) p -= (long)(kabs + kr - (d.K - 1)) * d.B.ld * 4;       // clamp to the last valid k-row (finite x 0 = 0)
+                    const int kr = ((j * NW + wave) * 1024) / (BN * EB) + ((BN * EB < 1024) ? (lane * 16) / (BN * EB) : 0);
+                    if (kabs + kr >= d.K) p -= (long)(kabs + kr - (d.K - 1)) * d.B.ld * EB;       // clamp to the last valid k-row (finite x 0 = 0)
                 }
                 __builtin_amdgcn_global_load_lds((const void*)p, (lds_vp)(sb + PART_A + (j * NW + wave) * 1024), 16, 0, 0);
             }
         }
         ++issued;
-        if (TA) a_ko += 32L * d.A.ld * 4;
+        if (TA) a_ko += (long)KT * d.A.ld * EB;
         else {
             a_ko += 128;
             if (d.A.seglen) {
-                a_w += 32;
+                a_w += KT;
                 if (a_w >= d.A.seglen) {
                     a_w -= d.A.seglen;
-                    a_ko += (d.A.segstride - d.A.seglen) * 4;
+                    a_ko += (d.A.segstride - d.A.seglen) * EB;
                 }
             }
         }
-        if (TB) b_ko += 32L * d.B.ld * 4;
+        if (TB) b_ko += (long)KT * d.B.ld * EB;
         else {
             b_ko += 128;
             if (d.B.seglen) {
-                b_w += 32;
+                b_w += KT;
                 if (b_w >= d.B.seglen) {
                     b_w -= d.B.seglen;
-                    b_ko += (d.B.segstride - d.B.seglen) * 4;
+                    b_ko += (d.B.segstride - d.B.seglen) * EB;
                 }
             }
         }
@@ -257,29 +266,29 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_img_kernel(const ImgGemmDe
     for (int mi = 0; mi < MI; ++mi) {
         if (!TA) {
             const int row = wm * WTM + mi * 32 + l31;
-            fa[mi] = row * 128 + (((kg << 1) ^ ((row >> 1) & 7)) << 4);
+            fa[mi] = row * 128 + ((((P1 ? kg : kg << 1)) ^ ((row >> 1) & 7)) << 4);     // chunk = 2 * k-group + plane (single-piece: the k-group)
         } else {
             const int x = wm * WTM + mi * 32 + (lane & 16) + 4 * tpp;
-            fa[mi] = (kg * 8 + tq) * (BM * 4) + (((x >> 3) ^ (tq << 2)) << 4) + ((x & 7) << 1);
+            fa[mi] = (kg * 8 + tq) * (BM * EB) + (((x >> 3) ^ (tq << 2)) << 4) + ((x & 7) << 1);
         }
     }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         if (!TB) {
             const int row = wn * WTN + ni * 32 + l31;
-            fb[ni] = row * 128 + (((kg << 1) ^ ((row >> 1) & 7)) << 4);
+            fb[ni] = row * 128 + ((((P1 ? kg : kg << 1)) ^ ((row >> 1) & 7)) << 4);
         } else {
             const int x = wn * WTN + ni * 32 + (lane & 16) + 4 * tpp;
-            fb[ni] = (kg * 8 + tq) * (BN * 4) + (((x >> 3) ^ (tq << 2)) << 4) + ((x & 7) << 1);
+            fb[ni] = (kg * 8 + tq) * (BN * EB) + (((x >> 3) ^ (tq << 2)) << 4) + ((x & 7) << 1);
         }
     }
     // one fragment (8 consecutive k of one tile row, one plane) of k16-step s
     auto frag = [&](const unsigned char* part, bool T, int BX, int o, int s, int plane) -> f16x8 {
-        if (!T) return *reinterpret_cast<const f16x8*>(part + (o ^ (plane << 4) ^ (s << 6)));
+        if (!T) return *reinterpret_cast<const f16x8*>(part + (P1 ? (o ^ (s << 5)) : (o ^ (plane << 4) ^ (s << 6))));
         typedef __attribute__((address_space(3))) s16x4* lptr;
-        const unsigned char* p = part + o + s * 16 * (BX * 4) + plane * (BX * 2);
+        const unsigned char* p = part + o + s * 16 * (BX * EB) + plane * (BX * 2);
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p + 4 * (BX * 4)));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p + 4 * (BX * EB)));
         const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
         return __builtin_bit_cast(f16x8, u32x4{l2[0], l2[1], h2[0], h2[1]});
     };
@@ -290,7 +299,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_img_kernel(const ImgGemmDe
     // tile t + NSLOT) sits inside the LAST stage of tile t, whose fragments are in registers by then.  (hipcc's own order was
     // read-everything / s_waitcnt lgkmcnt(0) / multiply, three times per k16-step: 238 us on the 8192 x 4096 x 1024 projection of which
     // 104 were MFMA time, profiles/r03/img_gemm_ablation.txt.)
-    constexpr int MH = MI >= 4 ? 2 : 1, MIH = MI / MH, NQ = 2 * MH;
+    constexpr int MH = MI >= 4 ? 2 : 1, MIH = MI / MH, NQ = KS * MH;
     f16x8 ah[2][MIH], al[2][MIH], bh[2][NI], bl[2][NI];
     auto load_stage = [&](int slot, int q) {              // q: compile-time after unrolling
         const unsigned char* sa = smem + slot * SLOT;
@@ -300,20 +309,31 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_img_kernel(const ImgGemmDe
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 bh[s & 1][ni] = frag(sb, TB, BN, fb[ni], s, 0);
-                bl[s & 1][ni] = frag(sb, TB, BN, fb[ni], s, 1);
+                if (!P1) bl[s & 1][ni] = frag(sb, TB, BN, fb[ni], s, 1);
             }
         }
 #pragma unroll
         for (int i = 0; i < MIH; ++i) {
             ah[par][i] = frag(sa, TA, BM, fa[h * MIH + i], s, 0);
-            al[par][i] = frag(sa, TA, BM, fa[h * MIH + i], s, 1);
+            if (!P1) al[par][i] = frag(sa, TA, BM, fa[h * MIH + i], s, 1);
         }
     };
     // part 0: the first product (h . l) of every accumulator tile of the stage; part 1: the other two
     auto mfma_stage = [&](int q, int part) {
         const int s = q / MH, h = q % MH, par = q & 1;
         if (IDIAG(d, 2)) {      // diag 2 (wrong results): no MFMAs -> DMA + fragment-read rate
-            if (part == 0) acc[0][0][0] += (float)ah[par][0][0] + (float)al[par][MIH - 1][1] + (float)bh[s & 1][NI - 1][2] + (float)bl[s & 1][0][3];
+            if (part == 0) acc[0][0][0] += (float)ah[par][0][0] + (P1 ? 0.f : (float)al[par][MIH - 1][1]) + (float)bh[s & 1][NI - 1][2] + (P1 ? 0.f : (float)bl[s & 1][0][3]);
+            return;
+        }
+        if (P1) {               // one bf16 product per accumulator tile: part 0 the first column block, part 1 the others
+#pragma unroll
+            for (int i = 0; i < MIH; ++i)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    if ((part == 0) != (ni == 0)) continue;
+                    acc[h * MIH + i][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[par][i]), __builtin_bit_cast(bf16x8, bh[s & 1][ni]),
+                                                                                   acc[h * MIH + i][ni], 0, 0, 0);
+                }
             return;
         }
 #pragma unroll
@@ -370,7 +390,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_img_kernel(const ImgGemmDe
     }
 
     // ---- epilogue
-    const float sa_ = d.scale_a ? *d.scale_a : 16.0f, sb_ = d.scale_b ? *d.scale_b : 16.0f;
+    const float sa_ = d.scale_a ? *d.scale_a : (P1 ? 1.0f : 16.0f), sb_ = d.scale_b ? *d.scale_b : (P1 ? 1.0f : 16.0f);
     const float unscale = (1.0f / sa_) * (1.0f / sb_);
     const bool to_part = d.ksplit > 1;
     float* Cb = to_part ? d.part + (long)z * d.M * d.N : d.C + (long)batch * d.cstride;
@@ -461,12 +481,12 @@ __global__ __launch_bounds__(256) void split_image_kernel(const float* __restric
     }
 }
 
-template <int WTM, int WTN, int WGM, int WGN, bool TA, bool TB, int NSLOT>
+template <int WTM, int WTN, int WGM, int WGN, bool TA, bool TB, int NSLOT, bool P1>
 hipError_t launch_one(const ImgGemmDesc& d, int gm, int gn, hipStream_t s) {
     constexpr int BM = WTM * WGM, BN = WTN * WGN;
     constexpr int LDS = NSLOT * (BM + BN) * 128;
     static bool attr_done = false;
-    auto kern = gemm_img_kernel<WTM, WTN, WGM, WGN, TA, TB, NSLOT>;
+    auto kern = gemm_img_kernel<WTM, WTN, WGM, WGN, TA, TB, NSLOT, P1>;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
@@ -481,7 +501,7 @@ hipError_t launch_one(const ImgGemmDesc& d, int gm, int gn, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, bool P1>
 hipError_t launch_layout(ImgGemmDesc& d, int cfg, hipStream_t s) {
     const int BM = cfg == 1 ? 128 : 256, BN = cfg == 0 ? 256 : 128;
     d.gm = cdiv(d.M, BM);
@@ -496,26 +516,27 @@ hipError_t launch_layout(ImgGemmDesc& d, int cfg, hipStream_t s) {
             d.bw = c[1];
             break;
         }
-    if (cfg == 0) return launch_one<128, 64, 2, 4, TA, TB, 2>(d, d.gm, d.gn, s);
-    if (cfg == 1) return launch_one<64, 64, 2, 2, TA, TB, 2>(d, d.gm, d.gn, s);
-    if (cfg == 3) return launch_one<64, 64, 4, 2, TA, TB, 2>(d, d.gm, d.gn, s);       // 256 x 128 on two slots: 96 KB, leaves a CU room for a 48 KB neighbour
-    return launch_one<64, 64, 4, 2, TA, TB, 3>(d, d.gm, d.gn, s);
+    if (cfg == 0) return launch_one<128, 64, 2, 4, TA, TB, 2, P1>(d, d.gm, d.gn, s);
+    if (cfg == 1) return launch_one<64, 64, 2, 2, TA, TB, 2, P1>(d, d.gm, d.gn, s);
+    if (cfg == 3) return launch_one<64, 64, 4, 2, TA, TB, 2, P1>(d, d.gm, d.gn, s);       // 256 x 128 on two slots: 96 KB, leaves a CU room for a 48 KB neighbour
+    return launch_one<64, 64, 4, 2, TA, TB, 3, P1>(d, d.gm, d.gn, s);
 }
 
 }  // namespace
 
 bool gemm_img_supported(const ImgGemmDesc& d) {
     const bool ta = d.flags & GEMM_TA, tb = d.flags & GEMM_TB;
+    const int KT = d.bf16 ? 64 : 32;
     auto ok = [&](const ImgOperand& op, bool T, int X) {
-        // whole image groups (32 bytes); full speed wants whole 128-byte lines (ld % 32 == 0, 128-byte aligned base)
-        if (((size_t)op.p & 31) || op.ld % 8 || op.bstride % 8) return false;
-        if (op.seglen && (op.seglen % (T ? 8 : 32) || op.segstride % 8)) return false;      // a k-tile of 32 lies inside one segment
-        if (!T) return d.K % 32 == 0;               // K-contiguous: whole k-tiles
+        // whole image groups (32 bytes; single-piece: 16); full speed wants whole 128-byte lines (128-byte aligned base and row stride)
+        if (((size_t)op.p & (d.bf16 ? 15 : 31)) || op.ld % 8 || op.bstride % 8) return false;
+        if (op.seglen && (op.seglen % (T ? 8 : KT) || op.segstride % 8)) return false;      // a k-tile lies inside one segment
+        if (!T) return d.K % KT == 0;               // K-contiguous: whole k-tiles
         return X % 8 == 0;                          // reduction-major: whole column groups
     };
     if (d.M < 1 || d.N < 1 || d.K < 1) return false;
     if (d.N % 4) return false;
-    if ((ta || tb) && d.K % 32 && !d.zeros) return false;
+    if ((ta || tb) && d.K % KT && !d.zeros) return false;
     if (d.rm_T && (d.rm_T < 32 || ta || d.row_period)) return false;
     return ok(d.A, ta, d.M) && ok(d.B, tb, d.N);
 }
@@ -535,10 +556,15 @@ hipError_t launch_gemm_img(const ImgGemmDesc& din, hipStream_t s) {
         cfg = wgs(256, 256) >= 256 ? 0 : (wgs(256, 128) >= 256 ? 2 : 1);
     }
     hipError_t e;
-    if (!ta && !tb) e = launch_layout<false, false>(d, cfg, s);
-    else if (!ta && tb) e = launch_layout<false, true>(d, cfg, s);
-    else if (ta && tb) e = launch_layout<true, true>(d, cfg, s);
-    else e = launch_layout<true, false>(d, cfg, s);
+    if (d.bf16) {
+        if (!ta && !tb) e = launch_layout<false, false, true>(d, cfg, s);
+        else if (!ta && tb) e = launch_layout<false, true, true>(d, cfg, s);
+        else if (ta && tb) e = launch_layout<true, true, true>(d, cfg, s);
+        else e = launch_layout<true, false, true>(d, cfg, s);
+    } else if (!ta && !tb) e = launch_layout<false, false, false>(d, cfg, s);
+    else if (!ta && tb) e = launch_layout<false, true, false>(d, cfg, s);
+    else if (ta && tb) e = launch_layout<true, true, false>(d, cfg, s);
+    else e = launch_layout<true, false, false>(d, cfg, s);
     if (e != hipSuccess) return e;
     if (d.ksplit > 1) e = splitk_reduce(d.part, d.ksplit, d.M, d.N, d.batch, d.C, d.ldc, d.cstride, d.bias, (d.flags & GEMM_ACCUM) != 0, d.rm_T, d.rm_TP, s);
     return e;

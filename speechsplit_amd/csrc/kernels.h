@@ -55,10 +55,13 @@ hipError_t gn_relu_bwd(const float* x, long x_ld, long x_bs, float* dy, long dy_
 // test hook: mask [B, T, C] dense = 1.0f where the block's GroupNorm output is > 0 (the ReLU branch the kernels above take)
 hipError_t gn_relu_mask(const float* x, long x_ld, long x_bs, const float* gamma, const float* beta, const float* stats,
                         float* mask, int B, int T, int C, hipStream_t s);
-// out[c] += sum_r in[r*ld + c]   (atomic accumulate)
-hipError_t colsum_acc(const float* in, long ld, int R, int C, float* out, hipStream_t s);
+// out[c] += sum_r in[r*ld + c], float64 accumulation in a fixed order (elementwise.hip).  part / ctr (nullable): scratch of
+// colsum_scratch_doubles(columns) float64 words and cdiv(columns, 64) zeroed counters (left zero again); without them one workgroup per 64 columns
+long colsum_scratch_doubles(int cols);
+hipError_t colsum_acc(const float* in, long ld, int R, int C, float* out, double* part, unsigned* ctr, hipStream_t s);
 // column sums of a BLSTM layer's [R][2 x C] gradient slab added to (b_ih, b_hh) of both directions
-hipError_t colsum_bias(const float* in, long ld, int R, int C, float* bih0, float* bhh0, float* bih1, float* bhh1, hipStream_t s);
+hipError_t colsum_bias(const float* in, long ld, int R, int C, float* bih0, float* bhh0, float* bih1, float* bhh1, double* part, unsigned* ctr,
+                       hipStream_t s);
 hipError_t copy_rows(const float* src, long s_ld, long s_bs, float* dst, long d_ld, long d_bs, int B, int T, int C,
                      hipStream_t s);
 // batch assembly from a device-resident corpus: see collate_kernel (crop rows, clip mel to [0,1], pad mel with 0 / F0 with -1e10)

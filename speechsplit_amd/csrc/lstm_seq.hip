@@ -752,6 +752,11 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
             if (!ok) return;
         } else {
             f32x4 bsm[4] = {};
+            // bias gradients d b_ih = d b_hh = sum over utterances and time of da: this wave sees every da of the workgroup on its way to the
+            // slab, so it adds them up -- in float64 (a T-step fp32 chain of a cancelling sum was the least accurate reduction of the
+            // backward, profiles/r03/trained_error_budget.txt), off the cell threads' dependent chain
+            double bsd[4][4] = {};
+            float* gbias = dir == 0 ? gbias_f : gbias_b;
             for (int st = 0; st < T; ++st) {
                 if (!barriers_to_products(st)) return;
                 if (!(diag & 8)) {
@@ -763,6 +768,10 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
                         const f32x4 v = *reinterpret_cast<const f32x4*>(&da_st[g][u][4 * q]);
                         if (bt * 16 + u >= B) continue;
                         *reinterpret_cast<f32x4*>(gates + row_of(bt * 16 + u, tau) * (8 * H) + dir * 4 * H + g * H + jt * 16 + 4 * q) = v;
+                        if (gbias) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) bsd[i][j] += (double)v[j];
+                        }
                         if (dgs) {
                             bsm[i] += v;
                             if (close) {
@@ -772,6 +781,22 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
                         }
                     }
                 }
+            }
+            // lane = 4 * utterance + unit quad: the 16 utterances of the tile meet through a fixed butterfly, then one atomic per (gate, unit)
+            // and workgroup (gbias_*: [2][4H] = b_ih then b_hh gradient of one direction; the batch tiles meet in the arena)
+            if (gbias) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        double t = bsd[i][j];
+#pragma unroll
+                        for (int o = 4; o < 64; o <<= 1) t += __shfl_xor(t, o);
+                        if (lane < 4) {
+                            atomicAdd(gbias + i * H + jt * 16 + 4 * lane + j, (float)t);
+                            atomicAdd(gbias + 4 * H + i * H + jt * 16 + 4 * lane + j, (float)t);
+                        }
+                    }
             }
         }
     }
@@ -807,7 +832,6 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
     };
     Ops cur{};
     float amx = 0.f;                                  // max |da| this thread has produced (for the consumers' fp16 scaling)
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};             // sum over time of this thread's da: the bias gradient of its (utterance, unit)
 
     for (int st = 0; st < T && !helper; ++st) {
         f32x4 part = {0.f, 0.f, 0.f, 0.f};
@@ -861,8 +885,6 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
             da[3] = d_o * cur.go * (1.0f - cur.go);
             if (b < B) {
                 amx = fmaxf(fmaxf(amx, fmaxf(fabsf(da[0]), fabsf(da[1]))), fmaxf(fabsf(da[2]), fabsf(da[3])));
-#pragma unroll
-                for (int g = 0; g < 4; ++g) bsum[g] += da[g];
             }
             // power-of-two scale of this utterance's 64 gate units (16 lanes x 4 gates): its maximum lands in [2^7, 2^8)
             const float rmax = row16_max(fmaxf(fmaxf(fabsf(da[0]), fabsf(da[1])), fmaxf(fabsf(da[2]), fabsf(da[3]))));
@@ -915,26 +937,6 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o));
         if (lane == 0) atomicMax(amax, __float_as_uint(amx));
-    }
-    // bias gradients d b_ih = d b_hh = sum over utterances and time of da (gbias_*: [2][4H] = b_ih then b_hh gradient of one
-    // direction, nullable): the 16 utterances of the tile meet in LDS, one atomic per (gate, unit) and workgroup
-    float* gbias = dir == 0 ? gbias_f : gbias_b;
-    if (gbias) {
-        __syncthreads();
-        float* sums = &red[0][0][0];                  // [4][16 utterances][16 units], NW * 256 >= 1024 floats
-        if (cell) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) sums[(g * 16 + bi) * 16 + jj] = bsum[g];
-        }
-        __syncthreads();
-        if (tid < 64) {
-            const int g = tid >> 4, u = tid & 15;
-            float t = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) t += sums[(g * 16 + r) * 16 + u];
-            atomicAdd(gbias + g * H + jt * 16 + u, t);
-            atomicAdd(gbias + 4 * H + g * H + jt * 16 + u, t);
-        }
     }
 }
 

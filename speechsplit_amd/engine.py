@@ -213,10 +213,10 @@ class Engine:
         self.adam_step(1.0 / world)
         return self.loss
 
-    def dp_g6_train_step(self, mel, f0_onehot, target_idx, draws, world, group=None):
+    def dp_g6_train_step(self, mel, f0_onehot, target_idx, draws, world, group=None, bucket=False):
         """Data-parallel Generator_6 step (BASELINE config 4): the arena is 14 MB, one pass of the bucket plan behind the backward."""
         from . import dist as D
-        self.g6_train_step(mel, f0_onehot, target_idx, draws, no_adam=True)
+        self.g6_train_step(mel, f0_onehot, target_idx, draws, no_adam=True, bucket=bucket)
         D.reduce_arena(self.grads, self.grad_split, group)
         self.adam_step(1.0 / world)
         return self.loss

@@ -37,6 +37,13 @@ class Solver(object):
         self.resume_iters = config.resume_iters
         self.use_tensorboard = getattr(config, 'use_tensorboard', False)
         self.rank, self.local_rank, self.world = _dist.world_info()
+        # data-parallel exchange (world > 1): 'native' = the engine's own RCCL communicator and bucket schedule (ss_g3_dp_train_step /
+        # ss_g6_dp_train_step), 'torch' = torch.distributed all-reduces around the engine's no-Adam step (Engine.dp_train_step).  The native
+        # schedule has never run on more than one GPU (the development boxes have one); the torch path is the fallback until it has.
+        self.dp_backend = getattr(config, 'dp_backend', None) or os.environ.get('SS_DP_BACKEND', 'native')
+        if self.dp_backend not in ('native', 'torch'):
+            raise ValueError("dp_backend must be 'native' or 'torch', got {!r}".format(self.dp_backend))
+        self.dp_schedule = getattr(config, 'dp_schedule', None) or os.environ.get('SS_DP_SCHEDULE', 'overlap')
         self.use_cuda = torch.cuda.is_available()
         if not self.use_cuda:
             raise RuntimeError('speechsplit_amd.Solver needs a ROCm GPU (the engine has no CPU fallback)')
@@ -69,7 +76,8 @@ class Solver(object):
             self.eng.set_lockstep(True)              # never refuse a step on the status word: check() reports it on every rank at the same iteration
             # the engine's own RCCL communicator: its data-parallel step launches the collectives on the engine's streams and costs
             # nothing over the one-GPU step, where torch.distributed's path measured +0.5 ms
-            self.eng.comm_init(self.rank, self.world)
+            if self.dp_backend == 'native':
+                self.eng.comm_init(self.rank, self.world)
 
     def print_network(self, model, name):
         num_params = sum(p.numel() for p in model.parameters())
@@ -130,7 +138,10 @@ class Solver(object):
         to = dict(device=self.device, non_blocking=True)
         # a batch whose frame count is not hparams.max_len_pad is a length bucket (speechsplit_amd/buckets.py): max_len_pad = T
         bucket = x_real_org.shape[1] != self.hparams.max_len_pad
-        if self.world > 1:
+        if self.world > 1 and self.dp_backend == 'torch':
+            loss = self.eng.dp_train_step(x_real_org.to(**to), f0_org.to(**to), emb_org.to(**to), len_org.to(**to), draws, self.world,
+                                          schedule=self.dp_schedule, bucket=bucket)
+        elif self.world > 1:
             loss = self.eng.dp_train_step_native(x_real_org.to(**to), f0_org.to(**to), emb_org.to(**to), len_org.to(**to), draws,
                                                  bucket=bucket)
         else:
@@ -257,7 +268,9 @@ class SolverF0(Solver):
         mel, f0 = x_real_org.to(**to), f0_org.to(**to)
         onehot, idx = quantize_f0_torch(f0[:, :, 0])
         bucket = mel.shape[1] != self.hparams.max_len_pad
-        if self.world > 1:
+        if self.world > 1 and self.dp_backend == 'torch':
+            loss = self.eng.dp_g6_train_step(mel, onehot, idx.to(torch.int32), draws, self.world, bucket=bucket)
+        elif self.world > 1:
             loss = self.eng.g6_dp_train_step_native(mel, onehot, idx.to(torch.int32), draws, bucket=bucket)
         else:
             loss = self.eng.g6_train_step(mel, onehot, idx.to(torch.int32), draws, bucket=bucket)

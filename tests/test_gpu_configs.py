@@ -187,61 +187,27 @@ def test_trained_state_step_matches_oracle(E, case):
     assert moved > 0.02, moved                                 # far from the initial weights (lr * steps = 0.06 .. 0.1 at most)
     c.st = ref_model.TrainState({n: v.numpy() for n, v in pv.items()}, LR)
     c.st.load_adam({n: v.cpu().numpy() for n, v in eng.views(eng.adam_m).items()}, {n: v.cpu().numpy() for n, v in eng.views(eng.adam_v).items()}, steps)
-    mel_l, f0_l, emb_l, lens_l = c.mel, c.f0, c.emb, c.lens
-    masks_for64 = {}
-    orig_masks = eng.relu_masks
-
-    def keep_masks(*a, **k):                                   # the ReLU branches Case.step hands to the fp32 oracle, kept for the fp64 one
-        m = orig_masks(*a, **k)
-        masks_for64.update({kk: v.cpu() for kk, v in m.items()})
-        return m
-
-    eng.relu_masks = keep_masks
     p_before = {n: v.clone() for n, v in pv.items()}
     for kv in os.environ.get('SS_TRAINED_TUNE', '').split(','):       # diagnosis: e.g. SS_TRAINED_TUNE=bwd_f16x2=0 for the compared step only
         if '=' in kv:
             E.tune(kv.split('=')[0], int(kv.split('=')[1]))
     r = c.step(steps)
     tag = f'{kind} {B}x{T} after {steps} engine steps (loss {loss0:.4f} -> {lossN:.4f}, weights moved by up to {moved:.3f})'
-    # Bars as everywhere: loss 1e-5, output and every gradient element 1e-4 of its tensor's maximum against the fp32 oracle.  At a TRAINED
-    # state some gradient tensors are heavily cancelling sums (bias gradients above all: the head's is sum_r (softmax - onehot), two
-    # nearly equal totals), and two correct fp32 implementations then differ by more than 1e-4 of the tensor's maximum -- given a state
-    # the engine's distance is reproducible to two digits, it is a property of the state, not run-to-run noise (tools/
-    # trained_error_budget.py; profiles/r03/trained_error_budget.txt).  For a tensor beyond the bar the arbiter is the same oracle
-    # evaluated in FLOAT64 on the same inputs, draws and ReLU branches: the engine must be within the bar of THAT, or at most ARB times
-    # as far from it as the fp32 oracle itself is.  ARB = 16 is derived, not fitted: the engine's products carry 22 significand bits
-    # against fp32's 24 (4x the rounding noise per product) and its weight-gradient reductions run as single accumulation chains over
-    # up to B*T/ksplit rows where PyTorch-CPU's blocked GEMM adds partial sums of a few hundred terms (~sqrt(16) = 4x).  The training run
-    # is deterministic (ss_tune("deterministic")), so the compared state -- and with it the verdict -- is the same on every run.
-    ARB = 16.0
+    # Bars as everywhere, no exceptions: loss 1e-5, output and every element of every gradient tensor 1e-4 of its tensor's maximum against the
+    # fp32 oracle.  (Round 3 sent tensors beyond the bar to a float64 arbiter with a 16x allowance; round 4 removed the cause instead: the gate
+    # non-linearities were 3e-7 ABSOLUTE -- 1e-6 relative for |x| ~ 0.1 .. 0.5, where cell states live -- and the recurrences carry every such
+    # rounding forward; the bias-type sums were fp32 chains met through atomics.  Now tanh / sigmoid are good to ~2 ulp and those sums run in
+    # float64 in a fixed order: against the float64 oracle the engine's gradients are 2-3.5x as far as PyTorch-CPU's, worst tensor 2-3e-5,
+    # profiles/r04/trained_error_budget.txt.)  The training run is deterministic (ss_tune("deterministic")), so the compared state is the same
+    # on every run.
     assert abs(r['loss_gpu'] - r['loss_cpu']) <= 1e-5 * abs(r['loss_cpu']), (tag, r['loss_gpu'], r['loss_cpu'])
     assert rel(r['out_gpu'], r['out_cpu']) < TOL, tag
     errs = {n: rel(r['grads_gpu'][n], g) for n, g in r['grads_cpu'].items()}
-    beyond = {n: e for n, e in errs.items() if not e < TOL}
     worst = max(errs.items(), key=lambda x: x[1])
-    print(f'[{tag}] loss {r["loss_gpu"]:.8f} (oracle {r["loss_cpu"]:.8f}); worst gradient tensor {worst[0]}: {worst[1]:.2e}; beyond 1e-4 vs fp32 oracle: {sorted(beyond)}')
-    if beyond:
-        P64 = {n: v.double().requires_grad_(True) for n, v in p_before.items()}
-        draws = draws_for(c.dseed + steps, B, c.ncalls)
-        ref_model.MASK, ref_model.MASK_STATS = masks_for64, {}
-        try:
-            if kind == 'G3':
-                x_f0 = torch.cat((mel_l, f0_l), -1)
-                xi = ref_model.interp(x_f0, lens_l.numpy(), draws[0], c.hp)                 # resampling and re-quantisation in fp32, as the step does
-                onehot, _ = ref_model.quantize_f0(xi[:, :, -1])
-                out64 = ref_model.generator_3(P64, c.hp, torch.cat((xi[:, :, :-1], onehot), -1).double(), mel_l.double(), emb_l.double(), draws[1:4], training=True)
-                loss64 = torch.nn.functional.mse_loss(mel_l.double(), out64, reduction='mean')
-            else:
-                logits = ref_model.generator_6(P64, c.hp, mel_l.double(), c.onehot.double(), draws, training=True)
-                loss64 = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), c.qidx.reshape(-1))
-            loss64.backward()
-        finally:
-            ref_model.MASK, ref_model.MASK_STATS = None, None
-        for n in beyond:
-            g64 = P64[n].grad
-            e_gpu, e_cpu = rel(r['grads_gpu'][n], g64), rel(r['grads_cpu'][n], g64)
-            print(f'[{tag}] {n}: vs the float64 oracle: engine {e_gpu:.2e}, fp32 oracle {e_cpu:.2e}')
-            assert e_gpu <= max(TOL, ARB * e_cpu), (tag, n, e_gpu, e_cpu)
+    med = sorted(errs.values())[len(errs) // 2]
+    print(f'[{tag}] loss {r["loss_gpu"]:.8f} (oracle {r["loss_cpu"]:.8f}); gradient tensors vs the fp32 oracle: worst {worst[0]} {worst[1]:.2e}, median {med:.2e}')
+    beyond = {n: e for n, e in errs.items() if not e < TOL}
+    assert not beyond, (tag, beyond)
     # one Adam step from the SAME state on both sides
     tot = off = 0
     for n, pc in r['p_cpu'].items():

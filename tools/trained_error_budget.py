@@ -47,9 +47,11 @@ def main():
         q = torch.from_numpy(interp_np.quantize_f0(f0[:, :, 0].numpy()))
         return eng.g6_train_step(mel, torch.nn.functional.one_hot(q, 257).float(), q, d, no_adam=no_adam)
 
+    E.tune('deterministic', 1)                 # a reproducible trained state, the one tests/test_gpu_configs.py compares at
     for i in range(steps):
         loss = run(*batches[i % 4], stack(draws_for(20000 + i, B, ncalls)), False)
     eng.check()
+    E.tune('deterministic', 0)
     print(f'{kind} {B}x{T}: trained {steps} steps, loss {float(loss):.4f}')
     pv = {n: v.clone().cpu() for n, v in eng.param_views().items()}
     mel, f0, emb, lens = synth_batch(1300 + B, B, T, len_lo)
@@ -100,8 +102,36 @@ def main():
         print(f'{tag:38s} loss {abs(lo - lo64) / abs(lo64):.1e}  out {rel(out, out64):.1e}  grads: worst {errs[0][0]:.1e} ({errs[0][1]}), '
               f'median {errs[len(errs) // 2][0]:.1e}, beyond 1e-4: {beyond}')
 
+    def by_class(tag, g):
+        # the same errors grouped by what kind of reduction produced the tensor: (median, worst) per class
+        cls = {}
+        for n in g64:
+            k = ('lstm.bias' if '.bias_' in n else 'lstm.W_ih' if 'weight_ih' in n else 'lstm.W_hh' if 'weight_hh' in n else
+                 'head.' + n.rsplit('.', 1)[1] if 'linear_projection' in n else 'conv.' + n.rsplit('.', 1)[1] if '.conv.' in n else
+                 'gn.' + n.rsplit('.', 1)[1])
+            k = ('dec ' if n.startswith('decoder') else 'enc ') + k
+            cls.setdefault(k, []).append(rel(g[n], g64[n]))
+        print(f'    {tag}: ' + '; '.join(f'{k} {sorted(v)[len(v) // 2]:.1e}/{max(v):.1e}' for k, v in sorted(cls.items())))
+
+    if kind == 'G6':
+        # the loss kernel on its own: the engine's d(loss)/d(logits) against float64 cross-entropy gradients of the ENGINE's logits, and the
+        # same for PyTorch's fp32 cross_entropy on those logits
+        z = eng.debug_buffer('out', B, T).cpu()
+        dz = eng.debug_buffer('d_out', B, T).cpu()
+        z64 = z.double().reshape(-1, z.shape[-1]).requires_grad_(True)
+        torch.nn.functional.cross_entropy(z64, qidx.reshape(-1)).backward()
+        z32 = z.reshape(-1, z.shape[-1]).clone().requires_grad_(True)
+        torch.nn.functional.cross_entropy(z32, qidx.reshape(-1)).backward()
+        print(f'loss kernel alone (same logits): d_logits engine {rel(dz.reshape(-1, z.shape[-1]), z64.grad):.1e}, PyTorch fp32 {rel(z32.grad, z64.grad):.1e}; '
+              f'column sums (the head bias gradient): engine {rel(dz.reshape(-1, z.shape[-1]).double().sum(0), z64.grad.sum(0)):.1e}, '
+              f'PyTorch fp32 {rel(z32.grad.double().sum(0), z64.grad.sum(0)):.1e}; max |logit| {float(z.abs().max()):.1f}')
     print('errors against the float64 oracle (max-norm relative per tensor):')
     report('fp32 oracle (PyTorch CPU)', lo32, out32, g32)
+    by_class('fp32 oracle, median/worst per class', g32)
+    by_class('engine default, median/worst per class', first[2])
+    if os.environ.get('SS_BUDGET_SETTINGS'):                 # e.g. SS_BUDGET_SETTINGS=default: only the named settings
+        keep = os.environ['SS_BUDGET_SETTINGS'].split(',')
+        settings = [s for s in settings if s[0] in keep]
     for tag, tunes in settings:
         try:
             lo, out, g, _ = engine_pass(tunes)
