@@ -215,7 +215,9 @@ int ss_op_lstm_bwd(float* gates_dev, const float* whh_f_dev, const float* whh_b_
  * hi pieces and 16 bytes of lo pieces of the fp16 x 2 split of scale * x (scale a power of two).
  *   ss_op_split_image: fp32 [rows][cols] (row stride ld) -> image (row stride ldi; cols % 8 == 0).
  *   ss_op_gemm_img:    C[M,N] (+)= sum_k A(m,k) B(n,k) (+ bias) over two images split with scale_a / scale_b.  flags: 1 = A stored [K,M],
- *                      2 = B stored [K,N], 4 = accumulate into C.  a_seglen / a_segstride: segmented K axis of a K-contiguous A (k = seg *
+ *                      2 = B stored [K,N], 4 = accumulate into C, 8 = single-piece form: both operands are plain bf16 matrices (2 bytes
+ *                      per element, ld in elements, no scales; K % 64 == 0 for a K-contiguous operand) -- the 16-bit data path of
+ *                      SS_PRECISION_BF16, where a slab stored in bf16 is its own image.  a_seglen / a_segstride: segmented K axis of a K-contiguous A (k = seg *
  *                      seglen + w lives at column seg * segstride + w: a k=5 convolution over a haloed slab), 0 = none.  ksplit > 1 needs
  *                      part_dev (ksplit * M * N floats of scratch; partial slabs, added in a fixed order).  zeros_dev: >= 1 KB of zero bytes
  *                      (needed when both operands are reduction-major and K % 32 != 0).  cfg: -1 = choose the tile, 0 = 256 x 256,

@@ -113,7 +113,7 @@ hipError_t splitk_reduce(const float* part, int ksplit, int M, int N, int batch,
 // fp32 [rows][cols] -> image (cols % 8 == 0).  Scale: pow2_scale_of(*amax) when amax is given (device word), else fixed_scale; written to
 // *scale_out (nullable) for the GEMM's epilogue
 hipError_t split_image(const float* src, long ld, long rows, int cols, const float* amax, float fixed_scale, float* img, long ldi, float* scale_out,
-                       hipStream_t s);
+                       hipStream_t s, int bf16 = 0);       // bf16: the image is the plain bf16 tensor (no scale; amax / fixed_scale / scale_out unused)
 
 // phase probe of the bf16x3 kernel (timing experiments): 4 waves x {5 phases, k-tile count} tick sums; see gemm_bf16x3.hip
 hipError_t gemm_phase_probe(unsigned long long out[24], bool reset);
@@ -170,6 +170,21 @@ __device__ __forceinline__ void ss_store_group(float* at, uint4 g) {
     const int half = (int)((a >> 4) & 1) * 8;
     *reinterpret_cast<uint2*>(base + half) = make_uint2(g.x, g.y);
     *reinterpret_cast<uint2*>(base + 16 + half) = make_uint2(g.z, g.w);
+}
+// Four consecutive values into an image at ELEMENT index `elem` from the image's base.  bf16 == 0: format v2 (fp16 x 2 pieces of scale * v);
+// bf16 != 0 (the 16-bit data path, SS_PRECISION_BF16): the image is the plain bf16 tensor -- 8 bytes at 2 * elem, round to nearest even
+// (v_cvt_pk_bf16_f32; a NaN stays a NaN), no scale.
+__device__ __forceinline__ uint4 ss_split_group_s(float v0, float v1, float v2, float v3, float s);
+__device__ __forceinline__ void ss_store_group(float* at, uint4 g);
+__device__ __forceinline__ uint2 ss_pack_bf16x4(float v0, float v1, float v2, float v3) {
+    typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    const bf2_t a = __builtin_convertvector(f2_t{v0, v1}, bf2_t), b = __builtin_convertvector(f2_t{v2, v3}, bf2_t);
+    return make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+}
+__device__ __forceinline__ void ss_store_img4(float* img, long elem, float v0, float v1, float v2, float v3, float scale, int bf16) {
+    if (bf16) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(img) + 2 * elem) = ss_pack_bf16x4(v0, v1, v2, v3);
+    else ss_store_group(img + elem, ss_split_group_s(v0, v1, v2, v3, scale));
 }
 // the same with a caller-supplied power-of-two scale
 __device__ __forceinline__ uint4 ss_split_group_s(float v0, float v1, float v2, float v3, float s) {

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, MAXIT <= 8 ? 5 : 4) void gn_relu_gather_kernel
                                                              long y_bs, float* __restrict__ y_img, const float* __restrict__ img_scale,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ stats, int T, int C, int P, const int* __restrict__ i0,
-                                                             const float* __restrict__ lam, const int* __restrict__ nrows) {
+                                                             const float* __restrict__ lam, const int* __restrict__ nrows, int img_bf16) {
     __shared__ float red[256];
     __shared__ float g4[4];
     extern __shared__ __attribute__((aligned(16))) float gn_tile[];       // [T + 1][64]
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, MAXIT <= 8 ? 5 : 4) void gn_relu_gather_kernel
     const int live = nrows[b];
     const float isc = (y_img && img_scale) ? *img_scale : 16.0f;
     float* yb = y + b * y_bs + blockIdx.x * 64 + l16 * 4;
-    float* yib = y_img ? y_img + b * y_bs + blockIdx.x * 64 + l16 * 4 : nullptr;
+    const long yie = b * y_bs + blockIdx.x * 64 + l16 * 4;        // element index of this thread's column group in the image
     for (int r = rg; r < P; r += 16) {
         f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
         if (r < live) {
@@ -184,9 +184,9 @@ __global__ __launch_bounds__(256, MAXIT <= 8 ? 5 : 4) void gn_relu_gather_kernel
             for (int j = 0; j < 4; ++j) o[j] = ss_lerp_rn(ol, a[j], l, bb[j]);      // model.py:430, three roundings
         }
         *reinterpret_cast<f32x4*>(yb + (long)r * y_ld) = o;
-        if (yib) {
-            if (r < live) ss_store_group(yib + (long)r * y_ld, ss_split_group_s(o[0], o[1], o[2], o[3], isc));
-            else *reinterpret_cast<f32x4*>(yib + (long)r * y_ld) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (y_img) {
+            if (r < live || img_bf16) ss_store_img4(y_img, yie + (long)r * y_ld, o[0], o[1], o[2], o[3], isc, img_bf16);      // (o is zero past the live rows)
+            else *reinterpret_cast<f32x4*>(y_img + yie + (long)r * y_ld) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
 }
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256) void collate_kernel(const float* __restrict__ 
 
 __global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict__ w, int Co, int Ci, int Cp,
                                                         float* __restrict__ wf, float* __restrict__ wb, float* __restrict__ wf_img,
-                                                        float* __restrict__ wb_img) {
+                                                        float* __restrict__ wb_img, int img_bf16) {
     // wf[co][k][cp] ; wb[ci][k][co] = w[co][ci][4-k].  Cp and Co are multiples of 4: a thread writes one group of four (and its image)
     const long nf = (long)Co * 5 * Cp / 4;
     const long nb = (long)Ci * 5 * Co / 4;
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict_
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = cp + j < Ci ? w[((long)co * Ci + cp + j) * 5 + k] : 0.f;
             reinterpret_cast<float4*>(wf)[gi] = make_float4(v[0], v[1], v[2], v[3]);
-            if (wf_img) ss_store_group(wf_img + 4 * gi, ss_split_group(v[0], v[1], v[2], v[3]));
+            if (wf_img) ss_store_img4(wf_img, 4 * gi, v[0], v[1], v[2], v[3], 16.0f, img_bf16);
         } else if (wb) {
             const long q = (gi - nf) * 4;
             const int co = (int)(q % Co);
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict_
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = w[((long)(co + j) * Ci + ci) * 5 + (4 - k)];
             reinterpret_cast<float4*>(wb)[gi - nf] = make_float4(v[0], v[1], v[2], v[3]);
-            if (wb_img) ss_store_group(wb_img + 4 * (gi - nf), ss_split_group(v[0], v[1], v[2], v[3]));
+            if (wb_img) ss_store_img4(wb_img, 4 * (gi - nf), v[0], v[1], v[2], v[3], 16.0f, img_bf16);
         }
     }
 }
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepTable tb) {
                 v.x += w.x, v.y += w.y, v.z += w.z, v.w += w.w;
             }
             d[i] = v;
-            if (t.img) ss_store_group(t.img + 4 * i, ss_split_group(v.x, v.y, v.z, v.w));
+            if (t.img) ss_store_img4(t.img, 4 * i, v.x, v.y, v.z, v.w, 16.0f, tb.img_bf16);
         }
     } else {
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < t.n; i += stride) t.dst[i] = t.a[i] + (t.b ? t.b[i] : 0.f);
@@ -775,9 +775,9 @@ hipError_t gn_relu_fwd(const float* x, long x_ld, long x_bs, float* y, long y_ld
 }
 
 hipError_t gn_relu_gather(const float* x, long x_ld, long x_bs, float* y, long y_ld, long y_bs, float* y_img, const float* img_scale,
-                          const float* gamma, const float* beta, float* stats, const InterpPlan& p, int B, int T, int C, hipStream_t s) {
+                          const float* gamma, const float* beta, float* stats, const InterpPlan& p, int B, int T, int C, hipStream_t s, int img_bf16) {
     if (C % 64 != 0 || T > 16 * GN_MAXIT || p.T != T || y_ld % 4 || y_bs % 4 || (((size_t)y) & 15)) return hipErrorInvalidValue;
-    if (y_img && (y_ld % 8 || y_bs % 8 || (((size_t)y_img) & 31))) y_img = nullptr;             // image format v2: groups of eight
+    if (y_img && (y_ld % 8 || y_bs % 8 || (((size_t)y_img) & (img_bf16 ? 15 : 31)))) y_img = nullptr;             // image format v2: groups of eight (bf16: 16-byte fragments)
     const int lds = (T + 1) * 64 * 4;
     auto kern = T <= 128 ? gn_relu_gather_kernel<8> : (T <= 192 ? gn_relu_gather_kernel<12> : gn_relu_gather_kernel<GN_MAXIT>);
     if (lds > 64 * 1024) {
@@ -785,7 +785,7 @@ hipError_t gn_relu_gather(const float* x, long x_ld, long x_bs, float* y, long y
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3(C / 64, B), dim3(256), lds, s, x, x_ld, x_bs, y, y_ld, y_bs, y_img, img_scale, gamma, beta,
-                       stats, T, C, p.P, p.i0, p.lam, p.nrows);
+                       stats, T, C, p.P, p.i0, p.lam, p.nrows, img_bf16);
     return hipGetLastError();
 }
 
@@ -853,12 +853,12 @@ hipError_t collate(const float* mel_cat, const float* f0_cat, const float* emb_t
     return hipGetLastError();
 }
 
-hipError_t conv_pack(const float* w, int Co, int Ci, int Cp, float* wf, float* wb, float* wf_img, float* wb_img, hipStream_t s) {
+hipError_t conv_pack(const float* w, int Co, int Ci, int Cp, float* wf, float* wb, float* wf_img, float* wb_img, hipStream_t s, int img_bf16) {
     if (Cp % 4 || Co % 4) return hipErrorInvalidValue;
     const long n = ((long)Co * 5 * Cp + (long)Ci * 5 * Co) / 4;
     int g = cdiv(n, 256);
     if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(conv_pack_kernel, dim3(g), dim3(256), 0, s, w, Co, Ci, Cp, wf, wb, wf_img, wb_img);
+    hipLaunchKernelGGL(conv_pack_kernel, dim3(g), dim3(256), 0, s, w, Co, Ci, Cp, wf, wb, wf_img, wb_img, img_bf16);
     return hipGetLastError();
 }
 

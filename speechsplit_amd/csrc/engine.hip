@@ -47,6 +47,11 @@ int g_dp_model = 0;        // > 1: MODEL a data-parallel run of that many ranks 
                            // the modelled duration (tools/dp_timeline.sh); no communicator needed
 int g_dp_buckets = 1;      // 1: per-layer gradient buckets on the communication stream; 0: round 2's two buckets
 int g_cur_klass = -1;      // profile class of the contraction being launched (set by the PGEMM macros)
+int g_bf16_img = 1;        // SS_PRECISION_BF16: the 16-bit data path (round 4) -- operand images are plain bf16 tensors written by their producers (weights,
+                           // hidden states, resampled activations, pre-activation / conv-output gradients) and the contractions over them run on the
+                           // single-piece form of the image GEMM; 0: round 3's bf16 mode (fp32 slabs, operands rounded inside the GEMM)
+int g_seq_hi = 1;          // ... and the persistent recurrences multiply the high fp16 pieces only (one MFMA per product, half the forward's payload)
+int g_bf16_img_mask = ~0;  // ... per profile class (bit SS_PROF_*), for A/B runs
 int g_presplit = 7;        // weights (and, bit 1, the decoder's hidden states) reach the fp16 x 2 GEMMs as pre-split images: bit 0 weights, bit 1 the decoder's hidden states, bit 2 the trunk's resampled activations
 int g_compact0 = 1;        // decoder layer 0: input projections, input gradient and W_ih gradient once per block of repeated input frames
 int g_batch_dirs = 1;      // BLSTM weight gradients: both directions of a layer in one launch per matrix (batch = 2) + one bias kernel:
@@ -258,6 +263,7 @@ struct ss_engine {
     float* gp_all = nullptr;               // packed conv weight-gradient images (all blocks)
     // gradient slabs as images for the image GEMM: written by split_image with the measured scale (gscale[i] beside amax[i])
     float* dg_img[3] = {nullptr, nullptr, nullptr};       // decoder layers' pre-activation gradients [B, TP, 8H]
+    int dg16_written = 0;                                 // 16-bit data path: bit l = decoder layer l's backward recurrence wrote dg_img[l] (plain bf16) in this backward
     float *d_img = nullptr, *d_img_t = nullptr;           // conv-output gradients of the trunk [B, TP, CE] / Encoder_t [B, TP, dim_enc_2]
     float* gscale = nullptr;               // [16]
     float* act_scale = nullptr;            // [8] per conv block: scale of its output's fp16 x 2 split (act_scales, from the GroupNorm affine)
@@ -313,6 +319,11 @@ struct ss_engine {
     bool prof_live = true;                // this step is one of them
 
     long carve(int B, int T, bool assign);
+    // 16-bit data path: the operand images are plain bf16 tensors (2 bytes per element) instead of format-v2 images (4)
+    bool img16() const { return precision == SS_PRECISION_BF16 && g_bf16_img; }
+    // image pointer `elems` ELEMENTS behind `base` (an image has its tensor's geometry; the bytes per element depend on the format)
+    float* ioff(float* base, long elems) const { return img16() ? (float*)((char*)base + 2 * elems) : base + elems; }
+    const float* ioff(const float* base, long elems) const { return img16() ? (const float*)((const char*)base + 2 * elems) : base + elems; }
 };
 
 namespace {
@@ -634,9 +645,16 @@ int pick_ksplit(int M, int N, long K) {
 // Image GEMM (gemm_img.hip) for a contraction whose two operands exist as images.  Returns 1 when it was launched, 0 when the
 // contraction has to take round 2's kernels (no images, shape outside what the image kernel supports), < 0 on error.
 int try_img_gemm(ss_engine* e, const GemmDesc& d, hipStream_t st) {
-    if (!g_img || !(d.flags & GEMM_F16X2) || (d.flags & GEMM_BF16) || !d.a_pre || !d.b_pre) return 0;
-    if (g_cur_klass >= 0 && !((g_img_mask >> g_cur_klass) & 1) && !d.queue) return 0;
+    if (!g_img || !d.a_pre || !d.b_pre) return 0;
+    const bool b16 = e->img16();                     // the images are plain bf16 tensors: single-piece form, every class that has both
+    if (b16) {
+        if (g_cur_klass >= 0 && !((g_bf16_img_mask >> g_cur_klass) & 1)) return 0;
+    } else {
+        if (!(d.flags & GEMM_F16X2) || (d.flags & GEMM_BF16)) return 0;
+        if (g_cur_klass >= 0 && !((g_img_mask >> g_cur_klass) & 1) && !d.queue) return 0;
+    }
     ImgGemmDesc g{};
+    g.bf16 = b16 ? 1 : 0;
     g.A = {d.a_pre, d.A.ld, d.A.bstride, d.A.seglen, d.A.segstride};
     g.B = {d.b_pre, d.B.ld, d.B.bstride, d.B.seglen, d.B.segstride};
     g.C = d.C;
@@ -652,8 +670,8 @@ int try_img_gemm(ss_engine* e, const GemmDesc& d, hipStream_t st) {
     g.row_off = d.row_off;
     g.row_lo = d.row_lo;
     g.row_hi = d.row_hi;
-    g.scale_a = d.a_pre_scale;
-    g.scale_b = d.b_pre_scale;
+    g.scale_a = b16 ? nullptr : d.a_pre_scale;
+    g.scale_b = b16 ? nullptr : d.b_pre_scale;
     g.zeros = e->zeros;
     g.cfg = -1;
     g.ksplit = 1;
@@ -732,6 +750,7 @@ int gemm_on(ss_engine* e, GemmDesc& d, hipStream_t st) {
     const int r = try_img_gemm(e, d, st);
     if (r < 0) return r;
     if (r == 0) {
+        if (e->img16()) d.a_pre = d.b_pre = nullptr;        // plain bf16 tensors: not the format-v2 images round 2's kernel can take
         // split-K weight gradients: partial slabs + ordered reduce instead of fp32 atomics (ss_tune("part_splitk")), scratch from the step's bump allocator
         // (not for the encoder BLSTMs' tiny matrices: a one-block reduce over 32 slices is 17 us of latency, their atomics are nothing)
         if (g_part_splitk && d.ksplit > 1 && (d.flags & GEMM_TA) && (d.flags & GEMM_TB) && (d.flags & GEMM_ACCUM) && !d.row_period && !d.bias && d.N % 4 == 0 &&
@@ -984,7 +1003,7 @@ void flatten_rows(GemmDesc& d, int B, int T) {
 // ---- convolution block -------------------------------------------------------------------------------------
 int conv_pack_all(ss_engine* e, ConvBlk& cb, hipStream_t s) {
     const bool img = cb.img_ok();
-    HIPCHK(conv_pack(e->P + cb.w, cb.Co, cb.Ci, cb.Cp, cb.wf, cb.wb, img ? cb.wf_img : nullptr, img ? cb.wb_img : nullptr, s));
+    HIPCHK(conv_pack(e->P + cb.w, cb.Co, cb.Ci, cb.Cp, cb.wf, cb.wb, img ? cb.wf_img : nullptr, img ? cb.wb_img : nullptr, s, e->img16()));
     return 0;
 }
 
@@ -996,9 +1015,9 @@ int zero_conv_grads(ss_engine* e, hipStream_t s) {
 // where the image of a conv-output gradient slab view goes (the trunk's views share d_img, Encoder_t's has d_img_t); null: no image
 float* grad_img_of(ss_engine* e, const float* p, long R) {
     auto in = [&](const float* b, long cols) { return b && p >= b && p < b + R * cols; };
-    if (in(e->d_act, e->CE)) return e->d_img + (p - e->d_act);
-    if (in(e->d_xf, e->CE)) return e->d_img + (p - e->d_xf);
-    if (in(e->d_act_t, e->hp.dim_enc_2)) return e->d_img_t + (p - e->d_act_t);
+    if (in(e->d_act, e->CE)) return e->ioff(e->d_img, p - e->d_act);
+    if (in(e->d_xf, e->CE)) return e->ioff(e->d_img, p - e->d_xf);
+    if (in(e->d_act_t, e->hp.dim_enc_2)) return e->ioff(e->d_img_t, p - e->d_act_t);
     return nullptr;
 }
 
@@ -1030,7 +1049,7 @@ int conv_block_fwd(ss_engine* e, ConvBlk& cb, Slab x, Slab y, hipStream_t s, con
     if (gather) {
         if (gather_ready) HIPCHK(hipStreamWaitEvent(s, gather_ready, 0));
         HIPCHK(gn_relu_gather(cb.cout, cb.Co, TP * cb.Co, gy, gy_ld, TP * gy_ld, gy_img, e->act_scale + cb.scale_i, e->P + cb.ga, e->P + cb.be, cb.stats,
-                              *gather, B, T, cb.Co, s));
+                              *gather, B, T, cb.Co, s, e->img16()));
         return 0;
     }
     HIPCHK(gn_relu_fwd(cb.cout, cb.Co, TP * cb.Co, y.p, y.ld, TP * y.ld, e->P + cb.ga, e->P + cb.be, cb.stats, B, T, cb.Co, s));
@@ -1052,19 +1071,20 @@ int conv_block_bwd(ss_engine* e, ConvBlk& cb, Slab dy, Slab x, Slab dx, hipStrea
     // the conv-output gradient as an image for the image GEMM (scale: the power of two for the maximum gn_relu_bwd has just measured)
     const float* dimg = nullptr;
     const float* dsc = nullptr;
-    if (g_img && (g_img_mask & ((1 << SS_PROF_CONV_DW) | (1 << SS_PROF_CONV_DX))) && am && e->precision == SS_PRECISION_F32 && cb.Co % 8 == 0 && dy.ld % 8 == 0) {
+    const bool i16 = e->img16();
+    if (g_img && (i16 || ((g_img_mask & ((1 << SS_PROF_CONV_DW) | (1 << SS_PROF_CONV_DX))) && am && e->precision == SS_PRECISION_F32)) && cb.Co % 8 == 0 && dy.ld % 8 == 0) {
         float* im = grad_img_of(e, dy.p, R);
         if (im) {
-            HIPCHK(split_image(dy.p, dy.ld, R, cb.Co, am, 0.f, im, dy.ld, e->gscale + cb.amax_i, s));
+            HIPCHK(split_image(dy.p, dy.ld, R, cb.Co, am, 0.f, im, dy.ld, e->gscale + cb.amax_i, s, i16));
             dimg = im;
-            dsc = e->gscale + cb.amax_i;
+            dsc = i16 ? nullptr : e->gscale + cb.amax_i;
         }
     }
     // weight gradient: one reduction over every slab row (halo rows of dy are zero); cb.gp was zeroed by zero_conv_grads
     GemmDesc d{};
     d.A = {dy.p + 2 * dy.ld, dy.ld, 0, 0, 0};
     if (dimg) {
-        d.a_pre = dimg + 2 * dy.ld;
+        d.a_pre = e->ioff(dimg, 2 * dy.ld);
         d.a_pre_scale = dsc;
     }
     d.B = {x.p, x.ld, 0, cb.Cp, x.ld};
@@ -1145,7 +1165,7 @@ int lstm_prep(ss_engine* e, LstmBlk& lb, PrepTable& tb, hipStream_t s) {
             const long n = 4L * H * lb.in_of(l);
             if (tb.n + 2 > PREP_MAX) return fail("lstm_prep: task table full");
             tb.t[tb.n++] = {e->P + pd.bih, e->P + pd.bhh, lb.bsum + ((long)l * 2 + dir) * 4 * H, 4L * H};       // summed biases
-            tb.t[tb.n++] = {e->P + pd.wih, nullptr, lb.wcat[l] + dir * n, n, (lb.wcat_img[l] && lb.in_of(l) % 8 == 0) ? lb.wcat_img[l] + dir * n : nullptr};      // stacked W_ih (+ image: rows of whole groups of eight)
+            tb.t[tb.n++] = {e->P + pd.wih, nullptr, lb.wcat[l] + dir * n, n, (lb.wcat_img[l] && lb.in_of(l) % 8 == 0) ? e->ioff(lb.wcat_img[l], dir * n) : nullptr};      // stacked W_ih (+ image: rows of whole groups of eight)
         }
         // fragment-major W_hh for the one-launch-per-step schedule (the persistent kernels read the parameters directly)
         if (lb.big() && !persist) HIPCHK(lstm_pack_w(e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.wfrag[l], H, 0, s));
@@ -1165,7 +1185,7 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
     if (persist) ch[0] = {0, B, s};
     if (nch == 2) CHK(fork_join(e, s, ch[1].st));
     // only fp16 x 2 GEMMs read the hidden states' pre-split images, and only the persistent recurrences write them
-    lb.out_img_valid = persist && (g_presplit & 2) && e->precision == SS_PRECISION_F32 && g_fwd_f16x2 && !lb.out_img.empty() && lb.out_img[0];
+    lb.out_img_valid = persist && (g_presplit & 2) && ((e->precision == SS_PRECISION_F32 && g_fwd_f16x2) || e->img16()) && !lb.out_img.empty() && lb.out_img[0];
     for (int l = 0; l < lb.L; ++l) {
         const int In = lb.in_of(l);
         Slab xi = l == 0 ? x : Slab{lb.out[l - 1], 2L * H};
@@ -1189,7 +1209,7 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
             } else {   // both directions in one GEMM against the stacked W_ih / summed biases of lstm_prep (N = 8H)
                 GemmDesc d{};
                 d.A = {xi.p + (r0 + HALO) * xi.ld, xi.ld, TP * xi.ld, 0, 0};
-                if (l > 0 && lb.out_img_valid) d.a_pre = lb.out_img[l - 1] + (r0 + HALO) * xi.ld;       // written by the layer below's recurrence
+                if (l > 0 && lb.out_img_valid) d.a_pre = e->ioff(lb.out_img[l - 1], (r0 + HALO) * xi.ld);       // written by the layer below's recurrence
                 d.B = {lb.wcat[l], In, 0, 0, 0};
                 d.b_pre = (g_presplit & 1) ? lb.wimg(l) : nullptr;
                 d.C = lb.gates[l] + (r0 + HALO) * 8L * H;
@@ -1219,7 +1239,7 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
             const int pi = prof_begin(e, SS_PROF_REC_FWD, s, 2.0 * 2 * B * T * 4.0 * H * H);
             HIPCHK(lstm_seq_fwd(lb.gates[l], e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.hf_l(l), lb.out[l], lb.csave[l],
                                 lb.sync_f(l), e->sticky, compact ? lb.xp0 : nullptr, compact ? lb.xf : 0, lb.out_img_valid ? lb.out_img[l] : nullptr, B, T, H,
-                                false, false, s));
+                                false, false, s, (e->img16() ? 1 : 0) | (e->img16() && g_seq_hi ? 2 : 0)));
             prof_end(e, pi, s);
             if (pw) CHK(fork_join(e, e->side3, s));
             continue;
@@ -1338,7 +1358,10 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
     // the decoder's pre-activation gradients as an image for the image GEMM (scale: the power of two for the maximum the recurrence measured)
     const float* dimg = nullptr;
     const float* dsc = nullptr;
-    if (g_img && ((g_img_mask >> SS_PROF_DEC_DW) & 1) && am && &lb == &e->ld && l < 3 && e->dg_img[l] && e->precision == SS_PRECISION_F32 && img_ok) {
+    const bool i16 = e->img16();
+    if (i16) {
+        if (g_img && &lb == &e->ld && l < 3 && ((e->dg16_written >> l) & 1) && img_ok) dimg = e->dg_img[l];      // written by the backward recurrence's storing wave
+    } else if (g_img && ((g_img_mask >> SS_PROF_DEC_DW) & 1) && am && &lb == &e->ld && l < 3 && e->dg_img[l] && e->precision == SS_PRECISION_F32 && img_ok) {
         HIPCHK(split_image(dG, 8L * H, R, 8 * H, am, 0.f, e->dg_img[l], 8L * H, e->gscale + lb.amax0 + l, ws));
         dimg = e->dg_img[l];
         dsc = e->gscale + lb.amax0 + l;
@@ -1347,7 +1370,7 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
     // dW_hh: h_prev is `out` one row earlier (forward) / later (reverse), so the forward direction reads dG one row later instead.
     // (With the image GEMM the decoder's launches are batched as well: 64 + 32 tile jobs per layer instead of 4 x (32 or 16) halve the
     // split-K factor, i.e. the partial-slab traffic and the number of reduce passes.)
-    const bool img_batch = dimg && g_img_batch && ((g_img_mask >> SS_PROF_DEC_DW) & 1);
+    const bool img_batch = dimg && g_img_batch && (i16 ? ((g_bf16_img_mask >> SS_PROF_DEC_DW) & 1) != 0 : ((g_img_mask >> SS_PROF_DEC_DW) & 1) != 0);
     if ((!compact || img_batch) && (g_batch_dirs == 2 || (g_batch_dirs == 1 && !lb.big()) || img_batch) && p1.wih - p0.wih == p1.whh - p0.whh && p1.wih > p0.wih) {
         const long pstride = p1.wih - p0.wih;
         GemmDesc a{};
@@ -1373,7 +1396,7 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
         h.A = {dG + 8L * H, 8L * H, 4L * H - 8L * H, 0, 0};                    // forward: rows 1 .., reverse: rows 0 .. of its own columns
         h.B = {lb.out[l], 2L * H, 2L * H + H, 0, 0};                           // forward: rows 0 .. of h_f, reverse: rows 1 .. of h_b
         if (dimg) {
-            h.a_pre = dimg + 8L * H;
+            h.a_pre = e->ioff(dimg, 8L * H);
             h.a_pre_scale = dsc;
             h.b_pre = lb.out_img[l];
         }
@@ -1425,7 +1448,7 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
         GemmDesc a{};
         a.A = {compact ? lb.dgs + dir * 4L * H : dGd, 8L * H, 0, 0, 0};
         if (dimg && !compact) {
-            a.a_pre = dimg + (a.A.p - dG);
+            a.a_pre = e->ioff(dimg, a.A.p - dG);
             a.a_pre_scale = dsc;
         }
         a.B = {xi.p, xi.ld, 0, 0, 0};
@@ -1444,11 +1467,11 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
         GemmDesc h{};
         h.A = {dir == 0 ? dGd + 8L * H : dGd, 8L * H, 0, 0, 0};
         if (dimg) {
-            h.a_pre = dimg + (h.A.p - dG);
+            h.a_pre = e->ioff(dimg, h.A.p - dG);
             h.a_pre_scale = dsc;
         }
         h.B = {dir == 0 ? lb.out[l] : lb.out[l] + 2L * H + H, 2L * H, 0, 0, 0};
-        if (img_ok) h.b_pre = dir == 0 ? lb.out_img[l] : lb.out_img[l] + 2L * H + H;
+        if (img_ok) h.b_pre = dir == 0 ? lb.out_img[l] : e->ioff(lb.out_img[l], 2L * H + H);
         h.C = e->G + pd.whh;
         h.ldc = H;
         h.M = 4 * H;
@@ -1509,7 +1532,9 @@ int lstm_input_grad(ss_engine* e, LstmBlk& lb, int l, Slab dxi, long r0, long nr
     g.B = {lb.wcat[l], In, 0, 0, 0};
     // (round 2's kernel measured SLOWER with the weight image in format v2 on this transposing-read operand -- 573 us per step with it, 532
     // without -- so it only gets that image when asked to, presplit bit 3)
-    g.b_pre = ((g_presplit & 8) && (g_presplit & 1)) ? lb.wimg(l) : nullptr;
+    g.b_pre = (((g_presplit & 8) || e->img16()) && (g_presplit & 1)) ? lb.wimg(l) : nullptr;
+    const bool dg16 = e->img16() && &lb == &e->ld && l < 3 && ((e->dg16_written >> l) & 1);      // the gradient slab's bf16 image (backward recurrence's storing wave)
+    if (dg16) g.a_pre = e->ioff(e->dg_img[l], r0 * 8L * H);
     g.C = dxi.p + r0 * dxi.ld;
     g.ldc = dxi.ld;
     g.M = (int)nr;
@@ -1528,6 +1553,7 @@ int lstm_input_grad(ss_engine* e, LstmBlk& lb, int l, Slab dxi, long r0, long nr
         // whole utterances: leave the halo rows out (nobody reads them in a gradient slab) -- one batch entry per
         // utterance, T rows each (T a multiple of 64), which at T = 128 also makes the 128 x 128 tiling come out at exactly 2 workgroups per CU for B = 64
         g.A = {lb.gates[l] + (r0 + HALO) * 8L * H, 8L * H, TPr * 8L * H, 0, 0};
+        if (dg16) g.a_pre = e->ioff(e->dg_img[l], (r0 + HALO) * 8L * H);
         g.C = dxi.p + (r0 + HALO) * dxi.ld;
         g.cstride = TPr * dxi.ld;
         g.M = T;
@@ -1584,11 +1610,13 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
                     CHK(fork_join(e, s, e->side3));
                     HIPCHK(slab_prewarm(dG, 8 * H, lb.csave[l], dcur, 2 * H, e->amax, B, T, false, e->side3));
                 }
+                const bool dg16 = e->img16() && g_img && &lb == &e->ld && l < 3 && e->dg_img[l] && nch == 1;
                 const int pi = prof_begin(e, SS_PROF_REC_BWD, s, 2.0 * 2 * B * T * 4.0 * H * H);
                 HIPCHK(lstm_seq_bwd(dG, e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.px_l(l), dcur, lb.csave[l], lb.sync_b(l),
                                     e->sticky, am, bias_in_kernel ? e->G + lb.pd[l * 2].bih : nullptr,
                                     bias_in_kernel ? e->G + lb.pd[l * 2 + 1].bih : nullptr, (l == 0 && lb.xf && dx.p == lb.d_xc) ? lb.dgs : nullptr,
-                                    (l == 0 && lb.xf && dx.p == lb.d_xc) ? lb.xf : 0, B, T, H, false, false, s));
+                                    (l == 0 && lb.xf && dx.p == lb.d_xc) ? lb.xf : 0, B, T, H, false, false, s, dg16 ? e->dg_img[l] : nullptr, e->img16() && g_seq_hi));
+                if (dg16) e->dg16_written |= 1 << l;
                 prof_end(e, pi, s);
                 if (pw) CHK(fork_join(e, e->side3, s));
                 // XCD-aware weight gradients: this recurrence leaves XCDs free, the layer above is through -- its W_ih gradient runs beside it
@@ -1730,7 +1758,7 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
     // on the branch stream and the two stacks run as independent chains on `s` and `b1` -- conv, GroupNorm, gather of their OWN columns --
     // down to their BLSTMs, instead of meeting before every gather.
     const bool indep = g3 && par && g_conv_par && g_trunk_indep && !g_graph;
-    e->xf_img_valid = indep && training && (g_presplit & 4) && e->xf_img[0] && e->precision == SS_PRECISION_F32 && g_fwd_f16x2;     // only fp16 x 2 GEMMs read images
+    e->xf_img_valid = indep && training && (g_presplit & 4) && e->xf_img[0] && ((e->precision == SS_PRECISION_F32 && g_fwd_f16x2) || (e->img16() && g_gn_gather));     // only fp16 x 2 / 16-bit-path GEMMs read images
     hipEvent_t plans = nullptr;
     if (indep && training) {
         for (int i = 0; i < 3; ++i)
@@ -1760,6 +1788,7 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
     auto branch_work = [&]() -> int {
         PrepTable tb;
         tb.n = 0;
+        tb.img_bf16 = e->img16();
         if (g3) CHK(lstm_prep(e, e->l1, tb, b2));
         CHK(lstm_prep(e, e->l2, tb, b2));
         CHK(lstm_prep(e, e->lt, tb, b2));
@@ -1800,11 +1829,11 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
         if (indep) {
             const float* im = (e->xf_img_valid && i > 0) ? e->xf_img[i - 1] : nullptr;
             Slab x1 = i == 0 ? Slab{e->in_mel, e->hp.dim_freq} : Slab{e->xf[i - 1], CE, im, e->act_scale + e->c1[i - 1].scale_i};
-            Slab x2 = i == 0 ? Slab{e->in_f0, e->f0p} : Slab{e->xf[i - 1] + off2, CE, im ? im + off2 : nullptr, e->act_scale + e->c2[i - 1].scale_i};
+            Slab x2 = i == 0 ? Slab{e->in_f0, e->f0p} : Slab{e->xf[i - 1] + off2, CE, im ? e->ioff(im, off2) : nullptr, e->act_scale + e->c2[i - 1].scale_i};
             if (training && g_gn_gather) {       // conv -> [GroupNorm + ReLU + gather] per stack: the normalised slab is never written
                 InterpPlan& pl = e->plan[draw0 + i];
-                float* gi = (e->xf_img_valid && e->xf_img[i]) ? e->xf_img[i] + HALO * CE : nullptr;
-                CHK(conv_block_fwd(e, e->c2[i], x2, Slab{y + off2, CE}, b1, &pl, e->xf[i] + HALO * CE + off2, CE, gi ? gi + off2 : nullptr, i == 0 ? plans : nullptr));
+                float* gi = (e->xf_img_valid && e->xf_img[i]) ? e->ioff(e->xf_img[i], HALO * CE) : nullptr;
+                CHK(conv_block_fwd(e, e->c2[i], x2, Slab{y + off2, CE}, b1, &pl, e->xf[i] + HALO * CE + off2, CE, gi ? e->ioff(gi, off2) : nullptr, i == 0 ? plans : nullptr));
                 CHK(conv_block_fwd(e, e->c1[i], x1, Slab{y, CE}, s, &pl, e->xf[i] + HALO * CE, CE, gi, i == 0 ? plans : nullptr));
                 continue;
             }
@@ -1816,7 +1845,7 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
                     HIPCHK(hipStreamWaitEvent(b1, plans, 0));
                     HIPCHK(hipStreamWaitEvent(s, plans, 0));
                 }
-                float* gi = (e->xf_img_valid && e->xf_img[i]) ? e->xf_img[i] + HALO * CE : nullptr;
+                float* gi = (e->xf_img_valid && !e->img16() && e->xf_img[i]) ? e->xf_img[i] + HALO * CE : nullptr;      // (the separate gather writes format-v2 images only)
                 HIPCHK(interp_gather(pl, e->act + HALO * CE + off2, CE, TP * CE, e->xf[i] + HALO * CE + off2, CE, TP * CE, CE - off2, B, b1,
                                      gi ? gi + off2 : nullptr, e->act_scale + e->c2[i].scale_i));
                 HIPCHK(interp_gather(pl, e->act + HALO * CE, CE, TP * CE, e->xf[i] + HALO * CE, CE, TP * CE, off2, B, s, gi, e->act_scale + e->c1[i].scale_i));
@@ -1885,7 +1914,7 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
     GemmDesc d{};
     d.A = {e->ld.out[e->ld.L - 1] + HALO * HD, HD, TP * HD, 0, 0};
     if (e->ld.out_img_valid)
-        d.a_pre = e->ld.out_img[e->ld.L - 1] + HALO * HD;
+        d.a_pre = e->ioff(e->ld.out_img[e->ld.L - 1], HALO * HD);
     d.B = {e->P + e->head_w, HD, 0, 0, 0};
     d.C = e->out_slab + HALO * e->head_out;
     d.ldc = e->head_out;
@@ -1951,6 +1980,7 @@ int backward_decoder(ss_engine* e, hipStream_t s, bool late = false) {
     hipStream_t b2 = par ? e->side2 : s;
     if (par) CHK(fork_join(e, s, b2));
     e->dec_ih_done = 0;
+    e->dg16_written = 0;
     e->wq_next = 0;
     if (e->ld.big() && !prezeroed) {
         if (g_persist && lstm_seq_supported(e->curB, e->ld.H)) {
@@ -2104,7 +2134,7 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
             Slab x1 = i == 0 ? Slab{e->in_mel, h.dim_freq} : Slab{e->xf[i - 1], CE, bim, e->act_scale + e->c1[i - 1].scale_i};
             CHK(conv_block_bwd(e, e->c1[i], Slab{dy, CE}, x1, i > 0 ? Slab{dxbuf, CE} : Slab{nullptr, 0}, s, sc, sc_src, CE));
         }
-        Slab x2 = i == 0 ? Slab{e->in_f0, e->f0p} : Slab{e->xf[i - 1] + off2, CE, bim ? bim + off2 : nullptr, e->act_scale + e->c2[i - 1].scale_i};
+        Slab x2 = i == 0 ? Slab{e->in_f0, e->f0p} : Slab{e->xf[i - 1] + off2, CE, bim ? e->ioff(bim, off2) : nullptr, e->act_scale + e->c2[i - 1].scale_i};
         // Layer 0 is the step's tail: the decoder's weight gradients are through by then, and each of its two weight-gradient GEMMs alone
         // fills half the chip's workgroup slots -- the pitch block runs on the second branch stream beside the content block.  (Not under
         // data parallelism, where that stream carries the collectives.)
@@ -2428,6 +2458,7 @@ int ss_g3_rhythm(ss_engine* e, const float* x_org, int B, int T, float* codes, v
     CHK(conv_pack_all(e, e->ct, s));
     PrepTable tb;
     tb.n = 0;
+    tb.img_bf16 = e->img16();
     CHK(lstm_prep(e, e->lt, tb, s));
     HIPCHK(prep_run(tb, s));
     CHK(act_scales_all(e, s));
@@ -2730,9 +2761,10 @@ int ss_op_gemm_img(const float* a_img, long lda, const float* b_img, long ldb, f
     d.batch = 1;
     d.ksplit = ksplit < 1 ? 1 : ksplit;
     d.flags = (flags & 1 ? GEMM_TA : 0) | (flags & 2 ? GEMM_TB : 0) | (flags & 4 ? GEMM_ACCUM : 0);
+    d.bf16 = (flags & 8) ? 1 : 0;           // single-piece form: the operands are plain bf16 matrices, ld in elements
     d.part = part;
-    d.scale_a = sc;
-    d.scale_b = sc + 1;
+    d.scale_a = d.bf16 ? nullptr : sc;
+    d.scale_b = d.bf16 ? nullptr : sc + 1;
     d.zeros = zeros;
     d.cfg = cfg;
     d.diag = g_gemm_diag;
@@ -2849,6 +2881,9 @@ int ss_tune(const char* key, int value) {
     else if (k == "batch_dirs" && value >= 0 && value <= 2) g_batch_dirs = value;
     else if (k == "compact0" && (value == 0 || value == 1)) g_compact0 = value;
     else if (k == "presplit" && value >= 0 && value <= 15) g_presplit = value;
+    else if (k == "bf16_img" && (value == 0 || value == 1)) g_bf16_img = value;
+    else if (k == "bf16_img_mask") g_bf16_img_mask = value;
+    else if (k == "seq_hi" && (value == 0 || value == 1)) g_seq_hi = value;
     else if (k == "img" && (value == 0 || value == 1)) g_img = value;
     else if (k == "img_mask" && value >= 0 && value < 2048) g_img_mask = value;
     else if (k == "img_batch" && (value == 0 || value == 1)) g_img_batch = value;

@@ -465,7 +465,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // fp32 [rows][cols] (row stride ld) -> image of the same geometry (row stride ldi, cols % 8 == 0): per 8 values 16 B of hi pieces, 16 B of
 // lo pieces, of scale * value; the scale used is written to *scale_out (the GEMM's epilogue reads it back)
 __global__ __launch_bounds__(256) void split_image_kernel(const float* __restrict__ src, long ld, long rows, int cols, const float* __restrict__ amax,
-                                                          float fixed_scale, float* __restrict__ img, long ldi, float* __restrict__ scale_out) {
+                                                          float fixed_scale, float* __restrict__ img, long ldi, float* __restrict__ scale_out, int bf16) {
+    if (bf16) {             // the plain bf16 tensor (round to nearest even), no scale
+        const int c8 = cols >> 3;
+        const long n8 = rows * c8;
+        for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+            const long r = i / c8;
+            const int c = (int)(i - r * c8) * 8;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + r * ld + c), v1 = *reinterpret_cast<const f32x4*>(src + r * ld + c + 4);
+            const uint2 a = ss_pack_bf16x4(v0[0], v0[1], v0[2], v0[3]), b = ss_pack_bf16x4(v1[0], v1[1], v1[2], v1[3]);
+            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(img) + 2 * (r * ldi + c)) = uint4{a.x, a.y, b.x, b.y};
+        }
+        return;
+    }
     const float s = amax ? pow2_scale_of(*amax) : fixed_scale;
     if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = s;
     const int c8 = cols >> 3;
@@ -582,13 +594,13 @@ hipError_t splitk_reduce(const float* part, int ksplit, int M, int N, int batch,
 }
 
 hipError_t split_image(const float* src, long ld, long rows, int cols, const float* amax, float fixed_scale, float* img, long ldi, float* scale_out,
-                       hipStream_t s) {
-    if (cols % 8 || ld % 4 || ldi % 8 || (((size_t)src) & 15) || (((size_t)img) & 31)) return hipErrorInvalidValue;
+                       hipStream_t s, int bf16) {
+    if (cols % 8 || ld % 4 || ldi % 8 || (((size_t)src) & 15) || (((size_t)img) & (bf16 ? 15 : 31))) return hipErrorInvalidValue;
     const long n8 = rows * (cols >> 3);
     int g = cdiv(n8, 256);
     if (g > 8192) g = 8192;
     if (g < 1) return hipSuccess;
-    hipLaunchKernelGGL(split_image_kernel, dim3(g), dim3(256), 0, s, src, ld, rows, cols, amax, fixed_scale, img, ldi, scale_out);
+    hipLaunchKernelGGL(split_image_kernel, dim3(g), dim3(256), 0, s, src, ld, rows, cols, amax, fixed_scale, img, ldi, scale_out, bf16);
     return hipGetLastError();
 }
 

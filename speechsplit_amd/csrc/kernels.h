@@ -40,8 +40,9 @@ hipError_t gn_relu_fwd(const float* x, long x_ld, long x_bs, float* y, long y_ld
                        const float* beta, float* stats /*[B, C/16, 2] mean, rstd*/, int B, int T, int C, hipStream_t s);
 // the same followed by the training forward's random resampling of the block output (interp_gather), in one pass: y / y_img are the
 // resampled slab and its image AT the first real row and the block's first column (p.P output rows); bit-identical to the two kernels
+// img_bf16: y_img is the plain bf16 tensor (element offsets, 2 bytes each) instead of a format-v2 image (common.h ss_store_img4)
 hipError_t gn_relu_gather(const float* x, long x_ld, long x_bs, float* y, long y_ld, long y_bs, float* y_img, const float* img_scale,
-                          const float* gamma, const float* beta, float* stats, const InterpPlan& p, int B, int T, int C, hipStream_t s);
+                          const float* gamma, const float* beta, float* stats, const InterpPlan& p, int B, int T, int C, hipStream_t s, int img_bf16 = 0);
 // dy (grad of the ReLU output) is replaced in place by the grad of the GroupNorm input (= conv output).
 // g_gamma / g_beta / g_bias [C]: every utterance's d_gamma, d_beta, d_convbias are ACCUMULATED here (f32 atomics).
 // amax (nullable): receives max |conv-output gradient| written, as for lstm_seq_bwd.
@@ -69,7 +70,7 @@ hipError_t collate(const float* mel_cat, const float* f0_cat, const float* emb_t
                    const int* item, int B, int T, int C, int E, float* mel, float* f0, float* emb, hipStream_t s);
 // conv weight [Co][Ci][5] -> forward pack [Co][5][Cp] (zero-filled for ci >= Ci) and input-grad pack [Ci][5][Co] (taps flipped)
 // wf_img / wb_img (nullable): pre-split images of wf / wb (Cp % 4 == 0, Co % 4 == 0)
-hipError_t conv_pack(const float* w, int Co, int Ci, int Cp, float* wf, float* wb, float* wf_img, float* wb_img, hipStream_t s);
+hipError_t conv_pack(const float* w, int Co, int Ci, int Cp, float* wf, float* wb, float* wf_img, float* wb_img, hipStream_t s, int img_bf16 = 0);
 // packed weight grad [Co][5][Cp] -> grad arena [Co][Ci][5] (overwrite)
 hipError_t conv_unpack_grad(const float* gp, int Co, int Ci, int Cp, float* g, hipStream_t s);
 constexpr int CONV_UNPACK_MAX = 8;
@@ -98,6 +99,7 @@ struct PrepTask {
 struct PrepTable {
     PrepTask t[PREP_MAX];
     int n;
+    int img_bf16;         // the tasks' images are plain bf16 tensors instead of format v2
 };
 hipError_t prep_run(const PrepTable& tb, hipStream_t s);
 
@@ -198,14 +200,14 @@ long lstm_seq_xbytes(int B, int H, bool backward);
 // sticky (nullable): engine-wide word, host-visible, that a launch ORs 1 into when its bounded wait expires (never cleared by a step)
 hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, float* out, float* csave,
                         unsigned* sync, unsigned* sticky, const float* xc, int xf, float* out_img, int B, int T, int H, bool zero_state,
-                        bool time_major, hipStream_t s);
+                        bool time_major, hipStream_t s, int img_bf16 = 0);       // img_bf16 bit 0: out_img is the plain bf16 tensor, not a format-v2 image; bit 1: products from the high fp16 pieces alone
 // amax (nullable): device word that receives max |pre-activation gradient| written (atomic max of the float's bit pattern;
 // zero it first) -- the scale the fp16 x 2 GEMMs that consume the gradient slab need
 // gbias_f / gbias_b (nullable): [2][4H] gradient accumulators of (b_ih, b_hh) of the forward / reverse direction; the kernel
 // adds the sum over utterances and time of the pre-activation gradients to both halves (f32 atomics)
 hipError_t lstm_seq_bwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, const float* d_out,
                         const float* csave, unsigned* sync, unsigned* sticky, float* amax, float* gbias_f, float* gbias_b, float* dgs, int xf,
-                        int B, int T, int H, bool zero_state, bool time_major, hipStream_t s);
+                        int B, int T, int H, bool zero_state, bool time_major, hipStream_t s, float* dimg = nullptr, int hi = 0);      // dimg: the gradients also as a plain bf16 tensor (slab geometry); hi: products from the high fp16 pieces alone
 
 // seq_gate: the stream goes on once the persistent recurrence that owns `sync` is resident (all groups through round 0), see lstm_seq.hip;
 // lstm_seq_free_xcds: how many of the 8 XCDs such a launch leaves free (0: none, or not a persistent shape)

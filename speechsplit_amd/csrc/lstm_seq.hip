@@ -215,6 +215,13 @@ __device__ __forceinline__ void mfma3_each(const f16x8 (&a)[2], BF&& b, f32x4 (&
 #pragma unroll
     for (int i = 0; i < N; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b(i, 0), acc[i], 0, 0, 0);     // h.h
 }
+// 16-bit data path (SS_PRECISION_BF16, round 4): the recurrent product from the HIGH fp16 pieces alone -- one MFMA instead of three, half
+// the weight registers, half the forward's payload (11 significand bits per operand, fp32 accumulation and state as before)
+template <int N, typename BF>
+__device__ __forceinline__ void mfma1_each(const f16x8& a, BF&& b, f32x4 (&acc)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b(i), acc[i], 0, 0, 0);
+}
 __device__ __forceinline__ void load2x2_sc1(const unsigned char* p0, const unsigned char* p1, u32x4 (&r)[2][2]) {
     asm volatile(
         "global_load_dwordx4 %0, %4, off sc1\n\t"
@@ -324,8 +331,22 @@ __device__ __forceinline__ void store16_plain(unsigned char* p, f32x4 v) {      
 // The eight lanes that hold k % 8 = 0 .. 7 of one utterance row (consecutive lanes of one wave) gather their pieces in three
 // exchange rounds, and the first of them stores whole 16-byte fragment slots: a workgroup's h lands as 512 contiguous bytes per
 // plane in 2 x 32 lane-stores instead of 2 x 128 four-byte ones (measured neutral on the step time; four times fewer store transactions).
+template <bool HI = false>
 __device__ __forceinline__ void xb_store(unsigned char* xb_plane0, long plane_stride, int k, int bi, float v, bool local, int tag = -1) {
     unsigned h, l;
+    if constexpr (HI) {                                // high pieces only: one plane, the tag in the even element's last bit
+        h = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)(v * HSCALE));
+        if (tag >= 0 && (k & 1) == 0) h = (h & ~1u) | (unsigned)tag;
+        const unsigned h0 = h | ((unsigned)__shfl_xor((int)h, 1) << 16);
+        const unsigned h1 = (unsigned)__shfl_xor((int)h0, 2);
+        const u32x4 hq = {h0, h1, (unsigned)__shfl_xor((int)h0, 4), (unsigned)__shfl_xor((int)h1, 4)};
+        if ((k & 7) == 0) {
+            unsigned char* q = xb_plane0 + (long)(k >> 5) * 1024 + ((((k & 31) >> 3) * 16 + bi) << 4);
+            if (local) store16_plain(q, __builtin_bit_cast(f32x4, hq));
+            else store16_sc1(q, __builtin_bit_cast(f32x4, hq));
+        }
+        return;
+    }
     if (tag >= 0 && (k & 1) == 0) {
         const float y = v * HSCALE;
         h = ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)y) & ~1u) | (unsigned)tag;
@@ -350,7 +371,7 @@ __device__ __forceinline__ void xb_store(unsigned char* xb_plane0, long plane_st
 
 // grid = ngroups * (H/16), block = 64*NW.   sync (LSTM_SEQ_SYNC_WORDS, all zero on entry, like xb): [0] abort word,
 // [1 + group] XCD masks, [64 + 32 * group + member] completion flags
-template <int H, int NW, bool TAG>
+template <int H, int NW, bool TAG, bool HI>
 __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_fwd_kernel(float* __restrict__ gates, const float* __restrict__ whh_f,
                                                                const float* __restrict__ whh_b, unsigned char* __restrict__ xb,
                                                                float* __restrict__ out, float* __restrict__ csave,
@@ -468,7 +489,7 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_fwd_kernel(float* __re
                     float* dst = o < 4 ? gates + r * (8 * H) + dir * 4 * H + o * H + jt * 16 + 4 * q
                                        : (o == 4 ? csave : out) + r * (2 * H) + dir * H + jt * 16 + 4 * q;
                     *reinterpret_cast<f32x4*>(dst) = v;
-                    if (o == 5 && out_img) ss_store_group(out_img + r * (2 * H) + dir * H + jt * 16 + 4 * q, ss_split_group(v[0], v[1], v[2], v[3]));
+                    if (o == 5 && out_img) ss_store_img4(out_img, r * (2 * H) + dir * H + jt * 16 + 4 * q, v[0], v[1], v[2], v[3], 16.0f, (int)((unsigned)prio >> 31));      // (prio bit 31: plain bf16 image)
                 }
             };
             for (int st = 0; st < T; ++st) {
@@ -483,7 +504,7 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_fwd_kernel(float* __re
 
     // this wave's slice of W_hh as fp16 pieces, resident in registers for the whole sequence:
     // B fragment of gate g, k-step ks: lane holds W_hh[g*H + jt*16 + li][(w*KS + ks)*32 + 8*lq .. +7]
-    f16x8 bw[4][KS][2];
+    f16x8 bw[4][KS][HI ? 1 : 2];
     {
         const float* W = dir == 0 ? whh_f : whh_b;
 #pragma unroll
@@ -493,7 +514,10 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_fwd_kernel(float* __re
                 const float* src = W + (long)(g * H + jt * 16 + li) * H + (w * KS + ks) * 32 + 8 * lq;
                 const f32x4 v0 = ld4(src), v1 = ld4(src + 4);
                 const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                split8_f16(x, WSCALE, bw[g][ks][0], bw[g][ks][1]);
+                if constexpr (HI) {
+                    f16x8 lo_unused;
+                    split8_f16(x, WSCALE, bw[g][ks][0], lo_unused);
+                } else split8_f16(x, WSCALE, bw[g][ks][0], bw[g][ks][1]);
             }
     }
 
@@ -527,6 +551,25 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_fwd_kernel(float* __re
             if (diag & 1) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) r[ks][0] = r[ks][1] = u32x4{0u, 0u, 0u, 0u};
+            } else if constexpr (HI) {
+                // high pieces only: this wave's two fragments of plane 0 (1 KiB apart)
+                u32x4 r1[2];
+                if constexpr (TAG) {
+                    const unsigned tg = tag_of(st);
+                    for (unsigned spins = 0;; ++spins) {
+                        load2_sc1(p0, r1);
+                        unsigned bad = 0;
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) bad |= (r1[ks][0] ^ tg) | (r1[ks][1] ^ tg) | (r1[ks][2] ^ tg) | (r1[ks][3] ^ tg);
+                        if (__all(!(bad & 1u)) || (diag & 16) != 0) break;
+                        if (!poll_continue(spins, abortp)) {
+                            if (lane == 0) s_ok = 0;
+                            break;
+                        }
+                    }
+                } else load2_sc1(p0, r1);
+                r[0][0] = r1[0];
+                r[1][0] = r1[1];
             } else if constexpr (TAG) {
                 // every wave polls its own four fragments (64 hidden units = four producers) until all dwords carry this step's tag
                 const unsigned tg = tag_of(st);
@@ -544,6 +587,10 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_fwd_kernel(float* __re
                     }
                 }
             } else load2x2_sc1(p0, p1, r);
+            if constexpr (HI) {
+                mfma1_each<4>(__builtin_bit_cast(f16x8, r[0][0]), [&](int g) -> const f16x8& { return bw[g][0][0]; }, acc);
+                mfma1_each<4>(__builtin_bit_cast(f16x8, r[1][0]), [&](int g) -> const f16x8& { return bw[g][1][0]; }, acc);
+            } else {
             {
                 const f16x8 a[2] = {__builtin_bit_cast(f16x8, r[0][0]), __builtin_bit_cast(f16x8, r[0][1])};
                 mfma3_each<4>(a, [&](int g, int pc) -> const f16x8& { return bw[g][0][pc]; }, acc);
@@ -551,6 +598,7 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_fwd_kernel(float* __re
             {
                 const f16x8 a[2] = {__builtin_bit_cast(f16x8, r[1][0]), __builtin_bit_cast(f16x8, r[1][1])};
                 mfma3_each<4>(a, [&](int g, int pc) -> const f16x8& { return bw[g][1][pc]; }, acc);
+            }
             }
         }
         auto& rd = red[TAG ? (st & 1) : 0];
@@ -572,7 +620,7 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_fwd_kernel(float* __re
             c_state = gf * c_state + gi * gg;
             h_val = go * ss_tanh(c_state);
             // the hand-off payload: write-through, first (rows past B carry garbage nobody stores downstream)
-            if (!(diag & 2)) xb_store(xwr + ((st + 1) & 1) * half, plane, j, bi, h_val, local, TAG ? (int)tag_of(st + 1) : -1);
+            if (!(diag & 2)) xb_store<HI>(xwr + ((st + 1) & 1) * half, plane, j, bi, h_val, local, TAG ? (int)tag_of(st + 1) : -1);
             float(*sb)[16][16] = st_buf[st & 1];         // slab copies: the storing wave picks them up behind the next barrier
             sb[0][bi][jj] = gi;
             sb[1][bi][jj] = gf;
@@ -601,14 +649,16 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_fwd_kernel(float* __re
 // Tiles are stored write-through (sc1) unless round 0 found the whole group on one XCD (group_locality): then ordinary
 // stores are used, which is what makes this formulation pay (8 MB of sc1 traffic per step costs ~1.8 us of every step).
 // sync: as in the forward kernel.
-template <int H, int NW>
+template <int H, int NW, bool HI>
 __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __restrict__ gates, const float* __restrict__ whh_f,
                                                                const float* __restrict__ whh_b, unsigned char* __restrict__ xb,
                                                                const float* __restrict__ d_out, const float* __restrict__ csave,
                                                                unsigned* __restrict__ sync, unsigned* __restrict__ sticky,
                                                                unsigned* __restrict__ amax, float* __restrict__ gbias_f,
                                                                float* __restrict__ gbias_b, float* __restrict__ dgs, int xf, int B, int T,
-                                                               int nbt, int prio) {
+                                                               int nbt, int prio, float* __restrict__ dimg) {
+    // dimg (nullable; the 16-bit data path): the pre-activation gradients once more as a plain bf16 tensor of the slab's geometry -- the
+    // operand image of the layer's weight- and input-gradient contractions, written here instead of by a separate pass over the slab
     // dgs (nullable): the layer's input repeats in blocks of xf frames (see the forward kernel), so its input / weight gradients only
     // need da SUMMED over each block: the storing wave adds the steps of a block up and writes [B][T / xf][8H] (time order, no atomics)
     constexpr int JT = H / 16, CT = JT / NW, PW = JT / NW;      // column tiles (= consumers) / producers handled per wave
@@ -768,6 +818,7 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
                         const f32x4 v = *reinterpret_cast<const f32x4*>(&da_st[g][u][4 * q]);
                         if (bt * 16 + u >= B) continue;
                         *reinterpret_cast<f32x4*>(gates + row_of(bt * 16 + u, tau) * (8 * H) + dir * 4 * H + g * H + jt * 16 + 4 * q) = v;
+                        if (dimg) ss_store_img4(dimg, row_of(bt * 16 + u, tau) * (8 * H) + dir * 4 * H + g * H + jt * 16 + 4 * q, v[0], v[1], v[2], v[3], 1.0f, 1);
                         if (gbias) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) bsd[i][j] += (double)v[j];
@@ -803,7 +854,7 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
 
     // B fragments, resident for the whole sequence.  Local reduction index k = gate*16 + unit (64 per workgroup): k-step ks,
     // lane (li = column, lq) holds k = 32*ks + 8*lq + e  ->  W_hh[(2*ks + lq/2)*H + jt*16 + 8*(lq%2) + e][(w*CT + ct)*16 + li]
-    f16x8 bw[2][CT][2] = {};
+    f16x8 bw[2][CT][HI ? 1 : 2] = {};
     if (!helper) {
         const float* W = dir == 0 ? whh_f : whh_b;
 #pragma unroll
@@ -814,7 +865,10 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
                 float x[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) x[i] = src[(long)i * H];
-                split8_f16(x, WSCALE, bw[ks][ct][0], bw[ks][ct][1]);
+                if constexpr (HI) {
+                    f16x8 lo_unused;
+                    split8_f16(x, WSCALE, bw[ks][ct][0], lo_unused);
+                } else split8_f16(x, WSCALE, bw[ks][ct][0], bw[ks][ct][1]);
             }
     }
 
@@ -899,7 +953,7 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
                 split1_f16(da[g] * rsc, h, l);
                 const int la = ((g & 1) * 2 + (jj >> 3)) * 16 + bi;
                 a_lds[g >> 1][0][la][jj & 7] = (unsigned short)h;
-                a_lds[g >> 1][1][la][jj & 7] = (unsigned short)l;
+                if constexpr (!HI) a_lds[g >> 1][1][la][jj & 7] = (unsigned short)l;
                 da_st[g][bi][jj] = da[g];              // for the memory wave: slab copy for the weight-gradient GEMMs
             }
         }
@@ -909,7 +963,7 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int pc = 0; pc < 2; ++pc) a[ks][pc] = *reinterpret_cast<const f16x8*>(&a_lds[ks][pc][lane][0]);
+                for (int pc = 0; pc < (HI ? 1 : 2); ++pc) a[ks][pc] = *reinterpret_cast<const f16x8*>(&a_lds[ks][pc][lane][0]);
             const f32x4 us = *reinterpret_cast<const f32x4*>(&row_unscale[lq * 4]);      // accumulator rows 4*lq + r
             unsigned char* q = xwr + ((st + 1) & 1) * half;
             const unsigned tg = tag_of(st + 1);
@@ -918,8 +972,13 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
 #pragma unroll
             for (int c0 = 0; c0 < CT; c0 += 2) {
                 f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-                mfma3_each<2>(a[0], [&](int i, int pc) -> const f16x8& { return bw[0][c0 + i][pc]; }, acc);
-                mfma3_each<2>(a[1], [&](int i, int pc) -> const f16x8& { return bw[1][c0 + i][pc]; }, acc);
+                if constexpr (HI) {
+                    mfma1_each<2>(a[0][0], [&](int i) -> const f16x8& { return bw[0][c0 + i][0]; }, acc);
+                    mfma1_each<2>(a[1][0], [&](int i) -> const f16x8& { return bw[1][c0 + i][0]; }, acc);
+                } else {
+                    mfma3_each<2>(a[0], [&](int i, int pc) -> const f16x8& { return bw[0][c0 + i][pc]; }, acc);
+                    mfma3_each<2>(a[1], [&](int i, int pc) -> const f16x8& { return bw[1][c0 + i][pc]; }, acc);
+                }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     f32x4 v = acc[i] * us;
@@ -993,8 +1052,8 @@ static long resident_limit(int H) {
         int per_cu = 0;
         hipError_t e = hipGetDeviceProperties(&prop, dev);
         if (e == hipSuccess)
-            e = H == 512 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<512, 8>, 640, 0)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<256, 8>, 640, 0);
+            e = H == 512 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<512, 8, false>, 640, 0)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<256, 8, false>, 640, 0);
         c = e == hipSuccess ? (long)prop.multiProcessorCount * per_cu : -1;
         if (c == 0) c = -1;
     }
@@ -1013,11 +1072,14 @@ long lstm_seq_xbytes(int B, int H, bool backward) {
 }
 
 static int seq_slots(int nbt) { return 2 * nbt <= 8 ? 8 : 2 * nbt; }       // group slots per member index (see the kernels)
-static int seq_prio_arg(bool time_major) { return (g_seq_prio & 0xFFFF) | ((g_seq_spin_log2 & 31) << 16) | (time_major ? 1 << 21 : 0) | ((g_seq_wlead & 31) << 22) | ((g_seq_var & 15) << 27); }
+static int seq_prio_arg(bool time_major, bool img_bf16 = false) {
+    return (int)((unsigned)(g_seq_prio & 0xFFFF) | ((unsigned)(g_seq_spin_log2 & 31) << 16) | (time_major ? 1u << 21 : 0u) | ((unsigned)(g_seq_wlead & 31) << 22) |
+                 ((unsigned)(g_seq_var & 15) << 27) | (img_bf16 ? 1u << 31 : 0u));
+}
 
 hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, float* out, float* csave,
                         unsigned* sync, unsigned* sticky, const float* xc, int xf, float* out_img, int B, int T, int H, bool zero_state,
-                        bool time_major, hipStream_t s) {
+                        bool time_major, hipStream_t s, int img_bf16) {
     if (xc && (xf < 1 || T % xf)) return hipErrorInvalidValue;
     const int nbt = (B + 15) / 16;
     if (!lstm_seq_supported(B, H)) return hipErrorInvalidValue;
@@ -1027,21 +1089,24 @@ hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, vo
         if (e != hipSuccess) return e;
     }
     unsigned char* xb = static_cast<unsigned char*>(xbuf);
-    const int pa = seq_prio_arg(time_major);
+    const int pa = seq_prio_arg(time_major, (img_bf16 & 1) != 0);
+    const bool hi = (img_bf16 & 2) != 0;              // 16-bit data path: the recurrent product from the high fp16 pieces alone
     // Measured (tools/kbench.py seqtag, us per step flags -> tagged): groups that sit on one XCD each (B = 64: 8 groups under the
     // round-robin placement) 2.47 -> 2.03; groups that span XCDs, whose polls and write-through payload cross the fabric,
     // 3.10 -> 3.23 (B = 16) and 3.00 -> 3.47 (B = 48).  The backward gains either way (3.13 -> 2.98, 3.40 -> 2.49, 4.13 -> 3.25).
     const bool tag = g_seq_tag && (2 * nbt <= 8 || (2 * nbt) % 8 == 0);      // groups expected on one XCD each (seq_slots)
-    if (H == 512 && tag) hipLaunchKernelGGL((lstm_seq_fwd_kernel<512, 8, true>), dim3(seq_slots(nbt) * 32), dim3(640), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, xc, xf, out_img, B, T, nbt, pa);
-    else if (H == 512)         hipLaunchKernelGGL((lstm_seq_fwd_kernel<512, 8, false>), dim3(seq_slots(nbt) * 32), dim3(640), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, xc, xf, out_img, B, T, nbt, pa);
-    else if (tag)              hipLaunchKernelGGL((lstm_seq_fwd_kernel<256, 4, true>), dim3(seq_slots(nbt) * 16), dim3(384), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, xc, xf, out_img, B, T, nbt, pa);
-    else                       hipLaunchKernelGGL((lstm_seq_fwd_kernel<256, 4, false>), dim3(seq_slots(nbt) * 16), dim3(384), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, xc, xf, out_img, B, T, nbt, pa);
+#define SS_SEQ_FWD(HH, NWW, TG, HI_, GRID, BLK) hipLaunchKernelGGL((lstm_seq_fwd_kernel<HH, NWW, TG, HI_>), dim3(GRID), dim3(BLK), 0, s, gates, whh_f, whh_b, xb, out, csave, sync, sticky, xc, xf, out_img, B, T, nbt, pa)
+    if (H == 512 && tag) { if (hi) SS_SEQ_FWD(512, 8, true, true, seq_slots(nbt) * 32, 640); else SS_SEQ_FWD(512, 8, true, false, seq_slots(nbt) * 32, 640); }
+    else if (H == 512)   { if (hi) SS_SEQ_FWD(512, 8, false, true, seq_slots(nbt) * 32, 640); else SS_SEQ_FWD(512, 8, false, false, seq_slots(nbt) * 32, 640); }
+    else if (tag)        { if (hi) SS_SEQ_FWD(256, 4, true, true, seq_slots(nbt) * 16, 384); else SS_SEQ_FWD(256, 4, true, false, seq_slots(nbt) * 16, 384); }
+    else                 { if (hi) SS_SEQ_FWD(256, 4, false, true, seq_slots(nbt) * 16, 384); else SS_SEQ_FWD(256, 4, false, false, seq_slots(nbt) * 16, 384); }
+#undef SS_SEQ_FWD
     return hipGetLastError();
 }
 
 hipError_t lstm_seq_bwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, const float* d_out,
                         const float* csave, unsigned* sync, unsigned* sticky, float* amax, float* gbias_f, float* gbias_b, float* dgs, int xf,
-                        int B, int T, int H, bool zero_state, bool time_major, hipStream_t s) {
+                        int B, int T, int H, bool zero_state, bool time_major, hipStream_t s, float* dimg, int hi) {
     if (dgs && (xf < 1 || T % xf)) return hipErrorInvalidValue;
     const int nbt = (B + 15) / 16;
     if (!lstm_seq_supported(B, H)) return hipErrorInvalidValue;
@@ -1054,8 +1119,11 @@ hipError_t lstm_seq_bwd(float* gates, const float* whh_f, const float* whh_b, vo
     unsigned* am = reinterpret_cast<unsigned*>(amax);
     const dim3 grid(seq_slots(nbt) * (H / 16)), block(640);
     const int pa = seq_prio_arg(time_major);
-    if (H == 512) hipLaunchKernelGGL((lstm_seq_bwd_kernel<512, 8>), grid, block, 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, am, gbias_f, gbias_b, dgs, xf, B, T, nbt, pa);
-    else          hipLaunchKernelGGL((lstm_seq_bwd_kernel<256, 8>), grid, block, 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, am, gbias_f, gbias_b, dgs, xf, B, T, nbt, pa);
+    if (hi) {
+        if (H == 512) hipLaunchKernelGGL((lstm_seq_bwd_kernel<512, 8, true>), grid, block, 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, am, gbias_f, gbias_b, dgs, xf, B, T, nbt, pa, dimg);
+        else          hipLaunchKernelGGL((lstm_seq_bwd_kernel<256, 8, true>), grid, block, 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, am, gbias_f, gbias_b, dgs, xf, B, T, nbt, pa, dimg);
+    } else if (H == 512) hipLaunchKernelGGL((lstm_seq_bwd_kernel<512, 8, false>), grid, block, 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, am, gbias_f, gbias_b, dgs, xf, B, T, nbt, pa, dimg);
+    else                 hipLaunchKernelGGL((lstm_seq_bwd_kernel<256, 8, false>), grid, block, 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, am, gbias_f, gbias_b, dgs, xf, B, T, nbt, pa, dimg);
     return hipGetLastError();
 }
 

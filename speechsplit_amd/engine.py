@@ -401,8 +401,11 @@ _ZEROS = {}
 
 def gemm_img(a_img, b_img, ta=False, tb=False, bias=None, ksplit=1, cfg=-1, scale_a=16.0, scale_b=16.0, out=None, accumulate=False, a_seg=(0, 0),
              M=None, K=None, part=None):
-    """Test hook (ss_op_gemm_img): C[M,N] = A(m,k) B(n,k) over operand images.  a_img [M,K] ([K,M] if ta), b_img [N,K] ([K,N] if tb)."""
+    """Test hook (ss_op_gemm_img): C[M,N] = A(m,k) B(n,k) over operand images.  a_img [M,K] ([K,M] if ta), b_img [N,K] ([K,N] if tb).
+    torch.bfloat16 operands select the single-piece form (plain bf16 matrices, no scales)."""
     lib = _capi.lib()
+    bf16 = a_img.dtype == torch.bfloat16
+    assert (b_img.dtype == torch.bfloat16) == bf16
     if M is None:
         M = a_img.shape[1] if ta else a_img.shape[0]
     if K is None:
@@ -414,7 +417,7 @@ def gemm_img(a_img, b_img, ta=False, tb=False, bias=None, ksplit=1, cfg=-1, scal
         part = torch.empty(ksplit * M * N, device=dev)
     z = _ZEROS.setdefault(str(dev), torch.zeros(1024, device=dev))
     _capi.check(lib.ss_op_gemm_img(_ptr(a_img), a_img.stride(0), _ptr(b_img), b_img.stride(0), _ptr(c), c.stride(0), _ptr(bias), M, N, K,
-                                   (1 if ta else 0) | (2 if tb else 0) | (4 if accumulate else 0), int(ksplit), int(cfg), float(scale_a),
+                                   (1 if ta else 0) | (2 if tb else 0) | (4 if accumulate else 0) | (8 if bf16 else 0), int(ksplit), int(cfg), float(scale_a),
                                    float(scale_b), int(a_seg[0]), int(a_seg[1]), _ptr(part), _ptr(z), _stream()))
     return c
 

@@ -826,3 +826,42 @@ def test_image_gemm_conv_windows_and_scales(E):
         c = E.gemm_img(E.split_image(xs, 4.0), E.split_image(w.reshape(Co, 5 * Ci).cuda(), 64.0), cfg=cfg, scale_a=4.0, scale_b=64.0,
                        a_seg=(Ci, Ci), M=rows, K=5 * Ci)
         assert rel(c, ref) < 5e-6, cfg
+
+
+@pytest.mark.parametrize('cfg', [0, 1, 2])
+@pytest.mark.parametrize('layout', [(False, False), (False, True), (True, True), (True, False)])
+def test_image_gemm_bf16_single_piece(E, layout, cfg):
+    """The single-piece form of gemm_img.hip (round 4, the 16-bit data path of SS_PRECISION_BF16): operands are plain bf16 matrices, one
+    v_mfma_f32_32x32x16_bf16 per k16-step, k-tiles of 64.  A bf16 x bf16 product is exact in fp32 and the accumulation is fp32, so against
+    float64 on the SAME bf16 operands the result is fp32-grade -- every layout and tile configuration, ragged M / N, K tails of a
+    reduction-major pair, bias, accumulation, split-K, and the conv window (segmented K) over a haloed slab."""
+    ta, tb = layout
+    g = torch.Generator().manual_seed(23 + cfg)
+    shapes = [(264, 200, 128, 1), (1000, 520, 1024, 1), (512, 512, 4096, 4), (2048, 1024, 2112 if (ta and tb) else 2176, 8)]
+    if ta and tb:
+        shapes += [(512, 264, 1027, 3), (256, 256, 8447, 8), (136, 128, 31, 1)]
+    for M, N, K, ks in shapes:
+        A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+        Bm = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
+        bias = torch.randn(N, generator=g).cuda()
+        c0 = torch.randn(M, N, generator=g).cuda()
+        ref = A.double() @ Bm.double().t() + bias.double() + c0.double()
+        ai = A.t().contiguous() if ta else A
+        bi = Bm.t().contiguous() if tb else Bm
+        c = E.gemm_img(ai, bi, ta, tb, bias, ks, cfg, out=c0.clone(), accumulate=True)
+        assert rel(c, ref) < 5e-6, (M, N, K, ks, layout, cfg)
+        c2 = E.gemm_img(ai, bi, ta, tb, bias, ks, cfg, out=c0.clone(), accumulate=True)
+        assert torch.equal(c, c2)
+    if not ta and not tb:
+        B, T, Ci, Co = 3, 40, 64, 128
+        TP = T + 4
+        x = torch.zeros(B, TP, Ci)
+        x[:, 2:2 + T] = torch.randn(B, T, Ci, generator=g)
+        w = (torch.randn(Co, 5, Ci, generator=g) * 0.05).to(torch.bfloat16)
+        xs = x.reshape(B * TP, Ci).to(torch.bfloat16).cuda()
+        rows = B * TP - 4
+        ref = torch.zeros(rows, Co, dtype=torch.float64)
+        for tap in range(5):
+            ref += xs[tap:tap + rows].double().cpu() @ w[:, tap].double().t()
+        c = E.gemm_img(xs, w.reshape(Co, 5 * Ci).cuda(), cfg=cfg, a_seg=(Ci, Ci), M=rows, K=5 * Ci)
+        assert rel(c, ref) < 5e-6, cfg

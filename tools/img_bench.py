@@ -78,6 +78,18 @@ def main():
         t_sp = timeit(lambda: E.split_image(As))
         line += f' split_image(A) {t_sp:6.1f} us'
         print(line, flush=True)
+        # the single-piece (bf16) form on the same shape: plain bf16 operands, one MFMA per product
+        a16, b16 = As.to(torch.bfloat16), Bs.to(torch.bfloat16)
+        ref16 = (A.to(torch.bfloat16).double() @ B.to(torch.bfloat16).double().t()) if ref is not None else None
+        line = f'  {"  ... bf16 single-piece":28s}:' + ' ' * 41
+        for cfg in (0, 1, 2):
+            ks = kss[cfg]
+            part = torch.empty(ks * M * N, device=dev) if ks > 1 else None
+            c = E.gemm_img(a16, b16, ta, tb, None, ks, cfg, out=out, part=part)
+            err = rel(c, ref16) if ref16 is not None else float('nan')
+            t = timeit(lambda: E.gemm_img(a16, b16, ta, tb, None, ks, cfg, out=out, part=part))
+            line += f' cfg{cfg} ks{ks}: {t:7.1f} us = {fl / t / 1e6:6.1f} TF (err {err:.1e}) |'
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
