@@ -43,7 +43,9 @@ PEAK_16BIT_MFMA_TFLOPS = 2500.0    # dense bf16 / fp16 MFMA peak (MI355X_MICROAR
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 PRODUCTS = {'f32': 'fp32 operands/accumulate/storage; products on the 16-bit matrix pipe from an fp16 x 2 split (3 MFMAs, '
                    '22 significand bits rel. to the operand maximum); head + encoder BLSTMs bf16 x 3 (6 MFMAs, exact to 2^-24)',
-            'bf16': 'operands rounded to bf16 inside the GEMM (1 MFMA), fp32 accumulate/storage/recurrent state'}
+            'bf16': '16-bit data path: weights, hidden states, resampled activations and gradient slabs also stored as bf16 tensors by their producers and '
+                    'contracted from there (1 MFMA per product, fp32 accumulation); persistent recurrences multiply the high fp16 pieces of h and W_hh '
+                    '(1 MFMA); cell state, GroupNorm statistics, master weights and Adam fp32; small / unaligned contractions round fp32 operands inside the GEMM'}
 
 
 def synth(B, T, seed, device):
@@ -131,13 +133,25 @@ def kernel_report(eng, steps, ms_step, precision, top, survey, T):
              'conv_dw': 'gemm_bf16x3_kernel<.,.,TN> split-K: conv weight gradients',
              'conv_dx': 'gemm_img_kernel<64,64,.,.,NT> segmented-K: conv input gradients'}
     traffic, traffic_source = None, None
-    for rnd in ('r03', 'r02'):      # HBM bytes per launch: NOT measured in this run -- from the separate rocprofv3 --pmc passes kept under profiles/ (tools/pmc_summary.py)
+    # HBM bytes per launch: NOT measured in this run (a PMC pass needs rocprofv3 as the parent) -- from the separate rocprofv3 --pmc passes kept
+    # under profiles/ (tools/pmc_summary.py), and ONLY while the kernel sources are the ones those counters were read from: the record
+    # carries a hash of them, and a stale profile gives null instead of a number that no longer describes the kernel
+    try:
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        from kernel_sha import kernel_sources_sha
+        sha_now = kernel_sources_sha()
+    except Exception:
+        sha_now = None
+    for rnd in ('r04', 'r03', 'r02'):
         try:
             path = os.path.join('profiles', rnd, 'gemm_pmc.json')
             recs = [r for r in json.load(open(os.path.join(ROOT, path))) if r.get('class') == top]
             if recs:      # mean over the shapes of the class (dec_dw: dW_ih and dW_hh, six launches each per step)
+                if sha_now is None or recs[0].get('kernel_sources_sha') != sha_now:
+                    traffic_source = f'{path} is stale (GEMM kernel sources changed since its counters were read): traffic not reported'
+                    break
                 traffic = sum(r['hbm_read_bytes'] + r['hbm_write_bytes'] for r in recs) / len(recs)
-                traffic_source = f'{path} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gemm_pmc.py with the gfx950 correction; a profile figure, not measured in this run)'
+                traffic_source = f'{path} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gemm_pmc.py with the gfx950 correction; a profile figure of these kernel sources, not measured in this run)'
                 break
         except Exception:
             pass
@@ -193,6 +207,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=64, help='utterances per GPU')
     ap.add_argument('--frames', type=int, default=128)
+    ap.add_argument('--global-batch', type=int, default=0,
+                    help='STRONG scaling: the global batch is fixed and split over the ranks (BASELINE config 3 is --global-batch 64 --precision bf16 on 2 GPUs: '
+                         '32 utterances per GPU; config 4 --global-batch 256 --model G6 --frames 192 on 8).  Default 0: weak scaling, --batch utterances per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip alt_precisions and solver_loop')
     ap.add_argument('--precision', choices=['f32', 'bf16'], default='f32',
@@ -225,6 +242,10 @@ def main():
         k, v = kv.split('=')
         tune(k, int(v))
     B, T = args.batch, args.frames
+    if args.global_batch:
+        if args.global_batch % world:
+            sys.exit(f'bench.py: --global-batch {args.global_batch} is not a multiple of the {world} ranks')
+        B = args.global_batch // world
     kind = args.model
     hp = HP.default_hparams(max_len_pad=T, batch_size=B * world)
     eng = Engine(kind, hp, B, T, device=dev)
@@ -327,6 +348,24 @@ def main():
     dt = timed(args.steps, args.warmup, None if args.no_profile else [top, 'rec_fwd', 'rec_bwd'], PROF_EVERY)
     bracketed = (args.steps + PROF_EVERY - 1) // PROF_EVERY      # steps of the timed region that carried the brackets
     eng.check()                  # outside the timed region: no persistent kernel reported a bounded-wait expiry
+    # data parallel, native path: where every bucket's collective sat relative to the end of the backward -- hipEvent brackets on the
+    # communication stream (ss_dp_profile) over a few steps OUTSIDE the timed region; the record of the last one, from real RCCL kernels
+    dp_coll = None
+    if native:
+        eng.dp_profile(True)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        rec = eng.dp_profile_read()
+        eng.dp_profile(False)
+        if dist is not None:
+            dist.barrier()
+        if rec:
+            dp_coll = {'what': 'collectives of one data-parallel step in enqueue order, microseconds relative to the END OF THE BACKWARD on the main stream '
+                               '(negative: hidden beside the backward); offset -1 = the grouped rest (layer-0 convolutions, encoder BLSTMs, Encoder_t, status slot)',
+                       'world': world, 'rank': rank,
+                       'buckets': [{'arena_offset': o, 'mbytes': round(c * 4 / 1e6, 2), 'start_us': round(a, 1), 'end_us': round(b, 1)} for o, c, a, b in rec],
+                       'last_end_us': round(max(b for _, _, _, b in rec), 1)}
     ms = dt / args.steps * 1e3
     value = B * world / (dt / args.steps)
     mean_T = timed_frames[0] / max(1, args.steps) if stream is not None else T      # config 5: mean frames per batch over the timed batches only
@@ -371,8 +410,8 @@ def main():
         out = {
             'metric': 'utterances/sec (fwd+bwd, 128-frame 80-mel, batch 64) at 1/2/4/8 MI355X',
             'value': round(value, 1), 'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32 (fp16x2 products)' if args.precision == 'f32' else 'bf16 products (fp32 storage)', 'data': 'synthetic',
+            'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'strong' if args.global_batch else 'weak', 'vs_baseline': None,
+            'dtype': 'f32 (fp16x2 products)' if args.precision == 'f32' else 'bf16 (operand images stored in bf16, fp32 accumulation, state and master weights)', 'data': 'synthetic',
             'config': {'workload': (f'Generator_3 full training step (host draws+resample+quantise+fwd+MSE+bwd+Adam), '
                                     f'{B} utterances/GPU x {T} frames x 80 mel + F0, max_len_pad={T}' if kind == 'G3' and args.workload == 'fixed' else
                                     f'Generator_3 full training step over length-bucketed batches (BASELINE config 5): crops of 96..192 frames, one bucket '
@@ -383,7 +422,7 @@ def main():
                        'products': PRODUCTS[args.precision]},
             'step_tflops': round(3 * 2 * (MAC_PER_FRAME_G3 if kind == 'G3' else MAC_PER_FRAME_G6) * mean_T * B * world / (dt / args.steps) / 1e12, 2),
             'roofline': roof, 'kernel_classes': classes, 'recurrence': recur, 'alt_precisions': alt,
-            'solver_loop': sl,
+            'solver_loop': sl, 'dp_collectives': dp_coll,
             'cpu_baseline': None if args.no_cpu_baseline else cpu_baseline(T),
         }
         print(json.dumps(out), flush=True)

@@ -136,6 +136,13 @@ int ss_g3_dp_train_step(ss_engine* e, const float* mel_dev, const float* f0_dev,
                         const float* scales_dev, const int* len_seg_dev, int B, int T, int flags, float* loss_dev, void* stream);
 int ss_g6_dp_train_step(ss_engine* e, const float* mel_dev, const float* f0_onehot_dev, const int* target_idx_dev, const float* scales_dev,
                         const int* len_seg_dev, int B, int T, int flags, float* loss_dev, void* stream);
+/* Where the collectives of a data-parallel step sit (for the multi-GPU scaling record): with ss_dp_profile(e, 1) every collective of
+ * ss_g3_dp_train_step / ss_g6_dp_train_step is bracketed by hipEvents on the communication stream and one event marks the end of the
+ * backward on the main stream.  ss_dp_profile_read (synchronises) returns the number of collectives of the LAST step and, for up to
+ * `cap` of them in enqueue order, four doubles each: arena offset (-1: the grouped rest at the backward's end), element count, start
+ * and end in microseconds RELATIVE TO THE BACKWARD'S END (negative = the collective ran beside the backward).  out == NULL: count only. */
+int ss_dp_profile(ss_engine* e, int on);
+int ss_dp_profile_read(ss_engine* e, double* out, int cap);
 
 /* torch.optim.Adam(G.parameters(), lr, [beta1, beta2]) (solver.py:62,172).  `step` = updates already applied. */
 int ss_set_adam(ss_engine* e, double lr, double beta1, double beta2, double eps, long step, void* stream);

@@ -470,9 +470,9 @@ __global__ __launch_bounds__(256) void collate_kernel(const float* __restrict__ 
         for (int k = threadIdx.x; k < E; k += 256) emb[(long)b * E + k] = emb_tab[(long)item[b] * E + k];
 }
 
-__global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict__ w, int Co, int Ci, int Cp,
-                                                        float* __restrict__ wf, float* __restrict__ wb, float* __restrict__ wf_img,
-                                                        float* __restrict__ wb_img, int img_bf16) {
+__device__ __forceinline__ void conv_pack_body(const float* __restrict__ w, int Co, int Ci, int Cp,
+                                               float* __restrict__ wf, float* __restrict__ wb, float* __restrict__ wf_img,
+                                               float* __restrict__ wb_img, int img_bf16) {
     // wf[co][k][cp] ; wb[ci][k][co] = w[co][ci][4-k].  Cp and Co are multiples of 4: a thread writes one group of four (and its image)
     const long nf = (long)Co * 5 * Cp / 4;
     const long nb = (long)Ci * 5 * Co / 4;
@@ -498,6 +498,16 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict_
             if (wb_img) ss_store_img4(wb_img, 4 * (gi - nf), v[0], v[1], v[2], v[3], 16.0f, img_bf16);
         }
     }
+}
+__global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict__ w, int Co, int Ci, int Cp,
+                                                        float* __restrict__ wf, float* __restrict__ wb, float* __restrict__ wf_img,
+                                                        float* __restrict__ wb_img, int img_bf16) {
+    conv_pack_body(w, Co, Ci, Cp, wf, wb, wf_img, wb_img, img_bf16);
+}
+// grid = (blocks, tasks)
+__global__ __launch_bounds__(256) void conv_pack_many_kernel(ConvPackTable tb) {
+    const ConvPackTask t = tb.t[blockIdx.y];
+    conv_pack_body(t.w, t.Co, t.Ci, t.Cp, t.wf, t.wb, t.wf_img, t.wb_img, tb.img_bf16);
 }
 
 __global__ __launch_bounds__(256) void conv_unpack_grad_kernel(const float* __restrict__ gp, int Co, int Ci, int Cp,
@@ -866,6 +876,13 @@ hipError_t conv_unpack_grad(const float* gp, int Co, int Ci, int Cp, float* g, h
     int gr = cdiv((long)Co * Ci * 5, 256);
     if (gr > 2048) gr = 2048;
     hipLaunchKernelGGL(conv_unpack_grad_kernel, dim3(gr), dim3(256), 0, s, gp, Co, Ci, Cp, g);
+    return hipGetLastError();
+}
+
+hipError_t conv_pack_many(const ConvPackTable& tb, hipStream_t s) {
+    if (tb.n <= 0) return hipSuccess;
+    if (tb.n > 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(conv_pack_many_kernel, dim3(512, tb.n), dim3(256), 0, s, tb);
     return hipGetLastError();
 }
 

@@ -52,6 +52,7 @@ int g_bf16_img = 1;        // SS_PRECISION_BF16: the 16-bit data path (round 4) 
                            // single-piece form of the image GEMM; 0: round 3's bf16 mode (fp32 slabs, operands rounded inside the GEMM)
 int g_seq_hi = 1;          // ... and the persistent recurrences multiply the high fp16 pieces only (one MFMA per product, half the forward's payload)
 int g_bf16_img_mask = ~0;  // ... per profile class (bit SS_PROF_*), for A/B runs
+int g_pack_one = 1;        // every conv block's per-step weight re-layout in one launch at the start of the forward (conv_pack_many)
 int g_presplit = 7;        // weights (and, bit 1, the decoder's hidden states) reach the fp16 x 2 GEMMs as pre-split images: bit 0 weights, bit 1 the decoder's hidden states, bit 2 the trunk's resampled activations
 int g_compact0 = 1;        // decoder layer 0: input projections, input gradient and W_ih gradient once per block of repeated input frames
 int g_batch_dirs = 1;      // BLSTM weight gradients: both directions of a layer in one launch per matrix (batch = 2) + one bias kernel:
@@ -208,6 +209,17 @@ struct ss_engine {
     hipStream_t comm_s = nullptr;
     hipEvent_t ev_comm = nullptr;
     std::vector<std::pair<long, long>> dp_done;      // [offset, end) ranges already handed to a collective in this step
+    // ss_dp_profile: hipEvent brackets round every collective of the LAST data-parallel step on the communication stream, plus one event at
+    // the backward's end on the main stream -- where each bucket's all-reduce starts and ends relative to it (the overlap a scaling run achieved)
+    bool dp_prof = false;
+    struct DpRec {
+        long off, count;
+        hipEvent_t a, b;
+    };
+    std::vector<DpRec> dp_rec;             // this step's
+    std::vector<hipEvent_t> dp_ev_pool;    // events are created once and reused
+    int dp_ev_used = 0;
+    hipEvent_t dp_bwd_end = nullptr;
     bool lockstep = false;                 // data-parallel member: entry points never refuse on the status word (entry_check)
     unsigned* sticky = nullptr;            // engine status word in host-coherent pinned memory (kernels.h SS_STICKY_*): written by
                                            // kernels, read by the host without synchronising; cleared only by ss_clear_abort
@@ -1743,8 +1755,21 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
     hipStream_t b1 = par ? e->side : s, b2 = par ? e->side2 : s;
     e->grads_zeroed = false;               // set again below when this forward belongs to a fused training step
     e->bwd_sync_zeroed = false;
-    if (g3) CHK(conv_pack_all(e, e->c1[0], s));
-    CHK(conv_pack_all(e, e->c2[0], s));
+    const bool pack_one = g_pack_one && !g_graph;
+    if (pack_one) {
+        ConvPackTable pt{};
+        pt.img_bf16 = e->img16();
+        ConvBlk* all[7] = {&e->c1[0], &e->c2[0], &e->c1[1], &e->c2[1], &e->c1[2], &e->c2[2], &e->ct};
+        for (ConvBlk* cb : all) {
+            if (!cb->Co) continue;
+            const bool img = cb->img_ok();
+            pt.t[pt.n++] = {e->P + cb->w, cb->wf, cb->wb, img ? cb->wf_img : nullptr, img ? cb->wb_img : nullptr, cb->Co, cb->Ci, cb->Cp};
+        }
+        HIPCHK(conv_pack_many(pt, s));
+    } else {
+        if (g3) CHK(conv_pack_all(e, e->c1[0], s));
+        CHK(conv_pack_all(e, e->c2[0], s));
+    }
     CHK(act_scales_all(e, s));             // before every branch forks: the scale words of the conv blocks' outputs
     if (par) CHK(fork_join(e, s, b2));
     if (e->late_org && !g_graph) {
@@ -1769,13 +1794,13 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
         HIPCHK(hipEventRecord(plans, b2));
     }
     if (indep) CHK(fork_join(e, s, b1));
-    for (int i = 1; i < 3; ++i) {
+    for (int i = 1; i < 3 && !pack_one; ++i) {
         if (g3) CHK(conv_pack_all(e, e->c1[i], b2));
         CHK(conv_pack_all(e, e->c2[i], b2));
     }
-    CHK(conv_pack_all(e, e->ct, b2));
+    if (!pack_one) CHK(conv_pack_all(e, e->ct, b2));
     hipEvent_t packed = nullptr;
-    if (par) {
+    if (par && !pack_one) {
         packed = e->ev[e->ev_next];
         e->ev_next = (e->ev_next + 1) & 15;
         HIPCHK(hipEventRecord(packed, b2));
@@ -2264,6 +2289,8 @@ void ss_destroy(ss_engine* e) {
             if (ev) (void)hipEventDestroy(ev);
         (void)hipStreamDestroy(e->side);
         if (e->ev_comm) (void)hipEventDestroy(e->ev_comm);
+        for (hipEvent_t ev : e->dp_ev_pool) (void)hipEventDestroy(ev);
+        if (e->dp_bwd_end) (void)hipEventDestroy(e->dp_bwd_end);
         for (hipStream_t st : {e->side2, e->side3})
             if (st) {
                 (void)hipStreamSynchronize(st);
@@ -2884,6 +2911,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "bf16_img" && (value == 0 || value == 1)) g_bf16_img = value;
     else if (k == "bf16_img_mask") g_bf16_img_mask = value;
     else if (k == "seq_hi" && (value == 0 || value == 1)) g_seq_hi = value;
+    else if (k == "pack_one" && (value == 0 || value == 1)) g_pack_one = value;
     else if (k == "img" && (value == 0 || value == 1)) g_img = value;
     else if (k == "img_mask" && value >= 0 && value < 2048) g_img_mask = value;
     else if (k == "img_batch" && (value == 0 || value == 1)) g_img_batch = value;
@@ -3207,6 +3235,17 @@ int allreduce_range(ss_engine* e, long off, long count, hipStream_t st) {
     return 0;
 }
 
+// ss_dp_profile bracket: a timing event from the pool (null when profiling is off or an event could not be created)
+hipEvent_t dp_prof_event(ss_engine* e) {
+    if (!e->dp_prof) return nullptr;
+    if (e->dp_ev_used == (int)e->dp_ev_pool.size()) {
+        hipEvent_t ev = nullptr;
+        if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+        e->dp_ev_pool.push_back(ev);
+    }
+    return e->dp_ev_pool[e->dp_ev_used++];
+}
+
 // see the declaration above fork_join
 int dp_bucket(ss_engine* e, long off, long count, hipStream_t producer) {
     if (!e->dp_on || !g_dp_buckets || count <= 0) return 0;
@@ -3215,7 +3254,13 @@ int dp_bucket(ss_engine* e, long off, long count, hipStream_t producer) {
         if (off < r.second && r.first < off + count) return fail("dp_bucket: gradient range handed to a collective twice");
     HIPCHK(hipEventRecord(e->ev_comm, producer));
     HIPCHK(hipStreamWaitEvent(e->comm_s, e->ev_comm, 0));
+    hipEvent_t pa = dp_prof_event(e), pb = pa ? dp_prof_event(e) : nullptr;
+    if (pb) HIPCHK(hipEventRecord(pa, e->comm_s));
     CHK(allreduce_range(e, off, count, e->comm_s));
+    if (pb) {
+        HIPCHK(hipEventRecord(pb, e->comm_s));
+        e->dp_rec.push_back({off, count, pa, pb});
+    }
     e->dp_done.push_back({off, off + count});
     return 0;
 }
@@ -3234,6 +3279,14 @@ int dp_finish(ss_engine* e, hipStream_t s) {
     // ONE launch for all of them (ncclGroupStart / End); modelled: one stand-in over their total size
     HIPCHK(hipEventRecord(e->ev_comm, s));
     HIPCHK(hipStreamWaitEvent(e->comm_s, e->ev_comm, 0));
+    hipEvent_t pa = nullptr, pb = nullptr;
+    if (e->dp_prof) {
+        if (!e->dp_bwd_end) HIPCHK(hipEventCreate(&e->dp_bwd_end));
+        HIPCHK(hipEventRecord(e->dp_bwd_end, s));           // the backward's last kernel on the main stream: time zero of the record
+        pa = dp_prof_event(e);
+        pb = pa ? dp_prof_event(e) : nullptr;
+        if (pb) HIPCHK(hipEventRecord(pa, e->comm_s));
+    }
     const bool model = g_dp_model > 1 && (!e->comm || e->comm_world == 1);
     if (model && g_dp_emulate) {
         for (auto& r : rest) CHK(allreduce_range(e, r.first, r.second - r.first, e->comm_s));
@@ -3256,6 +3309,12 @@ int dp_finish(ss_engine* e, hipStream_t s) {
             if (rc) return fail(first_err);
             NCCLCHK(ge);
         } else if (rc) return rc;
+    }
+    if (pb) {
+        long tot = 0;
+        for (auto& r : rest) tot += r.second - r.first;
+        HIPCHK(hipEventRecord(pb, e->comm_s));
+        e->dp_rec.push_back({-1, tot, pa, pb});             // offset -1: the grouped rest
     }
     e->dp_done.clear();
     HIPCHK(hipEventRecord(e->ev_comm, e->comm_s));
@@ -3341,6 +3400,8 @@ static int dp_step(ss_engine* e, hipStream_t s, const std::function<int(hipStrea
         return adam_enqueue(e, gs, s);
     }
     e->dp_done.clear();
+    e->dp_rec.clear();              // ss_dp_profile keeps the LAST step's record
+    e->dp_ev_used = 0;
     e->dp_on = true;
     const int rc = body(s);
     e->dp_on = false;
@@ -3360,6 +3421,33 @@ int ss_g3_dp_train_step(ss_engine* e, const float* mel, const float* f0, const f
     hipStream_t s = own.s;
     CHK(geometry(e, B, T, s));
     return dp_step(e, s, [&](hipStream_t st) { return g3_step_body(e, mel, f0, emb, len_org, scales, len_seg, B, T, 1.0f, SS_STEP_NO_ADAM, loss, st); });
+}
+
+int ss_dp_profile(ss_engine* e, int on) {
+    if (!e) return fail("ss_dp_profile: null engine");
+    e->dp_prof = on != 0;
+    e->dp_rec.clear();
+    e->dp_ev_used = 0;
+    return 0;
+}
+
+int ss_dp_profile_read(ss_engine* e, double* out, int cap) {
+    if (!e) return fail("ss_dp_profile_read: null engine");
+    const int n = (int)e->dp_rec.size();
+    if (!out) return n;
+    if (n && !e->dp_bwd_end) return fail("ss_dp_profile_read: no data-parallel step has run with the profile on");
+    for (int i = 0; i < n && i < cap; ++i) {
+        const auto& r = e->dp_rec[i];
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventSynchronize(e->dp_bwd_end) != hipSuccess) return fail("ss_dp_profile_read: event sync failed");
+        float ta = 0, tb = 0;
+        if (hipEventElapsedTime(&ta, e->dp_bwd_end, r.a) != hipSuccess || hipEventElapsedTime(&tb, e->dp_bwd_end, r.b) != hipSuccess)
+            return fail("ss_dp_profile_read: elapsed time failed");
+        out[4 * i + 0] = (double)r.off;
+        out[4 * i + 1] = (double)r.count;
+        out[4 * i + 2] = ta * 1e3;
+        out[4 * i + 3] = tb * 1e3;
+    }
+    return n < cap ? n : cap;
 }
 
 int ss_g6_dp_train_step(ss_engine* e, const float* mel, const float* f0_onehot, const int* target_idx, const float* scales, const int* len_seg,

@@ -72,6 +72,18 @@ hipError_t collate(const float* mel_cat, const float* f0_cat, const float* emb_t
 // wf_img / wb_img (nullable): pre-split images of wf / wb (Cp % 4 == 0, Co % 4 == 0)
 hipError_t conv_pack(const float* w, int Co, int Ci, int Cp, float* wf, float* wb, float* wf_img, float* wb_img, hipStream_t s, int img_bf16 = 0);
 // packed weight grad [Co][5][Cp] -> grad arena [Co][Ci][5] (overwrite)
+// every conv block's per-step weight re-layout in ONE launch (seven launches of 6 - 17 us were a chain the trunk's second layer waited for)
+struct ConvPackTask {
+    const float* w;
+    float *wf, *wb, *wf_img, *wb_img;
+    int Co, Ci, Cp;
+};
+struct ConvPackTable {
+    ConvPackTask t[8];
+    int n;
+    int img_bf16;
+};
+hipError_t conv_pack_many(const ConvPackTable& tb, hipStream_t s);
 hipError_t conv_unpack_grad(const float* gp, int Co, int Ci, int Cp, float* g, hipStream_t s);
 constexpr int CONV_UNPACK_MAX = 8;
 struct ConvUnpackTask {

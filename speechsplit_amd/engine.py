@@ -236,6 +236,22 @@ class Engine:
         _capi.check(self.lib.ss_comm_init(self.h, buf, int(rank), int(world)))
         self.comm_world = int(world)
 
+    def dp_profile(self, on=True):
+        """hipEvent brackets round every collective of the native data-parallel steps (ss_dp_profile)."""
+        _capi.check(self.lib.ss_dp_profile(self.h, 1 if on else 0))
+
+    def dp_profile_read(self):
+        """[(arena offset or -1 for the grouped rest, elements, start_us, end_us)] of the last data-parallel step's collectives, times
+        relative to the end of the backward on the main stream (negative: hidden beside it).  Synchronises."""
+        n = self.lib.ss_dp_profile_read(self.h, None, 0)
+        if n <= 0:
+            return []
+        buf = (C.c_double * (4 * n))()
+        n = self.lib.ss_dp_profile_read(self.h, buf, n)
+        if n < 0:
+            _capi.check(n)
+        return [(int(buf[4 * i]), int(buf[4 * i + 1]), float(buf[4 * i + 2]), float(buf[4 * i + 3])) for i in range(n)]
+
     def allreduce_grads(self, lo=0, hi=None):
         hi = self.grads.numel() if hi is None else hi
         _capi.check(self.lib.ss_allreduce_grads(self.h, int(lo), int(hi - lo), _stream()))

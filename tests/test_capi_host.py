@@ -212,3 +212,31 @@ def test_mel_filter_bank_published_properties():
         assert abs(float(w[i].max()) - 2.0 / width) <= 2.0 / width * (15.625 / min(edges[i + 1] - edges[i], edges[i + 2] - edges[i + 1])) + 1e-6
     assert peaks == sorted(peaks)
     assert float(w[:, fft_f < 90.0].max()) == 0.0 and float(w[:, fft_f > 7600.0].max()) == 0.0
+
+
+def test_mel_filter_bank_closed_form_slaney_values():
+    """Pin of speechsplit_amd.features.mel_filter_bank against hand-computed values of the published definition (librosa.filters.mel with its
+    defaults: Slaney mel scale, 'slaney' area norm; make_spect_f0.py:15 calls it with sr 16000, n_fft 1024, fmin 90, fmax 7600, n_mels 80).
+    librosa itself is absent here, so this is a pin against the closed form, not against the reference's output -- it says so, and it is
+    the strongest pin this environment allows.  Derivation (scalar arithmetic, independent of the function under test):
+      mel(90) = 90 / (200/3) = 1.35;  mel(7600) = 15 + 27 ln(7.6) / ln(6.4) = 44.4995755;  82 edges, step 0.53271081 mel.
+      filter 0 (linear region): edges 90, 125.5141, 161.0281 Hz -> bins 6..10 (k x 15.625 Hz), height 2 / 71.0281 = 0.0281579
+          bin 8 (125.0 Hz): (125 - 90) / 35.5141 x 0.0281579 = 0.02775029
+      filter 25 (straddles 1 kHz, where the scale turns logarithmic): edges 977.8513, 1013.8789, 1051.7004 Hz -> bins 63..67
+      filter 79 (top of the log region): edges 7063.2029, 7326.6870, 7600 Hz -> bins 453..486, peak at bin 469."""
+    import numpy as np
+    from speechsplit_amd import features as F
+    w = F.mel_filter_bank()
+    want = {
+        0: {6: 0.002973245, 7: 0.01536177, 8: 0.02775029, 9: 0.01617692, 10: 0.003788397},
+        25: {63: 0.004903904, 64: 0.01664939, 65: 0.02583195, 66: 0.01464359, 67: 0.003455222},
+        79: {453: 0.0002110063, 460: 0.001757626, 468: 0.003525191, 469: 0.003706199, 470: 0.003493199, 480: 0.0013632, 486: 8.519999e-05},
+    }
+    for i, vals in want.items():
+        nz = np.nonzero(w[i])[0]
+        if i != 79:
+            assert list(nz) == sorted(vals), (i, list(nz))
+        else:
+            assert nz[0] == 453 and nz[-1] == 486 and len(nz) == 34 and int(w[i].argmax()) == 469
+        for k, v in vals.items():
+            assert abs(float(w[i, k]) - v) <= 2e-6 * v + 1e-12, (i, k, float(w[i, k]), v)

@@ -23,8 +23,9 @@ def _free_port():
 
 
 @pytest.mark.parametrize('extra', [[], ['--dp-backend', 'torch'], ['--workload', 'config5', '--frames', '192', '--precision', 'bf16'],
-                                   ['--model', 'G6', '--batch', '32', '--frames', '192', '--precision', 'bf16']],
-                         ids=['headline_native_rccl', 'headline_torch_distributed', 'config5_buckets_bf16', 'config4_g6_bf16'])
+                                   ['--model', 'G6', '--batch', '32', '--frames', '192', '--precision', 'bf16'],
+                                   ['--global-batch', '32', '--precision', 'bf16']],
+                         ids=['headline_native_rccl', 'headline_torch_distributed', 'config5_buckets_bf16', 'config4_g6_bf16', 'config3_strong_scaling_shape'])
 def test_bench_dp_path_under_torchrun(extra):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--force-dp', '--steps', '4', '--warmup', '2',
@@ -38,3 +39,12 @@ def test_bench_dp_path_under_torchrun(extra):
     assert 'forced DP path' in out['config']['parallelism']
     assert out['roofline'] and 0 < out['roofline']['frac'] < 1
     assert out['recurrence']['launches_per_step'] in (4.0, 6.0)
+    assert out['scaling'] == ('strong' if '--global-batch' in extra else 'weak')
+    if '--global-batch' in extra:
+        assert out['config']['global_batch'] == 32
+    if '--dp-backend' not in extra:
+        # the native RCCL path reports where each bucket's collective sat relative to the end of the backward (ss_dp_profile)
+        dc = out['dp_collectives']
+        assert dc and len(dc['buckets']) >= 3 and dc['buckets'][-1]['arena_offset'] == -1
+        assert all(b['end_us'] >= b['start_us'] for b in dc['buckets'])
+        assert sum(b['mbytes'] for b in dc['buckets']) > 10          # the whole gradient arena went through collectives (13.9 / 77.8 MB)

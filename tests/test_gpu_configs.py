@@ -69,7 +69,7 @@ class Case:
             self.onehot = torch.nn.functional.one_hot(self.qidx, 257).float()
         self.dseed = bseed + 100
 
-    def step(self, it, kink_bound=2e-5):
+    def step(self, it, kink_bound=2e-5, override=True):
         """Engine: forward, loss, backward (gradients kept), then Adam.  Oracle: the same step taking the engine's ReLU branches.
         Returns dict(loss=(gpu, cpu), out=(gpu, cpu), grads={name: (gpu, cpu)}, before/after params of the engine)."""
         eng, B, T = self.eng, self.B, self.T
@@ -85,7 +85,8 @@ class Case:
         masks = {k: v.cpu() for k, v in eng.relu_masks(B, T).items()}
         eng.adam_step()
         r['p_after'] = {n: v.clone().cpu() for n, v in eng.param_views().items()}
-        ref_model.MASK, ref_model.MASK_STATS = masks, {}
+        if override:
+            ref_model.MASK, ref_model.MASK_STATS = masks, {}
         try:
             if self.kind == 'G3':
                 lo, out = self.st.step_g3(self.hp, self.mel, self.f0, self.emb, self.lens.numpy(), draws)
@@ -94,11 +95,12 @@ class Case:
             stats = ref_model.MASK_STATS
         finally:
             ref_model.MASK, ref_model.MASK_STATS = None, None
-        assert set(stats) == set(masks), (sorted(stats), sorted(masks))
-        flips = {k: v for k, v in stats.items() if v[0]}
-        print(f'[{self.kind} {B}x{T} step {it}] ReLU branches overridden at the kink: {flips or "none"}')
-        for k, (n, zmax) in stats.items():
-            assert zmax < kink_bound, (k, n, zmax)          # the override never touched a clearly signed value
+        if override:
+            assert set(stats) == set(masks), (sorted(stats), sorted(masks))
+            flips = {k: v for k, v in stats.items() if v[0]}
+            print(f'[{self.kind} {B}x{T} step {it}] ReLU branches overridden at the kink: {flips or "none"}')
+            for k, (n, zmax) in stats.items():
+                assert zmax < kink_bound, (k, n, zmax)          # the override never touched a clearly signed value
         r.update(loss_cpu=float(lo), out_cpu=out, grads_cpu={n: p.grad.clone() for n, p in self.st.P.items()},
                  p_cpu={n: p.detach().clone() for n, p in self.st.P.items()})
         return r
@@ -153,6 +155,31 @@ def test_g3_fp32_config_shapes(E, shape):
     assert np.array_equal(c.eng.debug_buffer('in.mel', B, T).cpu().numpy(), xi[:, :, :80].numpy())
     cls = c.eng.debug_buffer('in.f0', B, T)[:, :, :257].argmax(-1).cpu().numpy()
     assert np.array_equal(cls, interp_np.quantize_f0(xi[:, :, -1].numpy()))
+
+
+# --------------------------------------------------------------------------------------------- the same comparison WITHOUT the ReLU hand-over
+@pytest.mark.parametrize('case', [('G3', 16, 128, 64), ('G3', 64, 128, 64), ('G3', 64, 192, 96), ('G6', 32, 192, 96)],
+                         ids=['g3_b16_t128', 'g3_b64_t128', 'g3_b64_t192', 'g6_b32_t192'])
+def test_no_override_relu_diagnostic(E, case):
+    """Round-3 review: every whole-model gradient comparison runs with the oracle taking the ENGINE's ReLU branches, so a sign bug in
+    gn_relu_bwd could hide behind the hook.  Here the oracle decides its own branches.  A GroupNorm output within rounding of zero may then
+    land on the other side in the two implementations, and that element's gradient contribution differs -- a handful of elements, each
+    worth at most one frame of one channel -- so the tensors beyond 1e-4 are REPORTED, not asserted; what is asserted is that nothing is
+    off by more than 1e-2 (a wrong branch rule would put whole tensors off by O(1)), that loss and output hold their usual bars (they do
+    not depend on the backward's branches) and that the decoder's and the head's gradients, whose backward passes through no ReLU, hold 1e-4."""
+    kind, B, T, len_lo = case
+    c = Case(E, kind, B, T, len_lo, wseed=0 if kind == 'G3' else 4, bseed=(900 if kind == 'G3' else 51) + B + T)
+    r = c.step(0, override=False)
+    assert abs(r['loss_gpu'] - r['loss_cpu']) <= 1e-5 * abs(r['loss_cpu'])
+    assert rel(r['out_gpu'], r['out_cpu']) < TOL
+    errs = {n: rel(r['grads_gpu'][n], g) for n, g in r['grads_cpu'].items()}
+    beyond = {n: e for n, e in errs.items() if not e < TOL}
+    print(f'[{kind} {B}x{T}, oracle with its OWN ReLU branches] gradient tensors beyond 1e-4: '
+          f'{ {n: float(f"{e:.1e}") for n, e in sorted(beyond.items())} or "none"}; worst {max(errs.values()):.2e}')
+    for n, e in errs.items():
+        assert e < 1e-2, (n, e)
+        if n.startswith('decoder.'):
+            assert e < TOL, (n, e)               # the decoder's gradients do not pass through any ReLU's backward
 
 
 # --------------------------------------------------------------------------------------------- parity away from initialisation

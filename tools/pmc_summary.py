@@ -29,16 +29,20 @@ def load(d):
     return [rows[i * LAUNCHES + LAUNCHES - 1] for i in range(len(SHAPES))]
 
 
+from kernel_sha import kernel_sources_sha      # noqa: E402
+
+
 def main():
     fetch, write, sq = load(sys.argv[1]), load(sys.argv[2]), load(sys.argv[3])
     out, lines = [], []
+    sha = kernel_sources_sha()
     for i, name in enumerate(SHAPES):
         c = sq[i]['c']
         rd, wr = 2.0 * fetch[i]['c']['FETCH_SIZE'] * 1024, write[i]['c']['WRITE_SIZE'] * 1024
         cyc = c['GRBM_GUI_ACTIVE'] / 8.0                                  # summed over the 8 XCDs
         busy = 100.0 * c['SQ_VALU_MFMA_BUSY_CYCLES'] / (cyc * 1024) if 'SQ_VALU_MFMA_BUSY_CYCLES' in c else None
         rec = {'shape': name, 'class': CLASSES[i], 'kernel': sq[i]['kernel'], 'us': sq[i]['us'], 'tflops': FLOPS[i] / sq[i]['us'] / 1e6,
-               'hbm_read_bytes': rd, 'hbm_write_bytes': wr, 'mfma_busy_pct': busy,
+               'hbm_read_bytes': rd, 'hbm_write_bytes': wr, 'mfma_busy_pct': busy, 'kernel_sources_sha': sha,
                'lds_bank_conflict_cycles': c.get('SQ_LDS_BANK_CONFLICT'), 'lds_idx_active_cycles': c.get('SQ_LDS_IDX_ACTIVE')}
         out.append(rec)
         lines.append(f"{name:72s} {rec['kernel'][:58]:58s} {rec['us']:7.1f} us {rec['tflops']:6.1f} TF  HBM read {rd / 1e6:6.1f} MB  write {wr / 1e6:5.1f} MB"
