@@ -766,7 +766,7 @@ int gemm_on(ss_engine* e, GemmDesc& d, hipStream_t st) {
         // split-K weight gradients: partial slabs + ordered reduce instead of fp32 atomics (ss_tune("part_splitk")), scratch from the step's bump allocator
         // (not for the encoder BLSTMs' tiny matrices: a one-block reduce over 32 slices is 17 us of latency, their atomics are nothing)
         if (g_part_splitk && d.ksplit > 1 && (d.flags & GEMM_TA) && (d.flags & GEMM_TB) && (d.flags & GEMM_ACCUM) && !d.row_period && !d.bias && d.N % 4 == 0 &&
-            (long)d.M * d.N >= 65536 && e->part && !g_deterministic) {
+            ((long)d.M * d.N >= 65536 || g_deterministic) && e->part) {        // deterministic mode: every split reduction through ordered slabs (small ones too)
             int ks = d.ksplit;
             const long need = (long)ks * d.M * d.N * (d.batch < 1 ? 1 : d.batch);
             if (e->part_off + need <= e->part_cap) {

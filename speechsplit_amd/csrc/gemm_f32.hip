@@ -17,7 +17,7 @@ namespace ss {
 
 int g_gemm_bk = 16;        // (unused: BK = 32 measured slower; kept so ss_tune("gemm_bk") stays valid)
 int g_gemm_want = 1024;
-int g_deterministic = 0;   // ss_tune("deterministic", 1): run-to-run bit-identical results -- no split-K (its fp32 atomics commit in arrival
+int g_deterministic = 0;   // ss_tune("deterministic", 1): run-to-run bit-identical results -- split-K only through ordered partial slabs (fp32 atomics commit in arrival
                            // order), ordered bias / affine gradient sums (elementwise.hip), bias gradients of the persistent recurrence
                            // through the ordered column sum.  Costs the weight-gradient GEMMs their split-K parallelism.
 int g_gemm_diag = 0;       // A/B experiments: bit 0 = XCD-aware tile order off, bit 1 = two-tile register prefetch
@@ -336,11 +336,14 @@ hipError_t launch_gemm(const GemmDesc& din, hipStream_t s) {
     GemmDesc d = din;
     d.diag = g_gemm_diag;
     if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return hipSuccess;
-    if (d.ksplit < 1 || g_deterministic) d.ksplit = 1;
-    if (d.ksplit > 1 && !(d.flags & GEMM_ACCUM)) return hipErrorInvalidValue;   // split-K needs a zeroed / live C
+    // deterministic mode: a split reduction only through partial slabs added in a fixed order (GemmDesc::part, round 3); without scratch no split
+    // (its fp32 atomics would commit in arrival order).  Round 2 dropped split-K altogether there: 2.2x the default step.
     const bool vec = vec_ok(d.A) && vec_ok(d.B);
     const bool seg_ok = (d.A.seglen == 0 || d.A.seglen >= 32) && (d.B.seglen == 0 || d.B.seglen >= 32);   // one wrap per k-tile
-    if (vec && seg_ok && g_gemm_mode == 1) return launch_gemm_bf16x3(d, s);
+    const bool split_kernel = vec && seg_ok && g_gemm_mode == 1;            // the bf16 x 3 / fp16 x 2 kernel: the one with the partial-slab split-K
+    if (d.ksplit < 1 || (g_deterministic && !(d.part && split_kernel))) d.ksplit = 1;
+    if (d.ksplit > 1 && !(d.flags & GEMM_ACCUM)) return hipErrorInvalidValue;   // split-K needs a zeroed / live C
+    if (split_kernel) return launch_gemm_bf16x3(d, s);
     d.part = nullptr;              // the fp32-MFMA kernel's split-K meets in C through atomics
     const bool ta = d.flags & GEMM_TA, tb = d.flags & GEMM_TB;
     if (!ta && !tb) return launch_layout<false, false>(d, vec, s);
