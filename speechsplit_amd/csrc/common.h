@@ -119,8 +119,8 @@ hipError_t split_image(const float* src, long ld, long rows, int cols, const flo
 hipError_t gemm_phase_probe(unsigned long long out[24], bool reset);
 
 // Gate non-linearities of the recurrence kernels.  They sit on the per-time-step critical path, where libdevice's expf /
-// tanhf (range reduction, branches) cost a few hundred cycles per step; these use the hardware exp2 / rcp with the
-// argument rounding compensated (ss_exp) and a series for tanh where the quotient form would cancel: a few ulp relative error.
+// tanhf (range reduction, branches) cost a few hundred cycles per step; these use the hardware exp2 / rcp, with a
+// series for tanh where the quotient form would cancel: a few ulp.
 #ifdef __HIPCC__
 // operand with a measured maximum m: the power of two that brings m into [128, 256) (256x headroom below fp16's 65504), capped
 // so that an all-zero / denormal tensor cannot produce an infinite scale (same rule as gemm_bf16x3.hip's pow2_scale)
@@ -199,40 +199,26 @@ __device__ __forceinline__ uint4 ss_split_group_s(float v0, float v1, float v2, 
     asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(r.w) : "v"(v3), "v"(s), "v"(r.y));
     return r;
 }
-// e^x to ~1.5 ulp for every x: v_exp_f32 is 2^t to 1 ulp, but t = x * log2(e) rounded to fp32 carries an error of |t| * 2^-24, i.e. a
-// relative error of |x| * 6e-8 in the result (1e-6 at |x| = 16: __expf's).  The rounding residual of the product and the low part of
-// log2(e) are applied as a first-order correction, computed beside the exp2 (one multiply more on the dependent chain).
-__device__ __forceinline__ float ss_exp(float x) {
-    constexpr float L2E = 1.44269502162933349609375f, L2E_LO = 1.92596299112661746e-8f, LN2 = 0.693147182464599609375f;
-    const float t = x * L2E;
-    float r = __builtin_fmaf(x, L2E, -t);
-    r = __builtin_fmaf(x, L2E_LO, r);
-    const float c = __builtin_fmaf(r, LN2, 1.0f);
-    return __builtin_amdgcn_exp2f(t) * c;                    // inf * 1 = inf, 0 * c = 0: no NaN at the ends
-}
-// 1 / d to ~0.5 ulp: v_rcp_f32 (1 ulp) and one Newton step (two fma); the IEEE division sequence is ~10 dependent instructions
-__device__ __forceinline__ float ss_rcp(float d) {
-    const float r = __builtin_amdgcn_rcpf(d);
-    return __builtin_fmaf(r, __builtin_fmaf(-d, r, 1.0f), r);      // d = inf: r = 0, fma(-inf, 0, 1) = NaN -> guarded by the callers' ranges (d < 2^126)
-}
+// sigmoid: 1 / (1 + 2^(-x log2 e)) on the hardware exp2 / rcp (1 ulp each).  The product x * log2(e) rounded to fp32 puts a RELATIVE error of
+// |x| * 9e-8 into e^-x; relative to the sigmoid that is weighted by e^-x / (1 + e^-x), so the ABSOLUTE error stays below 2 ulp of the result's
+// scale everywhere (the tails where the relative error of e^-x is largest are the tails where the gate is ~0 or ~1) -- a compensated exponent
+// and a Newton step on the reciprocal were measured (round 4): +0.1 us per forward recurrence step for nothing a gradient could see.
 __device__ __forceinline__ float ss_sigmoid(float x) {
-    x = __builtin_fmaxf(x, -87.0f);                            // e^87 < 2^126: the refinement never sees inf (sigmoid(-87) = 1.6e-38 either way)
-    return ss_rcp(1.0f + ss_exp(-x));
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504f));
 }
-// tanh to ~2 ulp RELATIVE (round 4; before: 3e-7 absolute, i.e. 1e-6 relative where |x| ~ 0.1 .. 0.5 -- cell states live there -- which is
+// tanh to ~3 ulp RELATIVE (round 4; before: 3e-7 absolute, i.e. 1e-6 relative where |x| ~ 0.1 .. 0.5 -- cell states live there -- which is
 // what put the engine's trained-state gradients 10x further from float64 than PyTorch's: the recurrences carry every rounding of their
 // non-linearities forward).  |x| < 0.7: p = tanh(x / 2) from the odd series through x^11 (|x / 2| < 0.35: next term 1.2e-8 relative; Estrin
 // form), then tanh(x) = 2 p / (1 + p^2) -- no cancellation anywhere; above: 1 - 2 / (e^2x + 1), whose subtraction amplifies the quotient's
-// rounding by (1 - tanh) / tanh <= 0.65 there.
+// rounding by (1 - tanh) / tanh <= 0.65 there (e^2x = inf gives 1 - 0, e^2x = 0 gives 1 - 2).
 __device__ __forceinline__ float ss_tanh(float x) {
-    const float xc = __builtin_fminf(__builtin_fmaxf(x, -10.0f), 10.0f);       // tanh(10) rounds to 1; keeps e^2x finite for the refinement
-    const float e = ss_exp(2.0f * xc);
-    const float q = __builtin_fmaf(-2.0f, ss_rcp(e + 1.0f), 1.0f);
+    const float e = __builtin_amdgcn_exp2f(x * 2.88539008f);
+    const float q = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
     const float a = 0.5f * x, y = a * a, y2 = y * y;
     const float p01 = __builtin_fmaf(y, -0.333333343f, 1.0f), p23 = __builtin_fmaf(y, -0.0539682545f, 0.13333334f),
                 p45 = __builtin_fmaf(y, -0.00886323582f, 0.0218694881f);
     const float p = a * __builtin_fmaf(y2 * y2, p45, __builtin_fmaf(y2, p23, p01));
-    const float t = (p + p) * ss_rcp(__builtin_fmaf(p, p, 1.0f));
+    const float t = (p + p) * __builtin_amdgcn_rcpf(__builtin_fmaf(p, p, 1.0f));
     return fabsf(x) < 0.7f ? t : q;
 }
 #endif

@@ -157,6 +157,22 @@ def test_g3_fp32_config_shapes(E, shape):
     assert np.array_equal(cls, interp_np.quantize_f0(xi[:, :, -1].numpy()))
 
 
+def test_g3_all_fp32_mfma_mode_b64_t128(E):
+    """The headline shape once more with EVERY product fp32-wide (bench.py's alt_precisions.all_fp32_mfma): GEMMs on v_mfma_f32_32x32x2_f32
+    (ss_tune gemm_mode 0) and the decoder recurrences as one fp32-MFMA launch per time step (persist 0) -- the reference's arithmetic width
+    (model.py has no autocast anywhere).  Same bars as the default mode."""
+    E.tune('gemm_mode', 0)
+    E.tune('persist', 0)
+    try:
+        c = Case(E, 'G3', 64, 128, 64, wseed=0, bseed=900 + 64 + 128)
+        r = c.step(0)
+        check_fp32_step(r, 'G3 64x128, all products on the fp32 MFMA')
+        check_adam(r, 'G3 64x128, all products on the fp32 MFMA', 0)
+    finally:
+        E.tune('gemm_mode', 1)
+        E.tune('persist', 1)
+
+
 # --------------------------------------------------------------------------------------------- the same comparison WITHOUT the ReLU hand-over
 @pytest.mark.parametrize('case', [('G3', 16, 128, 64), ('G3', 64, 128, 64), ('G3', 64, 192, 96), ('G6', 32, 192, 96)],
                          ids=['g3_b16_t128', 'g3_b64_t128', 'g3_b64_t192', 'g6_b32_t192'])
