@@ -217,6 +217,12 @@ int ss_op_lstm_fwd(float* gates_dev, const float* whh_f_dev, const float* whh_b_
 /* BPTT of the same: d_out [B,T+4,2H]; gates is replaced by the pre-activation gradients. */
 int ss_op_lstm_bwd(float* gates_dev, const float* whh_f_dev, const float* whh_b_dev, const float* d_out_dev,
                    const float* csave_dev, float* scratch_dev, long scratch_floats, int B, int T, int H, void* stream);
+/* Test hook for the fused weight / bias gradient kernel of the encoder BLSTMs (csrc/lstm_wgrad.hip; hidden size <= 32): from the pre-activation
+ * gradients dg [R][8H], the layer input x [R][In] (row stride x_ld) and the layer output hout [R][2H] (haloed slabs flattened to R rows, halo
+ * rows zero) ACCUMULATE dW_ih [2][4H][In], dW_hh [2][4H][H] and the bias gradients gb [2][2][4H] (b_ih, b_hh per direction).  scratch:
+ * >= 16 * 4096 * tiles + 64 floats with tiles = ceil(8H / 64) * (ceil(In / 64) + (H >= 16 ? 1 : 2)). */
+int ss_op_lstm_wgrad(const float* dg_dev, const float* x_dev, long x_ld, const float* hout_dev, float* gwih_dev, float* gwhh_dev, float* gb_dev,
+                     float* scratch_dev, long scratch_floats, long R, int H, int In, void* stream);
 /* The GEMM over operand images (speechsplit_amd/csrc/gemm_img.hip), the engine's default for every large contraction: an IMAGE has the
  * geometry of its fp32 matrix (4 bytes per element) with every aligned group of 8 elements along the contiguous axis replaced by 16 bytes of
  * hi pieces and 16 bytes of lo pieces of the fp16 x 2 split of scale * x (scale a power of two).

@@ -64,6 +64,7 @@ SYMBOLS = {
     'ss_op_gemm': (_i, [_fp, _l, _fp, _l, _fp, _l, _fp, _i, _i, _i, _i, _i, _vp]),
     'ss_op_lstm_fwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _l, _i, _i, _i, _vp]),
     'ss_op_lstm_bwd': (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _l, _i, _i, _i, _vp]),
+    'ss_op_lstm_wgrad': (_i, [_fp, _fp, _l, _fp, _fp, _fp, _fp, _fp, _l, _l, _i, _i, _vp]),
     'ss_op_split_image': (_i, [_fp, _l, _l, _i, _f, _fp, _l, _vp]),
     'ss_op_gemm_img': (_i, [_fp, _l, _fp, _l, _fp, _l, _fp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _l, _fp, _vp, _vp]),
     'ss_op_conv_block_scratch': (_l, [_i, _i, _i, _i]),

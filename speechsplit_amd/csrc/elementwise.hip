@@ -201,7 +201,9 @@ __global__ __launch_bounds__(256, MAXIT <= 12 ? 3 : 2) void gn_relu_bwd_kernel(c
                                                           float* __restrict__ g_beta, float* __restrict__ g_bias,
                                                           unsigned* __restrict__ amax, float* __restrict__ part, int B, int T, int C,
                                                           const float* __restrict__ src, long src_ld, long src_bs, int P,
-                                                          const float* __restrict__ lam, const int* __restrict__ start) {
+                                                          const float* __restrict__ lam, const int* __restrict__ start, float* __restrict__ dy_img) {
+    // dy_img (nullable; 16-bit data path): the conv-output gradient once more as a plain bf16 tensor of dy's geometry (the operand image of the
+    // block's weight- and input-gradient contractions), written here instead of by a pass of its own over the slab
     // src (nullable): the gradient of the RESAMPLED block output [P rows at src, first real row / first column of the block] -- the adjoint of
     // the training forward's gather (interp.hip interp_scatter_kernel, same terms in the same order: bit-identical) is then taken on the fly
     // instead of being read from dy, which is only written
@@ -294,6 +296,7 @@ __global__ __launch_bounds__(256, MAXIT <= 12 ? 3 : 2) void gn_relu_bwd_kernel(c
                 amx = fmaxf(amx, fabsf(o[j]));
             }
             *reinterpret_cast<f32x4*>(db + (long)t * dy_ld) = o;
+            if (dy_img) ss_store_img4(dy_img, b * dy_bs + (long)(HALO + t) * dy_ld + c, o[0], o[1], o[2], o[3], 1.0f, 1);
         }
     }
 #pragma unroll
@@ -801,15 +804,16 @@ hipError_t gn_relu_gather(const float* x, long x_ld, long x_bs, float* y, long y
 
 hipError_t gn_relu_bwd(const float* x, long x_ld, long x_bs, float* dy, long dy_ld, long dy_bs, const float* gamma,
                        const float* beta, const float* stats, float* g_gamma, float* g_beta, float* g_bias, float* amax, float* part,
-                       int B, int T, int C, hipStream_t s, const InterpPlan* scatter, const float* src, long src_ld, long src_bs) {
+                       int B, int T, int C, hipStream_t s, const InterpPlan* scatter, const float* src, long src_ld, long src_bs, float* dy_img) {
     if (C % 64 != 0 || T > 16 * GN_MAXIT) return hipErrorInvalidValue;
+    if (dy_img && (dy_ld % 8 || dy_bs % 8 || (((size_t)dy_img) & 7))) return hipErrorInvalidValue;
     if (scatter && (!src || scatter->T != T || scatter->P > 16 * GN_MAXIT + 2 || src_ld % 4 || src_bs % 4 || (((size_t)src) & 15))) return hipErrorInvalidValue;
     if (!g_deterministic && !g_gn_part) part = nullptr;
     // (an 8-iteration instantiation for T <= 128 makes hipcc hoist every source-row load: 418 registers unbounded, spills when bounded)
     auto kern = T <= 192 ? gn_relu_bwd_kernel<12> : gn_relu_bwd_kernel<GN_MAXIT>;
     hipLaunchKernelGGL(kern, dim3(C / 64, B), dim3(256), 0, s, x, x_ld, x_bs, dy, dy_ld, dy_bs, gamma, beta,
                        stats, g_gamma, g_beta, g_bias, reinterpret_cast<unsigned*>(amax), part, B, T, C, scatter ? src : nullptr, src_ld, src_bs,
-                       scatter ? scatter->P : 0, scatter ? scatter->lam : nullptr, scatter ? scatter->start : nullptr);
+                       scatter ? scatter->P : 0, scatter ? scatter->lam : nullptr, scatter ? scatter->start : nullptr, dy_img);
     if (part) hipLaunchKernelGGL(gn_part_reduce_kernel, dim3(cdiv(3 * C, 256)), dim3(256), 0, s, part, B, C, g_gamma, g_beta, g_bias);
     return hipGetLastError();
 }

@@ -52,6 +52,7 @@ int g_bf16_img = 1;        // SS_PRECISION_BF16: the 16-bit data path (round 4) 
                            // single-piece form of the image GEMM; 0: round 3's bf16 mode (fp32 slabs, operands rounded inside the GEMM)
 int g_seq_hi = 1;          // ... and the persistent recurrences multiply the high fp16 pieces only (one MFMA per product, half the forward's payload)
 int g_bf16_img_mask = ~0;  // ... per profile class (bit SS_PROF_*), for A/B runs
+int g_wgrad_fused = 1;     // the encoder BLSTMs' weight and bias gradients (H <= 32) in one fused fp32 launch (lstm_wgrad.hip) instead of 12-14 tiny GEMMs + column sums
 int g_pack_one = 1;        // every conv block's per-step weight re-layout in one launch at the start of the forward (conv_pack_many)
 int g_presplit = 7;        // weights (and, bit 1, the decoder's hidden states) reach the fp16 x 2 GEMMs as pre-split images: bit 0 weights, bit 1 the decoder's hidden states, bit 2 the trunk's resampled activations
 int g_compact0 = 1;        // decoder layer 0: input projections, input gradient and W_ih gradient once per block of repeated input frames
@@ -242,6 +243,9 @@ struct ss_engine {
     unsigned* colsum_ctr = nullptr;
     static constexpr int COLSUM_CTRS = 2048;
     int colsum_next = 0;
+    // encoder-BLSTM weight gradients waiting for their fused launch (lstm_wgrad.hip): lstm_weight_grads appends, wgrad_flush launches
+    WgradTable wg{};
+    bool wg_defer = false;                 // backward_encoder collects every small block's layers and flushes once at the end
     int wq_next = 0;
     static constexpr int WQ_SLOTS = 16;
     int dec_ih_done = 0;                   // bit l: decoder layer l's W_ih gradient went out beside a recurrence (lstm_late_weights skips it)
@@ -756,6 +760,30 @@ bool colsum_scratch(ss_engine* e, int cols, double** part, unsigned** ctr) {
     return true;
 }
 
+// launch the pending encoder-BLSTM weight-gradient tasks (one kernel for all of them) on `st`: everything they read must be complete in
+// st's order.  Scratch: partial tiles from the step's bump allocator, arrival counters from the column sums' ring.
+int wgrad_flush(ss_engine* e, hipStream_t st) {
+    if (e->wg.n == 0) return 0;
+    WgradTable& w = e->wg;
+    w.row_groups = 16;
+    const long need = (long)w.tiles_total * w.row_groups * 4096;
+    if (!e->part || !e->colsum_ctr || w.tiles_total > ss_engine::COLSUM_CTRS || e->part_off + need > e->part_cap) {
+        w.n = 0;
+        w.tiles_total = 0;
+        return fail("wgrad_flush: no scratch left for the fused encoder-BLSTM weight gradients (ss_tune(\"wgrad_fused\", 0) selects the GEMM path)");
+    }
+    w.part = e->part + e->part_off;
+    e->part_off += (need + 63) & ~63L;
+    if (e->colsum_next + w.tiles_total > ss_engine::COLSUM_CTRS) e->colsum_next = 0;
+    w.ctr = e->colsum_ctr + e->colsum_next;
+    e->colsum_next += w.tiles_total;
+    const hipError_t rc = lstm_small_wgrad(w, st);
+    w.n = 0;
+    w.tiles_total = 0;
+    HIPCHK(rc);
+    return 0;
+}
+
 // every contraction of the engine honours its precision mode (ss_set_precision)
 int gemm_on(ss_engine* e, GemmDesc& d, hipStream_t st) {
     if (e->precision == SS_PRECISION_BF16) d.flags |= GEMM_BF16;
@@ -1078,18 +1106,21 @@ int conv_block_bwd(ss_engine* e, ConvBlk& cb, Slab dy, Slab x, Slab dx, hipStrea
     const int B = e->curB, T = e->curT;
     const long TP = T + 2 * HALO, R = (long)B * TP;
     float* am = (g_bwd_f16x2 && cb.amax_i >= 0) ? e->amax + cb.amax_i : nullptr;
-    HIPCHK(gn_relu_bwd(cb.cout, cb.Co, TP * cb.Co, dy.p, dy.ld, TP * dy.ld, e->P + cb.ga, e->P + cb.be, cb.stats,
-                       e->G + cb.ga, e->G + cb.be, e->G + cb.b, am, cb.part, B, T, cb.Co, s, scatter, src, src_ld, TP * src_ld));
-    // the conv-output gradient as an image for the image GEMM (scale: the power of two for the maximum gn_relu_bwd has just measured)
-    const float* dimg = nullptr;
-    const float* dsc = nullptr;
     const bool i16 = e->img16();
-    if (g_img && (i16 || ((g_img_mask & ((1 << SS_PROF_CONV_DW) | (1 << SS_PROF_CONV_DX))) && am && e->precision == SS_PRECISION_F32)) && cb.Co % 8 == 0 && dy.ld % 8 == 0) {
+    // 16-bit data path: the GroupNorm backward writes the gradient's bf16 image itself (the image's halo rows are zero since the geometry
+    // was planned and nobody writes them); fp32 mode: a split_image pass with the scale gn_relu_bwd has just measured
+    float* im16 = (i16 && g_img && cb.Co % 8 == 0 && dy.ld % 8 == 0) ? grad_img_of(e, dy.p, R) : nullptr;
+    HIPCHK(gn_relu_bwd(cb.cout, cb.Co, TP * cb.Co, dy.p, dy.ld, TP * dy.ld, e->P + cb.ga, e->P + cb.be, cb.stats,
+                       e->G + cb.ga, e->G + cb.be, e->G + cb.b, am, cb.part, B, T, cb.Co, s, scatter, src, src_ld, TP * src_ld, im16));
+    // the conv-output gradient as an image for the image GEMM (scale: the power of two for the maximum gn_relu_bwd has just measured)
+    const float* dimg = im16;
+    const float* dsc = nullptr;
+    if (!i16 && g_img && (g_img_mask & ((1 << SS_PROF_CONV_DW) | (1 << SS_PROF_CONV_DX))) && am && e->precision == SS_PRECISION_F32 && cb.Co % 8 == 0 && dy.ld % 8 == 0) {
         float* im = grad_img_of(e, dy.p, R);
         if (im) {
-            HIPCHK(split_image(dy.p, dy.ld, R, cb.Co, am, 0.f, im, dy.ld, e->gscale + cb.amax_i, s, i16));
+            HIPCHK(split_image(dy.p, dy.ld, R, cb.Co, am, 0.f, im, dy.ld, e->gscale + cb.amax_i, s));
             dimg = im;
-            dsc = i16 ? nullptr : e->gscale + cb.amax_i;
+            dsc = e->gscale + cb.amax_i;
         }
     }
     // weight gradient: one reduction over every slab row (halo rows of dy are zero); cb.gp was zeroed by zero_conv_grads
@@ -1364,6 +1395,17 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
     const int In = lb.in_of(l);
     float* dG = lb.gates[l];
     const LstmDir &p0 = lb.pd[l * 2], &p1 = lb.pd[l * 2 + 1];
+    if (!lb.big() && g_wgrad_fused && H <= 32 && !bias_done && e->part && e->colsum_ctr && e->wg.n < WGRAD_MAX &&
+        e->part_off + (long)(e->wg.tiles_total + lstm_small_wgrad_tiles(H, In)) * 16 * 4096 <= e->part_cap) {
+        // encoder BLSTMs: one fused fp32 kernel for the weight and bias gradients of every layer (lstm_wgrad.hip)
+        WgradTask& t = e->wg.t[e->wg.n];
+        t = WgradTask{dG, xi.p, xi.ld, lb.out[l], e->G + p0.wih, e->G + p1.wih, e->G + p0.whh, e->G + p1.whh, e->G + p0.bih, e->G + p0.bhh, e->G + p1.bih,
+                      e->G + p1.bhh, H, In, R, e->wg.tiles_total};
+        e->wg.tiles_total += lstm_small_wgrad_tiles(H, In);
+        ++e->wg.n;
+        if (!e->wg_defer) CHK(wgrad_flush(e, ws));
+        return 0;
+    }
     const bool compact = l == 0 && lb.xf && xi.p == lb.xc;     // dW_ih from the block sums and one input row per block (K / xf)
     // the hidden-state slabs of a decoder-size block on the persistent kernels also exist as pre-split images (written by the forward)
     const bool img_ok = lb.out_img_valid && lb.out_img[l];
@@ -2087,6 +2129,13 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
     // Encoder_t's whole backward) follow below, each ordered behind its producer by an event that was recorded when the producer
     // was enqueued.
     const bool prio = par && g_prio_order && !g_graph && !e->l2.big() && !e->l1.big() && !e->lt.big();
+    struct WgDefer {           // the small blocks' weight gradients of this backward: collected, launched once on b3 below (prio schedule)
+        ss_engine* e;
+        ~WgDefer() { e->wg_defer = false; e->wg.n = 0; e->wg.tiles_total = 0; }
+    } wg_scope{e};
+    e->wg.n = 0;
+    e->wg.tiles_total = 0;
+    e->wg_defer = prio;
     if (par) {
         if (prio) HIPCHK(hipEventRecord(e->ev_join[2], s));                 // dec_in_grad done: what Encoder_t's backward needs
         CHK(fork_join(e, s, b2));
@@ -2186,9 +2235,12 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
             HIPCHK(hipStreamWaitEvent(b3, e->ev_join[3], 0));
             CHK(lstm_late_weights(e, e->l1, Slab{e->xf[2], CE, nullptr, e->act_scale + e->c1[2].scale_i}, b3));
         }
+        CHK(wgrad_flush(e, b3));                   // lstm_2 and both layers of lstm_1: one launch, beside the trunk's backward
         HIPCHK(hipStreamWaitEvent(b3, e->ev_join[2], 0));                   // d_ot from dec_in_grad
         CHK(lstm_bwd(e, e->lt, e->d_ot, Slab{e->act_t, h.dim_enc_2, nullptr, e->act_scale + e->ct.scale_i}, Slab{e->d_act_t, h.dim_enc_2}, b3));
         CHK(conv_block_bwd(e, e->ct, Slab{e->d_act_t, h.dim_enc_2}, Slab{e->org, h.dim_freq}, Slab{nullptr, 0}, b3));
+        CHK(wgrad_flush(e, b3));                   // Encoder_t's BLSTM
+        e->wg_defer = false;
     }
     if (par) CHK(fork_join(e, b3, s));
     CHK(join_side(e, s));
@@ -2334,7 +2386,7 @@ long ss_arena_numel(const ss_engine* e) { return e->arena; }
 
 // split-K scratch of the image GEMM behind the planned workspace (never zeroed, independent of the geometry): partial slabs have the
 // size of weight tensors, so 16 arenas' worth holds a step's launches at ksplit <= 8 with room to spare
-static long part_floats(const ss_engine* e) { return e->kind == SS_INTERP_ONLY ? 0 : 16 * ((e->arena + 63) & ~63L); }
+static long part_floats(const ss_engine* e) { return e->kind == SS_INTERP_ONLY ? 0 : 16 * ((e->arena + 63) & ~63L) + (32L << 20); }      // + 32 M floats: the small generator's deterministic mode, column sums, fused encoder weight gradients
 static long plan_bytes(const ss_engine* e) {
     ss_engine tmp = *e;             // dry run on a copy: carve() assigns the slab pointers
     return (tmp.carve(e->maxB, e->maxT, false) + 255) & ~255L;
@@ -2912,6 +2964,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "bf16_img_mask") g_bf16_img_mask = value;
     else if (k == "seq_hi" && (value == 0 || value == 1)) g_seq_hi = value;
     else if (k == "pack_one" && (value == 0 || value == 1)) g_pack_one = value;
+    else if (k == "wgrad_fused" && (value == 0 || value == 1)) g_wgrad_fused = value;
     else if (k == "img" && (value == 0 || value == 1)) g_img = value;
     else if (k == "img_mask" && value >= 0 && value < 2048) g_img_mask = value;
     else if (k == "img_batch" && (value == 0 || value == 1)) g_img_batch = value;
@@ -3011,6 +3064,24 @@ int ss_op_lstm_bwd(float* gates, const float* whh_f, const float* whh_b, const f
     } else {
         HIPCHK(lstm_small_bwd(gates, whh_f, whh_b, d_out, csave, B, T, H, s));
     }
+    return 0;
+}
+
+int ss_op_lstm_wgrad(const float* dg, const float* x, long x_ld, const float* hout, float* gwih, float* gwhh, float* gb, float* scratch, long scratch_floats,
+                     long R, int H, int In, void* stream) {
+    if (H < 1 || H > 32 || In < 1 || R < 1) return fail("ss_op_lstm_wgrad: H in 1..32, In >= 1");
+    WgradTable w{};
+    w.n = 1;
+    w.tiles_total = lstm_small_wgrad_tiles(H, In);
+    w.row_groups = 16;
+    const long need = (long)w.tiles_total * w.row_groups * 4096, ctr_floats = (w.tiles_total + 63) & ~63L;
+    if (!scratch || scratch_floats < need + ctr_floats) return fail("ss_op_lstm_wgrad: scratch too small");
+    w.part = scratch;
+    w.ctr = (unsigned*)(scratch + need);
+    HIPCHK(hipMemsetAsync(w.ctr, 0, ctr_floats * 4, S(stream)));
+    // gwih [2][4H][In], gwhh [2][4H][H], gb [2][2][4H] (b_ih then b_hh per direction): accumulated into, as the engine's gradient arena is
+    w.t[0] = WgradTask{dg, x, x_ld, hout, gwih, gwih + 4L * H * In, gwhh, gwhh + 4L * H * H, gb, gb + 4L * H, gb + 8L * H, gb + 12L * H, H, In, R, 0};
+    HIPCHK(lstm_small_wgrad(w, S(stream)));
     return 0;
 }
 

@@ -52,7 +52,8 @@ hipError_t gn_relu_gather(const float* x, long x_ld, long x_bs, float* y, long y
 hipError_t gn_relu_bwd(const float* x, long x_ld, long x_bs, float* dy, long dy_ld, long dy_bs, const float* gamma,
                        const float* beta, const float* stats, float* g_gamma, float* g_beta, float* g_bias, float* amax, float* part,
                        int B, int T, int C, hipStream_t s,
-                       const InterpPlan* scatter = nullptr, const float* src = nullptr, long src_ld = 0, long src_bs = 0);
+                       const InterpPlan* scatter = nullptr, const float* src = nullptr, long src_ld = 0, long src_bs = 0,
+                       float* dy_img = nullptr);      // dy_img: dy also as a plain bf16 tensor (same geometry; halo rows are the caller's: zero)
 // test hook: mask [B, T, C] dense = 1.0f where the block's GroupNorm output is > 0 (the ReLU branch the kernels above take)
 hipError_t gn_relu_mask(const float* x, long x_ld, long x_bs, const float* gamma, const float* beta, const float* stats,
                         float* mask, int B, int T, int C, hipStream_t s);
@@ -220,6 +221,29 @@ hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, vo
 hipError_t lstm_seq_bwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, const float* d_out,
                         const float* csave, unsigned* sync, unsigned* sticky, float* amax, float* gbias_f, float* gbias_b, float* dgs, int xf,
                         int B, int T, int H, bool zero_state, bool time_major, hipStream_t s, float* dimg = nullptr, int hi = 0);      // dimg: the gradients also as a plain bf16 tensor (slab geometry); hi: products from the high fp16 pieces alone
+
+// ---- lstm_wgrad.hip: weight and bias gradients of the encoder BLSTMs (H <= 32), every layer of every block in one launch
+constexpr int WGRAD_MAX = 8;
+struct WgradTask {
+    const float* dG;          // pre-activation gradients [R][8H] (halo rows zero)
+    const float* X;           // the layer's input rows [R][In], row stride x_ld
+    long x_ld;
+    const float* Hout;        // the layer's output [R][2H] (halo rows zero)
+    float *gwih0, *gwih1;     // += dW_ih of the forward / reverse direction [4H][In]
+    float *gwhh0, *gwhh1;     // += dW_hh [4H][H]
+    float *gbih0, *gbhh0, *gbih1, *gbhh1;      // += bias gradients [4H] (b_ih and b_hh have the same gradient)
+    int H, In;
+    long R;
+    int tile0;                // first blockIdx.y of this task: lstm_small_wgrad_tiles(H, In) tiles each
+};
+struct WgradTable {
+    WgradTask t[WGRAD_MAX];
+    int n, tiles_total, row_groups;
+    float* part;              // scratch: tiles_total * row_groups * 4096 floats
+    unsigned* ctr;            // tiles_total arrival counters, zero at rest
+};
+int lstm_small_wgrad_tiles(int H, int In);
+hipError_t lstm_small_wgrad(const WgradTable& tb, hipStream_t s);
 
 // seq_gate: the stream goes on once the persistent recurrence that owns `sync` is resident (all groups through round 0), see lstm_seq.hip;
 // lstm_seq_free_xcds: how many of the 8 XCDs such a launch leaves free (0: none, or not a persistent shape)

@@ -470,6 +470,21 @@ def _slab(x):
     return s
 
 
+def lstm_wgrad(dg, x, hout):
+    """Test hook (ss_op_lstm_wgrad): the fused weight / bias gradient kernel of the encoder BLSTMs.  dg [R, 8H], x [R, In] (may be a
+    column view of a wider tensor), hout [R, 2H] -> (gw_ih [2, 4H, In], gw_hh [2, 4H, H], gb [2, 2, 4H])."""
+    lib = _capi.lib()
+    R, H8 = dg.shape
+    H, In = H8 // 8, x.shape[1]
+    dev = dg.device
+    tiles = ((8 * H + 63) // 64) * ((In + 63) // 64 + (1 if H >= 16 else 2))
+    scratch = torch.empty(16 * 4096 * tiles + 256, device=dev)
+    gwih, gwhh, gb = torch.zeros(2, 4 * H, In, device=dev), torch.zeros(2, 4 * H, H, device=dev), torch.zeros(2, 2, 4 * H, device=dev)
+    _capi.check(lib.ss_op_lstm_wgrad(_ptr(dg), _ptr(x), x.stride(0), _ptr(hout), _ptr(gwih), _ptr(gwhh), _ptr(gb), _ptr(scratch), scratch.numel(), R, H, In,
+                                     _stream()))
+    return gwih, gwhh, gb
+
+
 def blstm_layer(x, w_ih, w_hh, b_ih, b_hh, d_out=None):
     """Test hook: one bidirectional LSTM layer through ss_op_lstm_fwd / ss_op_lstm_bwd (the engine's recurrence kernels) with
     the input projection and the weight / input gradients on the engine's GEMM (ss_op_gemm).  w_ih etc. are (forward, reverse)

@@ -865,3 +865,32 @@ def test_image_gemm_bf16_single_piece(E, layout, cfg):
             ref += xs[tap:tap + rows].double().cpu() @ w[:, tap].double().t()
         c = E.gemm_img(xs, w.reshape(Co, 5 * Ci).cuda(), cfg=cfg, a_seg=(Ci, Ci), M=rows, K=5 * Ci)
         assert rel(c, ref) < 5e-6, cfg
+
+
+@pytest.mark.parametrize('shape', [(1, 128, 4 * 132), (8, 512, 8 * 132 + 3), (8, 16, 5 * 196), (32, 256, 6 * 196), (32, 100, 1000)],
+                         ids=['h1_in128', 'h8_in512', 'h8_in16', 'h32_in256', 'h32_in100_ragged'])
+def test_fused_encoder_blstm_weight_gradients(E, shape):
+    """csrc/lstm_wgrad.hip: dW_ih, dW_hh (h(t-1) = one slab row earlier / later per direction) and both bias gradients of an encoder BLSTM
+    layer in one fp32 launch, against float64 -- including an input that is a column view of a wider slab and row counts that are not
+    multiples of the chunk; run twice: the ordered float64 reduction makes it bit-reproducible."""
+    H, In, R = shape
+    g = torch.Generator().manual_seed(3 + H + In)
+    dg = torch.randn(R, 8 * H, generator=g) * 1e-3
+    dg[0] = 0
+    dg[-1] = 0                       # halo rows of a gradient slab are zero
+    wide = torch.randn(R, In + 24, generator=g)
+    hout = torch.tanh(torch.randn(R, 2 * H, generator=g))
+    hout[0] = 0
+    hout[-1] = 0
+    xd = wide.cuda()[:, 8:8 + In] if In % 4 == 0 else wide.cuda()[:, 3:3 + In]
+    x = wide[:, 8:8 + In] if In % 4 == 0 else wide[:, 3:3 + In]
+    gwih, gwhh, gb = E.lstm_wgrad(dg.cuda(), xd, hout.cuda())
+    d64, x64, h64 = dg.double(), x.double(), hout.double()
+    for d in range(2):
+        dd = d64[:, d * 4 * H:(d + 1) * 4 * H]
+        assert rel(gwih[d], dd.t() @ x64) < 2e-6, (shape, d)
+        ref_hh = dd[1:].t() @ h64[:-1, :H] if d == 0 else dd[:-1].t() @ h64[1:, H:]
+        assert rel(gwhh[d], ref_hh) < 2e-6, (shape, d)
+        assert rel(gb[d, 0], dd.sum(0)) < 2e-6 and torch.equal(gb[d, 0], gb[d, 1])
+    again = E.lstm_wgrad(dg.cuda(), xd, hout.cuda())
+    assert all(torch.equal(a, b) for a, b in zip((gwih, gwhh, gb), again))

@@ -9,6 +9,12 @@ run --frames 192
 run --model G6 --batch 32 --frames 192
 run --model G6 --batch 32 --frames 192 --precision bf16
 run --batch 32 --precision bf16
+run --batch 32 --precision bf16 --tune bf16_img=0
+run --batch 64 --precision bf16
+run --batch 64 --precision bf16 --tune bf16_img=0
+run --model G6 --batch 32 --frames 192 --precision bf16 --tune bf16_img=0
+run --batch 16
+run --batch 32
 run --force-dp
 run --force-dp --dp-backend torch
 run --tune deterministic=1
