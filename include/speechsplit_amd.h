@@ -283,8 +283,20 @@ int ss_tune(const char* key, int value);
  *       3-way truncation split x = h + m + l, 6 v_mfma_f32_32x32x16_bf16 per k-step, dropped terms <= 2^-24 relative.
  *     ss_tune("gemm_mode", 0): true fp32 MFMA (v_mfma_f32_32x32x2_f32), the A/B reference.
  *   Against fp64 the three measure 1.3-2.2e-6, 1.2e-6 and 1.3e-6 of max|C| (profiles/r02/f16x2_error.txt).
- * SS_PRECISION_BF16: operands rounded to bf16 (nearest-even) inside the GEMM, one MFMA, fp32 accumulation; storage, the
- *   recurrences (W_hh.h, cell state), GroupNorm, losses, resampling indices and Adam stay fp32 (BASELINE configs 3-5). */
+ *   ss_tune("gemm_mode", 0) together with ss_tune("persist", 0) (the decoder recurrences as one fp32-MFMA launch per time step) is the mode in
+ *   which EVERY product of the step is fp32-wide -- the reference's arithmetic; bench.py times it as alt_precisions.all_fp32_mfma.
+ * SS_PRECISION_BF16 (BASELINE configs 3-5) -- the 16-bit data path (round 4).  Whoever produces an operand of a large contraction also stores
+ *   it as a plain bf16 tensor of the same geometry (round to nearest even), and the contraction runs from there on the single-piece form of
+ *   the image GEMM (csrc/gemm_img.hip: one v_mfma_f32_32x32x16_bf16 per product, fp32 accumulation, no scales): packed conv weights and
+ *   stacked W_ih (per-step re-layouts), decoder hidden states (the forward recurrence's storing wave), resampled trunk activations (the
+ *   fused GroupNorm + gather), pre-activation gradients (the backward recurrence's storing wave), conv-output gradients (the GroupNorm
+ *   backward).  The persistent recurrences multiply the HIGH fp16 pieces of h and W_hh only (one v_mfma_f32_16x16x32_f16 per product, half the
+ *   hand-off payload, 11 significand bits per operand).  fp32 throughout: master weights, gradients' accumulation and the gradient arena,
+ *   cell state, gate pre-activations, GroupNorm statistics, losses, the resampling index path (bit-exact as in the fp32 mode), Adam.
+ *   Contractions without images (layer-0 convolutions over the 80 / 264-channel inputs, the decoder's 164-column layer-0 input, the head's
+ *   weights, the encoder BLSTM projections) round their fp32 operands to bf16 inside round 2's GEMM kernel; the encoder BLSTMs' weight
+ *   gradients are exact fp32 sums in both modes (csrc/lstm_wgrad.hip).  ss_tune("bf16_img", 0) / ("seq_hi", 0) select round 3's form of the
+ *   mode (fp32 slabs only, operands rounded inside the GEMM, fp16 x 2 recurrences) for A/B runs. */
 #define SS_PRECISION_F32 0
 #define SS_PRECISION_BF16 1
 int ss_set_precision(ss_engine* e, int precision);

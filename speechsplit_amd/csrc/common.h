@@ -206,6 +206,14 @@ __device__ __forceinline__ uint4 ss_split_group_s(float v0, float v1, float v2, 
 __device__ __forceinline__ float ss_sigmoid(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504f));
 }
+// The cell-candidate gate g = tanh(pre-activation) as 2 sigmoid(2x) - 1: one exp2 and one rcp like the other three gates.  Its ABSOLUTE error
+// (~1.5e-7) is what matters for g -- it enters the cell state as i * g beside terms of magnitude ~1 -- unlike tanh(c) below, whose RELATIVE error
+// at small |c| becomes the relative error of h.  `two` selects the form per lane: 2.0f for the g gate, 1.0f for a sigmoid gate (one code path
+// for the single-wave kernels whose lanes hold different gates).
+__device__ __forceinline__ float ss_gate(float x, float two) {
+    const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * two * -1.44269504f));
+    return __builtin_fmaf(two, r, 1.0f - two);            // two = 1: r;  two = 2: 2 r - 1
+}
 // tanh to ~3 ulp RELATIVE (round 4; before: 3e-7 absolute, i.e. 1e-6 relative where |x| ~ 0.1 .. 0.5 -- cell states live there -- which is
 // what put the engine's trained-state gradients 10x further from float64 than PyTorch's: the recurrences carry every rounding of their
 // non-linearities forward).  |x| < 0.7: p = tanh(x / 2) from the odd series through x^11 (|x / 2| < 0.35: next term 1.2e-8 relative; Estrin

@@ -616,7 +616,7 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_fwd_kernel(float* __re
                 for (int ww = 0; ww < NW; ++ww) s += rd[ww][g][jj][bi];
                 pre[g] = xg[g * 16] + s * (1.0f / (HSCALE * WSCALE));
             }
-            const float gi = sigmoidf_(pre[0]), gf = sigmoidf_(pre[1]), gg = ss_tanh(pre[2]), go = sigmoidf_(pre[3]);
+            const float gi = sigmoidf_(pre[0]), gf = sigmoidf_(pre[1]), gg = ss_gate(pre[2], 2.0f), go = sigmoidf_(pre[3]);
             c_state = gf * c_state + gi * gg;
             h_val = go * ss_tanh(c_state);
             // the hand-off payload: write-through, first (rows past B carry garbage nobody stores downstream)

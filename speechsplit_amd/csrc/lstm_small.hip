@@ -54,7 +54,7 @@ __global__ __launch_bounds__((4 * H > 64 ? 4 * H : 64)) void lstm_small_fwd_kern
             float acc = xn;
 #pragma unroll
             for (int k = 0; k < H; ++k) acc += w[k] * hs[k];
-            const float act = (n / H == 2) ? ss_tanh(acc) : sigmoidf_(acc);
+            const float act = ss_gate(acc, (n / H == 2) ? 2.0f : 1.0f);
             gs[n] = act;
             grow[(long)tau * (8 * H)] = act;
         }
@@ -200,7 +200,7 @@ __global__ __launch_bounds__((4 * H > 64 ? 4 * H : 64)) void lstm_small_fwd_lds_
             float acc = xs[s * 4 * H + n];
 #pragma unroll
             for (int k = 0; k < H; ++k) acc += w[k] * hs[k];
-            const float act = (n / H == 2) ? ss_tanh(acc) : sigmoidf_(acc);
+            const float act = ss_gate(acc, (n / H == 2) ? 2.0f : 1.0f);
             gs[n] = act;
             grow[(long)tau * (8 * H)] = act;
         }
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64) void lstm_small_fwd_wave_kernel(float* __restri
         if (s + 1 < T) xn = xs[(s + 1) * 4 * H + nn];         // next step's pre-activation: no dependence on this step
 #pragma unroll
         for (int k = 0; k < H; ++k) acc += w[k] * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h), k));
-        const float act = (nn / H == 2) ? ss_tanh(acc) : sigmoidf_(acc);
+        const float act = ss_gate(acc, (nn / H == 2) ? 2.0f : 1.0f);
         if (gate_thread) grow[(long)tau * (8 * H)] = act;
         // unit u's gates sit in lanes u, u+H, u+2H, u+3H; lanes >= H compute along (their c / h are never used)
         const int u = n & (H - 1);

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_step_fwd_kernel(float* __restric
             pre[g] = xg[g] + s;
         }
         const long o = ((long)b * TP + tau) * (2 * H) + dir * H + j;
-        const float gi = sigmoidf_(pre[0]), gf = sigmoidf_(pre[1]), gg = ss_tanh(pre[2]), go = sigmoidf_(pre[3]);
+        const float gi = sigmoidf_(pre[0]), gf = sigmoidf_(pre[1]), gg = ss_gate(pre[2], 2.0f), go = sigmoidf_(pre[3]);
         const float c = gf * cp + gi * gg;
         const float h = go * ss_tanh(c);
         grow[0] = gi;

@@ -4,9 +4,10 @@ What runs where.  Host (scipy / numpy, float64, as the reference): the 5th-order
 and backwards (`signal.filtfilt`, make_spect_f0.py:53) and the 1e-6 dither from the per-speaker generator (:54) -- a sequential
 recurrence over the waveform.  GPU (csrc/features.hip through the C ABI): STFT magnitude -> mel projection -> dB -> [0, 1]
 scaling, and the F0 normalisation.  The mel filter bank (`librosa.filters.mel`, make_spect_f0.py:15) is restated here from the published
-algorithm (`mel_filter_bank`: Slaney's Auditory-Toolbox mel scale and area normalisation, librosa's defaults) -- PARITY UNPINNED: librosa
-is absent in this environment, so nothing of the reference's could be run to produce a vector; the tests check the published
-properties only.  NOT built: RAPT (`pysptk.sptk.rapt`, :63 -- a third-party C algorithm with no source here): the raw F0 track is an input.
+algorithm (`mel_filter_bank`: Slaney's Auditory-Toolbox mel scale and area normalisation, librosa's defaults) -- parity against librosa itself
+is UNPINNED (it is absent in this environment, so nothing of the reference's could be run to produce a vector); the function is pinned against
+hand-computed closed-form values of the published definition for three filters (linear region, across 1 kHz, top band:
+tests/test_capi_host.py::test_mel_filter_bank_closed_form_slaney_values) and against its published properties.  NOT built: RAPT (`pysptk.sptk.rapt`, :63 -- a third-party C algorithm with no source here): the raw F0 track is an input.
 The spectrogram half is pinned by tests/golden/features.npz, generated from the reference's own `butter_highpass` / `pySTFT` /
 `speaker_normalization`."""
 import ctypes as C
@@ -43,7 +44,7 @@ def mel_filter_bank(sr=16000, n_fft=1024, n_mels=80, fmin=90.0, fmax=7600.0):
     """The basis make_spect_f0.py:15 takes from `librosa.filters.mel(16000, 1024, fmin=90, fmax=7600, n_mels=80)` (and transposes),
     restated from the published algorithm with librosa's defaults: n_mels + 2 band edges equally spaced on Slaney's mel scale, one
     triangle per band over the 1 + n_fft/2 FFT bin frequencies, each scaled by 2 / (its band's width in Hz) ('slaney' norm: unit area).
-    Returns float32 [n_mels, 1 + n_fft // 2]; `melspectrogram` wants its transpose.  PARITY UNPINNED (see the module docstring)."""
+    Returns float32 [n_mels, 1 + n_fft // 2]; `melspectrogram` wants its transpose.  Pinned against the closed form, not against librosa (see the module docstring)."""
     fft_f = np.linspace(0.0, sr / 2.0, 1 + n_fft // 2)
     mel_f = _mel_to_hz(np.linspace(_hz_to_mel(fmin), _hz_to_mel(fmax), n_mels + 2))
     fdiff = np.diff(mel_f)
