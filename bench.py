@@ -348,6 +348,7 @@ def main():
     dt = timed(args.steps, args.warmup, None if args.no_profile else [top, 'rec_fwd', 'rec_bwd'], PROF_EVERY)
     bracketed = (args.steps + PROF_EVERY - 1) // PROF_EVERY      # steps of the timed region that carried the brackets
     eng.check()                  # outside the timed region: no persistent kernel reported a bounded-wait expiry
+    fallbacks = eng.scratch_fallbacks()      # launches that ran out of scratch and took a slower path: must be 0
     # data parallel, native path: where every bucket's collective sat relative to the end of the backward -- hipEvent brackets on the
     # communication stream (ss_dp_profile) over a few steps OUTSIDE the timed region; the record of the last one, from real RCCL kernels
     dp_coll = None
@@ -431,7 +432,7 @@ def main():
                        'products': PRODUCTS[args.precision]},
             'step_tflops': round(3 * 2 * (MAC_PER_FRAME_G3 if kind == 'G3' else MAC_PER_FRAME_G6) * mean_T * B * world / (dt / args.steps) / 1e12, 2),
             'roofline': roof, 'kernel_classes': classes, 'recurrence': recur, 'alt_precisions': alt,
-            'solver_loop': sl, 'dp_collectives': dp_coll,
+            'solver_loop': sl, 'dp_collectives': dp_coll, 'scratch_fallbacks': fallbacks,
             'cpu_baseline': None if args.no_cpu_baseline else cpu_baseline(T),
         }
         print(json.dumps(out), flush=True)

@@ -141,6 +141,10 @@ int ss_g6_dp_train_step(ss_engine* e, const float* mel_dev, const float* f0_oneh
  * backward on the main stream.  ss_dp_profile_read (synchronises) returns the number of collectives of the LAST step and, for up to
  * `cap` of them in enqueue order, four doubles each: arena offset (-1: the grouped rest at the backward's end), element count, start
  * and end in microseconds RELATIVE TO THE BACKWARD'S END (negative = the collective ran beside the backward).  out == NULL: count only. */
+/* Number of launches since ss_create that found the step's scratch (split-K partial slabs, column-sum partials, fused encoder weight gradients)
+ * exhausted and took their slower fallback (atomics / unsplit / one workgroup per column block).  0 in a healthy run: an undersized scratch shows
+ * up here instead of only in a profile. */
+long ss_scratch_fallbacks(const ss_engine* e);
 int ss_dp_profile(ss_engine* e, int on);
 int ss_dp_profile_read(ss_engine* e, double* out, int cap);
 

@@ -77,6 +77,7 @@ SYMBOLS = {
     'ss_set_precision': (_i, [_vp, _i]),
     'ss_profile': (_i, [_vp, C.c_uint]),
     'ss_profile_sample': (_i, [_vp, _i]),
+    'ss_scratch_fallbacks': (_l, [_vp]),
     'ss_dp_profile': (_i, [_vp, _i]),
     'ss_dp_profile_read': (_i, [_vp, C.POINTER(C.c_double), _i]),
     'ss_profile_read': (_i, [_vp, _i, C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

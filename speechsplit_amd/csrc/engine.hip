@@ -286,6 +286,7 @@ struct ss_engine {
     void* zeros = nullptr;                 // 1 KB of zero bytes (image GEMM: reduction rows past K)
     float* part = nullptr;                 // split-K partial slabs of the image GEMM: a bump allocator over part_cap floats, reset per step
     long part_cap = 0, part_off = 0;
+    long scratch_fallbacks = 0;            // launches that found the step's scratch exhausted and took the slower path (ss_scratch_fallbacks): 0 in a healthy run
     float* amax = nullptr;                 // [16] max |gradient| of the slabs the fp16 x 2 gradient GEMMs read: decoder layers 0..2, then the 7 convs
     long gp_bytes = 0;
     float *loss_part = nullptr;
@@ -727,7 +728,7 @@ int try_img_gemm(ss_engine* e, const GemmDesc& d, hipStream_t st) {
             g.ksplit = (int)ks;
             g.part = e->part + e->part_off;
             e->part_off += (need + 63) & ~63L;
-        }
+        } else if (need) ++e->scratch_fallbacks;      // the contraction runs unsplit
     } else {
         g.cfg = wgs(256, 256) >= 256 ? 0 : (wgs(256, 128) >= 224 ? 2 : 1);
     }
@@ -751,7 +752,10 @@ bool colsum_scratch(ss_engine* e, int cols, double** part, unsigned** ctr) {
     *ctr = nullptr;
     const long need = 2 * colsum_scratch_doubles(cols);          // in floats
     const int nb = cdiv(cols, 64);
-    if (!e->part || !e->colsum_ctr || nb > ss_engine::COLSUM_CTRS || e->part_off + need > e->part_cap) return false;
+    if (!e->part || !e->colsum_ctr || nb > ss_engine::COLSUM_CTRS || e->part_off + need > e->part_cap) {
+        ++e->scratch_fallbacks;
+        return false;
+    }
     *part = (double*)(e->part + e->part_off);                    // part_off is kept at multiples of 64 floats
     e->part_off += (need + 63) & ~63L;
     if (e->colsum_next + nb > ss_engine::COLSUM_CTRS) e->colsum_next = 0;
@@ -800,7 +804,7 @@ int gemm_on(ss_engine* e, GemmDesc& d, hipStream_t st) {
             if (e->part_off + need <= e->part_cap) {
                 d.part = e->part + e->part_off;
                 e->part_off += (need + 63) & ~63L;
-            }
+            } else ++e->scratch_fallbacks;            // atomics (or, deterministic mode, no split) instead of ordered slabs
         }
         HIPCHK(launch_gemm(d, st));
     }
@@ -1430,6 +1434,7 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
         GemmDesc a{};
         a.A = {dG, 8L * H, 4L * H, 0, 0};
         a.B = {xi.p, xi.ld, 0, 0, 0};
+        a.b_pre_scale = l == 0 ? xi.scale : nullptr;      // a conv block's output carries its own split scale (act_scales): right whichever product mode runs
         a.C = e->G + p0.wih;
         a.ldc = In;
         a.cstride = pstride;
@@ -2484,11 +2489,18 @@ struct AdamEarly {
         e->adam_early_gs = gs;
         e->adam_early_from = -1;
     }
-    ~AdamEarly() { e->adam_early = false; }
+    // A step that returns with an error behind the early range (decoder + head already updated on the side stream) must not leave the field
+    // set: a later ss_adam_step would then update [0, from) only, with that step's prepared state.  The failed step's partial update stands
+    // (its caller has an error in hand); the next optimiser call starts clean.
+    ~AdamEarly() {
+        e->adam_early = false;
+        e->adam_early_from = -1;
+    }
 };
 
 int ss_adam_step(ss_engine* e, float grad_scale, void* stream) {
     CHK(entry_check(e));
+    e->adam_early_from = -1;               // a stand-alone optimiser step always covers the whole arena
     Own own(e, stream);
     return adam_enqueue(e, grad_scale, own.s);
 }
@@ -2620,10 +2632,10 @@ static int g3_step_body(ss_engine* e, const float* mel, const float* f0, const f
         return 0;
     }
     {
-        AdamEarly ae(e, !(flags & SS_STEP_NO_ADAM), grad_scale);
+        AdamEarly ae(e, !(flags & SS_STEP_NO_ADAM), grad_scale);      // (its scope covers the optimiser call: the early range's bookkeeping ends with it)
         CHK(backward_core(e, s));                                                           // solver.py:170-171
+        if (!(flags & SS_STEP_NO_ADAM)) CHK(adam_enqueue(e, grad_scale, s));                // solver.py:172
     }
-    if (!(flags & SS_STEP_NO_ADAM)) CHK(adam_enqueue(e, grad_scale, s));                    // solver.py:172
     return 0;
 }
 
@@ -2740,8 +2752,8 @@ int ss_g6_train_step(ss_engine* e, const float* mel, const float* f0_onehot, con
     {
         AdamEarly ae(e, !(flags & SS_STEP_NO_ADAM), grad_scale);
         CHK(backward_core(e, s));
+        if (!(flags & SS_STEP_NO_ADAM)) CHK(adam_enqueue(e, grad_scale, s));
     }
-    if (!(flags & SS_STEP_NO_ADAM)) CHK(adam_enqueue(e, grad_scale, s));
     return 0;
 }
 
@@ -3493,6 +3505,8 @@ int ss_g3_dp_train_step(ss_engine* e, const float* mel, const float* f0, const f
     CHK(geometry(e, B, T, s));
     return dp_step(e, s, [&](hipStream_t st) { return g3_step_body(e, mel, f0, emb, len_org, scales, len_seg, B, T, 1.0f, SS_STEP_NO_ADAM, loss, st); });
 }
+
+long ss_scratch_fallbacks(const ss_engine* e) { return e ? e->scratch_fallbacks : -1; }
 
 int ss_dp_profile(ss_engine* e, int on) {
     if (!e) return fail("ss_dp_profile: null engine");

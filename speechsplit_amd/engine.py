@@ -236,6 +236,10 @@ class Engine:
         _capi.check(self.lib.ss_comm_init(self.h, buf, int(rank), int(world)))
         self.comm_world = int(world)
 
+    def scratch_fallbacks(self):
+        """Launches that found the step's scratch exhausted and took their slower path (ss_scratch_fallbacks); 0 in a healthy run."""
+        return int(self.lib.ss_scratch_fallbacks(self.h))
+
     def dp_profile(self, on=True):
         """hipEvent brackets round every collective of the native data-parallel steps (ss_dp_profile)."""
         _capi.check(self.lib.ss_dp_profile(self.h, 1 if on else 0))

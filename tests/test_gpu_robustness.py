@@ -102,21 +102,31 @@ def test_remote_abort_reaches_every_rank_through_the_status_slot(E):
     assert not torch.equal(eng.params, p0)
 
 
-def test_large_groupnorm_affine_trains_in_the_default_mode(E):
+@pytest.mark.parametrize('where', ['inner_blocks', 'last_blocks'])
+def test_large_groupnorm_affine_trains_in_the_default_mode(E, where):
     """Round-2 review: a GroupNorm gamma of 100 made the default (fp16 x 2) engine refuse every step.  The conv blocks' outputs now carry
     their own split scale, computed on the device from the block's affine parameters, so such weights train in the default mode and match
-    the oracle at the standing 1e-4 bars: loss, output, every gradient element, two Adam steps."""
+    the oracle at the standing 1e-4 bars: loss, output, every gradient element, two Adam steps.
+    last_blocks (round-3 advice): a large affine on the LAST block of each stack -- whose output scale feeds the BLSTM layer-0 projection and
+    the BLSTM weight gradients' activation operand (since round 4 exact fp32 sums, lstm_wgrad.hip; the GEMM fallback takes the scale too)."""
     B, T = 4, 128
     hp = W.default_hparams(max_len_pad=T)
     w = W.make_weights('G3', hp, 7)
-    w['encoder_1.convolutions_1.1.1.weight'][3] = 100.0        # gamma of one channel of a 512-channel block
-    w['encoder_1.convolutions_2.0.1.weight'][:] *= 300.0       # a whole block's gamma: its output scale drops below 16
-    w['encoder_2.convolutions.0.1.bias'][5] = -40.0
+    if where == 'inner_blocks':
+        w['encoder_1.convolutions_1.1.1.weight'][3] = 100.0        # gamma of one channel of a 512-channel block
+        w['encoder_1.convolutions_2.0.1.weight'][:] *= 300.0       # a whole block's gamma: its output scale drops below 16
+        w['encoder_2.convolutions.0.1.bias'][5] = -40.0
+    else:
+        w['encoder_1.convolutions_1.2.1.weight'][:] *= 300.0       # feeds lstm_1
+        w['encoder_1.convolutions_2.2.1.weight'][:] *= 300.0       # feeds lstm_2
+        w['encoder_2.convolutions.0.1.weight'][:4] *= 300.0        # Encoder_t's only block, feeds its BLSTM (max |gamma| sets the block's scale)
     eng = E.Engine('G3', hp, B, T)
     eng.load_weights(w)
     eng.set_adam(1e-4, 0.9, 0.999, 1e-8, 0)
     st = ref_model.TrainState(w)
-    for it in range(2):
+    # (last_blocks: one step -- Adam turns the encoder gradients' 1e-3 differences of that regime into +-lr differences of the weights, after
+    # which the two sides are no longer at the same point)
+    for it in range(2 if where == 'inner_blocks' else 1):
         mel, f0, emb, lens = synth_batch(50 + it, B, T, 64)
         draws = draws_for(60 + it, B, 4)
         loss = eng.g3_train_step(mel, f0, emb, lens, stack_draws(draws), no_adam=True)
@@ -133,8 +143,20 @@ def test_large_groupnorm_affine_trains_in_the_default_mode(E):
             ref_model.MASK, ref_model.MASK_STATS = None, None
         assert abs(float(loss) - float(lo)) <= 1e-5 * float(lo), (it, float(loss), float(lo))
         assert rel(out, ro) < 1e-4, it
-        worst = max((rel(grads[n], p.grad), n) for n, p in st.P.items())
-        assert worst[0] < 1e-4, (it, worst)
+        if where == 'inner_blocks':
+            worst = max((rel(grads[n], p.grad), n) for n, p in st.P.items())
+            assert worst[0] < 1e-4, (it, worst)
+        else:
+            # Activations 300x the usual size saturate the BLSTMs they feed: their gradients are differences of nearly equal totals (or
+            # numerically zero: Encoder_t's hidden size is 1), and the PyTorch-CPU oracle itself is 1e-4 .. 1e-3 away from the same step in
+            # float64 on every encoder tensor (checked on the CPU).  What this case is for is that nothing overflows or turns to garbage
+            # when a block's reduced split scale feeds the BLSTM path: status clean (above), loss and output at their bars (above), the
+            # decoder's gradients -- which see the encoder only through its bounded codes -- at 1e-4, the encoder's within 3e-3.
+            for n, p in st.P.items():
+                if float(p.grad.abs().max()) <= 1e-8:
+                    continue
+                e = rel(grads[n], p.grad)
+                assert e < (1e-4 if n.startswith('decoder.') else 3e-3), (it, n, e)
 
 
 def test_parameter_outside_fp16x2_range_is_refused(E):
