@@ -50,6 +50,7 @@ int g_cur_klass = -1;      // profile class of the contraction being launched (s
 int g_bf16_img = 1;        // SS_PRECISION_BF16: the 16-bit data path (round 4) -- operand images are plain bf16 tensors written by their producers (weights,
                            // hidden states, resampled activations, pre-activation / conv-output gradients) and the contractions over them run on the
                            // single-piece form of the image GEMM; 0: round 3's bf16 mode (fp32 slabs, operands rounded inside the GEMM)
+int g_seq_skip32 = 1;      // ... and a decoder layer whose gradient consumers all read the bf16 tensor does not get the fp32 copy of its pre-activation gradients
 int g_seq_hi = 1;          // ... and the persistent recurrences multiply the high fp16 pieces only (one MFMA per product, half the forward's payload)
 int g_bf16_img_mask = ~0;  // ... per profile class (bit SS_PROF_*), for A/B runs
 int g_wgrad_fused = 1;     // the encoder BLSTMs' weight and bias gradients (H <= 32) in one fused fp32 launch (lstm_wgrad.hip) instead of 12-14 tiny GEMMs + column sums
@@ -279,6 +280,7 @@ struct ss_engine {
     float* gp_all = nullptr;               // packed conv weight-gradient images (all blocks)
     // gradient slabs as images for the image GEMM: written by split_image with the measured scale (gscale[i] beside amax[i])
     float* dg_img[3] = {nullptr, nullptr, nullptr};       // decoder layers' pre-activation gradients [B, TP, 8H]
+    int dg32_skipped = 0;                                 // ... bit l = and NOT the fp32 slab: gates[l] still holds the forward's activated gates (gemm_on refuses to read it)
     int dg16_written = 0;                                 // 16-bit data path: bit l = decoder layer l's backward recurrence wrote dg_img[l] (plain bf16) in this backward
     float *d_img = nullptr, *d_img_t = nullptr;           // conv-output gradients of the trunk [B, TP, CE] / Encoder_t [B, TP, dim_enc_2]
     float* gscale = nullptr;               // [16]
@@ -795,6 +797,12 @@ int gemm_on(ss_engine* e, GemmDesc& d, hipStream_t st) {
     if (r < 0) return r;
     if (r == 0) {
         if (e->img16()) d.a_pre = d.b_pre = nullptr;        // plain bf16 tensors: not the format-v2 images round 2's kernel can take
+        if (e->dg32_skipped) {                              // a decoder layer's fp32 gradient slab was not written: nothing may read it as an operand
+            const long R8 = (long)e->curB * (e->curT + 2 * HALO) * 8L * e->ld.H;
+            for (int l = 0; l < e->ld.L && l < 3; ++l)
+                if (((e->dg32_skipped >> l) & 1) && ((d.A.p >= e->ld.gates[l] && d.A.p < e->ld.gates[l] + R8) || (d.B.p >= e->ld.gates[l] && d.B.p < e->ld.gates[l] + R8)))
+                    return fail("internal: a contraction fell back to the fp32 gradient slab of a decoder layer that was only written as bf16 (ss_tune(\"seq_skip32\", 0))");
+        }
         // split-K weight gradients: partial slabs + ordered reduce instead of fp32 atomics (ss_tune("part_splitk")), scratch from the step's bump allocator
         // (not for the encoder BLSTMs' tiny matrices: a one-block reduce over 32 slices is 17 us of latency, their atomics are nothing)
         if (g_part_splitk && d.ksplit > 1 && (d.flags & GEMM_TA) && (d.flags & GEMM_TB) && (d.flags & GEMM_ACCUM) && !d.row_period && !d.bias && d.N % 4 == 0 &&
@@ -1670,12 +1678,20 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
                     HIPCHK(slab_prewarm(dG, 8 * H, lb.csave[l], dcur, 2 * H, e->amax, B, T, false, e->side3));
                 }
                 const bool dg16 = e->img16() && g_img && &lb == &e->ld && l < 3 && e->dg_img[l] && nch == 1;
+                // only as bf16 when every reader takes the image: weight gradients and input gradient on the image GEMM (layers >= 1: aligned
+                // shapes, both images present; layer 0: compact form -- dW_ih and dX from the block sums, dW_hh from the image), bias sums in the
+                // kernel (not the deterministic mode's column sum over the fp32 slab), weight gradients deferred or not: same readers
+                const bool compact0 = l == 0 && lb.xf && dx.p == lb.d_xc;
+                const bool skip32 = dg16 && g_seq_skip32 && bias_in_kernel && lb.out_img_valid && lb.out_img[l] && g_img_batch &&
+                                    ((g_bf16_img_mask >> SS_PROF_DEC_DW) & 1) && ((g_bf16_img_mask >> SS_PROF_DEC_DX) & 1) &&
+                                    (l == 0 ? compact0 : (lb.wimg(l) != nullptr && (g_presplit & 1) && lb.in_of(l) % 64 == 0)) && H % 64 == 0;
                 const int pi = prof_begin(e, SS_PROF_REC_BWD, s, 2.0 * 2 * B * T * 4.0 * H * H);
                 HIPCHK(lstm_seq_bwd(dG, e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.px_l(l), dcur, lb.csave[l], lb.sync_b(l),
                                     e->sticky, am, bias_in_kernel ? e->G + lb.pd[l * 2].bih : nullptr,
                                     bias_in_kernel ? e->G + lb.pd[l * 2 + 1].bih : nullptr, (l == 0 && lb.xf && dx.p == lb.d_xc) ? lb.dgs : nullptr,
-                                    (l == 0 && lb.xf && dx.p == lb.d_xc) ? lb.xf : 0, B, T, H, false, false, s, dg16 ? e->dg_img[l] : nullptr, e->img16() && g_seq_hi));
+                                    (l == 0 && lb.xf && dx.p == lb.d_xc) ? lb.xf : 0, B, T, H, false, false, s, dg16 ? e->dg_img[l] : nullptr, (e->img16() && g_seq_hi ? 1 : 0) | (skip32 ? 4 : 0)));
                 if (dg16) e->dg16_written |= 1 << l;
+                if (skip32) e->dg32_skipped |= 1 << l;
                 prof_end(e, pi, s);
                 if (pw) CHK(fork_join(e, e->side3, s));
                 // XCD-aware weight gradients: this recurrence leaves XCDs free, the layer above is through -- its W_ih gradient runs beside it
@@ -2053,6 +2069,7 @@ int backward_decoder(ss_engine* e, hipStream_t s, bool late = false) {
     if (par) CHK(fork_join(e, s, b2));
     e->dec_ih_done = 0;
     e->dg16_written = 0;
+    e->dg32_skipped = 0;
     e->wq_next = 0;
     if (e->ld.big() && !prezeroed) {
         if (g_persist && lstm_seq_supported(e->curB, e->ld.H)) {
@@ -2975,6 +2992,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "bf16_img" && (value == 0 || value == 1)) g_bf16_img = value;
     else if (k == "bf16_img_mask") g_bf16_img_mask = value;
     else if (k == "seq_hi" && (value == 0 || value == 1)) g_seq_hi = value;
+    else if (k == "seq_skip32" && (value == 0 || value == 1)) g_seq_skip32 = value;
     else if (k == "pack_one" && (value == 0 || value == 1)) g_pack_one = value;
     else if (k == "wgrad_fused" && (value == 0 || value == 1)) g_wgrad_fused = value;
     else if (k == "img" && (value == 0 || value == 1)) g_img = value;

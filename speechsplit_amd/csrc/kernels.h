@@ -220,7 +220,7 @@ hipError_t lstm_seq_fwd(float* gates, const float* whh_f, const float* whh_b, vo
 // adds the sum over utterances and time of the pre-activation gradients to both halves (f32 atomics)
 hipError_t lstm_seq_bwd(float* gates, const float* whh_f, const float* whh_b, void* xbuf, const float* d_out,
                         const float* csave, unsigned* sync, unsigned* sticky, float* amax, float* gbias_f, float* gbias_b, float* dgs, int xf,
-                        int B, int T, int H, bool zero_state, bool time_major, hipStream_t s, float* dimg = nullptr, int hi = 0);      // dimg: the gradients also as a plain bf16 tensor (slab geometry); hi: products from the high fp16 pieces alone
+                        int B, int T, int H, bool zero_state, bool time_major, hipStream_t s, float* dimg = nullptr, int hi = 0);      // dimg: the gradients also as a plain bf16 tensor (slab geometry); hi bit 0: products from the high fp16 pieces alone, bit 2 (with dimg): the gradients ONLY as the bf16 tensor
 
 // ---- lstm_wgrad.hip: weight and bias gradients of the encoder BLSTMs (H <= 32), every layer of every block in one launch
 constexpr int WGRAD_MAX = 8;

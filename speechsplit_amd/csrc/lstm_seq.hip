@@ -817,7 +817,8 @@ __global__ __launch_bounds__(64 * (NW + 2)) void lstm_seq_bwd_kernel(float* __re
                         const int idx = lane + 64 * i, g = idx >> 6, u = (idx & 63) >> 2, q = idx & 3;
                         const f32x4 v = *reinterpret_cast<const f32x4*>(&da_st[g][u][4 * q]);
                         if (bt * 16 + u >= B) continue;
-                        *reinterpret_cast<f32x4*>(gates + row_of(bt * 16 + u, tau) * (8 * H) + dir * 4 * H + g * H + jt * 16 + 4 * q) = v;
+                        // (prio bit 31, with dimg only: every consumer of this layer's gradients reads the bf16 tensor -- the fp32 slab keeps the forward's gates)
+                        if (!((unsigned)prio >> 31)) *reinterpret_cast<f32x4*>(gates + row_of(bt * 16 + u, tau) * (8 * H) + dir * 4 * H + g * H + jt * 16 + 4 * q) = v;
                         if (dimg) ss_store_img4(dimg, row_of(bt * 16 + u, tau) * (8 * H) + dir * 4 * H + g * H + jt * 16 + 4 * q, v[0], v[1], v[2], v[3], 1.0f, 1);
                         if (gbias) {
 #pragma unroll
@@ -1118,7 +1119,8 @@ hipError_t lstm_seq_bwd(float* gates, const float* whh_f, const float* whh_b, vo
     unsigned char* xb = static_cast<unsigned char*>(xbuf);
     unsigned* am = reinterpret_cast<unsigned*>(amax);
     const dim3 grid(seq_slots(nbt) * (H / 16)), block(640);
-    const int pa = seq_prio_arg(time_major);
+    const int pa = seq_prio_arg(time_major, dimg != nullptr && (hi & 4) != 0);       // hi bit 2: skip the fp32 copy of the gradients (bit 31 of the kernel's prio word)
+    hi &= 1;
     if (hi) {
         if (H == 512) hipLaunchKernelGGL((lstm_seq_bwd_kernel<512, 8, true>), grid, block, 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, am, gbias_f, gbias_b, dgs, xf, B, T, nbt, pa, dimg);
         else          hipLaunchKernelGGL((lstm_seq_bwd_kernel<256, 8, true>), grid, block, 0, s, gates, whh_f, whh_b, xb, d_out, csave, sync, sticky, am, gbias_f, gbias_b, dgs, xf, B, T, nbt, pa, dimg);
