@@ -228,9 +228,18 @@ __global__ __launch_bounds__(256, MAXIT <= 12 ? 3 : 2) void gn_relu_bwd_kernel(c
     // of three dependent ones (start -> lam -> data), eight rows per thread in a row
     __shared__ int s_start[16 * GN_MAXIT + 2];
     __shared__ float s_lam[16 * GN_MAXIT + 2];
+    // ... and (round 4) the utterance's P source rows of this block's 64 channels themselves: a thread's rows each need 2-3 source rows, fetched
+    // one after the other behind data-dependent loop bounds -- twelve rows x three dependent HBM trips made the kernel latency-bound (60 us for
+    // 60 MB of traffic); one coalesced bulk copy with every load in flight, then the adjoint runs out of LDS (same terms, same order: bit-identical)
+    extern __shared__ __attribute__((aligned(16))) float gn_src[];      // [P][64] when src is given
     if (src) {
         for (int i = tid; i <= T; i += 256) s_start[i] = start[(long)b * (T + 1) + i];
         for (int i = tid; i < P && i < 16 * GN_MAXIT + 2; i += 256) s_lam[i] = lam[(long)b * P + i];
+        const float* sb0 = src + b * src_bs + blockIdx.x * 64;
+        for (int i = tid; i < P * 16; i += 256) {
+            const int r = i >> 4, q = i & 15;
+            *reinterpret_cast<f32x4*>(gn_src + r * 64 + q * 4) = *reinterpret_cast<const f32x4*>(sb0 + (long)r * src_ld + q * 4);
+        }
         __syncthreads();
     }
 #pragma unroll
@@ -242,19 +251,19 @@ __global__ __launch_bounds__(256, MAXIT <= 12 ? 3 : 2) void gn_relu_bwd_kernel(c
             if (src) {
                 const int* st = s_start;
                 const float* lm = s_lam;
-                const float* sb = src + b * src_bs + c;
+                const float* sb = gn_src + l16 * 4;
                 const int a0 = st[t], a1 = st[t + 1];
                 const int b0 = t > 0 ? st[t - 1] : 0, b1 = t > 0 ? a0 : 0;
                 dv = f32x4{0.f, 0.f, 0.f, 0.f};
                 for (int r = a0; r < a1; ++r) {
                     const float w = 1.0f - lm[r];
-                    const f32x4 g = *reinterpret_cast<const f32x4*>(sb + (long)r * src_ld);
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(sb + r * 64);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) dv[j] = __builtin_fmaf(w, g[j], dv[j]);
                 }
                 for (int r = b0; r < b1; ++r) {
                     const float w = lm[r];
-                    const f32x4 g = *reinterpret_cast<const f32x4*>(sb + (long)r * src_ld);
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(sb + r * 64);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) dv[j] = __builtin_fmaf(w, g[j], dv[j]);
                 }
@@ -811,7 +820,12 @@ hipError_t gn_relu_bwd(const float* x, long x_ld, long x_bs, float* dy, long dy_
     if (!g_deterministic && !g_gn_part) part = nullptr;
     // (an 8-iteration instantiation for T <= 128 makes hipcc hoist every source-row load: 418 registers unbounded, spills when bounded)
     auto kern = T <= 192 ? gn_relu_bwd_kernel<12> : gn_relu_bwd_kernel<GN_MAXIT>;
-    hipLaunchKernelGGL(kern, dim3(C / 64, B), dim3(256), 0, s, x, x_ld, x_bs, dy, dy_ld, dy_bs, gamma, beta,
+    const int lds = scatter ? scatter->P * 64 * 4 : 0;                    // the utterance's source rows of the block's 64 channels
+    if (lds > 40 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(C / 64, B), dim3(256), lds, s, x, x_ld, x_bs, dy, dy_ld, dy_bs, gamma, beta,
                        stats, g_gamma, g_beta, g_bias, reinterpret_cast<unsigned*>(amax), part, B, T, C, scatter ? src : nullptr, src_ld, src_bs,
                        scatter ? scatter->P : 0, scatter ? scatter->lam : nullptr, scatter ? scatter->start : nullptr, dy_img);
     if (part) hipLaunchKernelGGL(gn_part_reduce_kernel, dim3(cdiv(3 * C, 256)), dim3(256), 0, s, part, B, C, g_gamma, g_beta, g_bias);
