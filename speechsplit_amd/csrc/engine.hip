@@ -54,6 +54,11 @@ int g_seq_skip32 = 1;      // ... and a decoder layer whose gradient consumers a
 int g_seq_hi = 1;          // ... and the persistent recurrences multiply the high fp16 pieces only (one MFMA per product, half the forward's payload)
 int g_bf16_img_mask = ~0;  // ... per profile class (bit SS_PROF_*), for A/B runs
 int g_wgrad_fused = 1;     // the encoder BLSTMs' weight and bias gradients (H <= 32) in one fused fp32 launch (lstm_wgrad.hip) instead of 12-14 tiny GEMMs + column sums
+int g_trunk_bwd_par = 1;   // Encoder_7 backward: the pitch conv stack's blocks stay on the stream of lstm_2's backward (second branch stream), beside the content
+                           // stack on the main stream, through all three layers (the two stacks are independent chains; round 3 did this for layer 0 only).
+                           // 64 x 128 unchanged (that phase is throughput-bound), 32 x 128 bf16 3.16 -> 3.02 ms, 16 x 128 fp32 3.44 -> 3.29.
+                           // (Measured and rejected beside it: each block's weight-gradient GEMM on the side stream beside its input-gradient GEMM --
+                           // +8 % at B <= 32: the two cross-stream event hops per block cost more than the overlap gains.)
 int g_pack_one = 1;        // every conv block's per-step weight re-layout in one launch at the start of the forward (conv_pack_many)
 int g_presplit = 7;        // weights (and, bit 1, the decoder's hidden states) reach the fp16 x 2 GEMMs as pre-split images: bit 0 weights, bit 1 the decoder's hidden states, bit 2 the trunk's resampled activations
 int g_compact0 = 1;        // decoder layer 0: input projections, input gradient and W_ih gradient once per block of repeated input frames
@@ -2210,6 +2215,10 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
     // instead of every decoder bucket in front of (or behind) every trunk bucket.  (One GPU: the decoder's weight gradients stay behind
     // the trunk in enqueue order, see prio_order.)
     if (e->dp_on) CHK(dec_late(e->ld.L - 1));
+    // Encoder_7's content (512 ch) and pitch (256 ch) stacks are independent chains in the backward as in the forward (forward_core, trunk_indep):
+    // each block's output gradient comes from its own BLSTM / its own upper block, its input gradient goes to its own lower block, and the two
+    // write disjoint columns of the shared slabs.  With g_trunk_bwd_par the pitch chain never leaves the stream lstm_2's backward ran on.
+    const bool chain_par = g_trunk_bwd_par && training && g3 && par && !e->dp_on && !g_graph && (g_exp & 2) == 0 && g_gn_gather;
     // conv trunk, last layer first
     for (int i = 2; i >= 0; --i) {
         float* dy = e->d_xf;
@@ -2225,7 +2234,7 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
         float* dxbuf = training ? e->d_xf : e->d_act;
         // the resampled activations also exist as pre-split images when the forward's gathers wrote them (training, independent trunk chains)
         const float* bim = (training && e->xf_img_valid && i > 0) ? e->xf_img[i - 1] : nullptr;
-        if (i == 0 && g3 && par && !e->dp_on && !g_graph && (g_exp & 2) == 0) CHK(fork_join(e, s, b2));      // tail_par below: the pitch block's stream forks BEFORE the content block is enqueued
+        if (!chain_par && i == 0 && g3 && par && !e->dp_on && !g_graph && (g_exp & 2) == 0) CHK(fork_join(e, s, b2));      // tail_par below: the pitch block's stream forks BEFORE the content block is enqueued
         if (g3) {
             Slab x1 = i == 0 ? Slab{e->in_mel, h.dim_freq} : Slab{e->xf[i - 1], CE, bim, e->act_scale + e->c1[i - 1].scale_i};
             CHK(conv_block_bwd(e, e->c1[i], Slab{dy, CE}, x1, i > 0 ? Slab{dxbuf, CE} : Slab{nullptr, 0}, s, sc, sc_src, CE));
@@ -2234,10 +2243,10 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
         // Layer 0 is the step's tail: the decoder's weight gradients are through by then, and each of its two weight-gradient GEMMs alone
         // fills half the chip's workgroup slots -- the pitch block runs on the second branch stream beside the content block.  (Not under
         // data parallelism, where that stream carries the collectives.)
-        const bool tail_par = i == 0 && g3 && par && !e->dp_on && !g_graph && (g_exp & 2) == 0;
+        const bool tail_par = chain_par || (i == 0 && g3 && par && !e->dp_on && !g_graph && (g_exp & 2) == 0);
         hipStream_t s2 = tail_par ? b2 : s;
         CHK(conv_block_bwd(e, e->c2[i], Slab{dy + off2, CE}, x2, i > 0 ? Slab{dxbuf + off2, CE} : Slab{nullptr, 0}, s2, sc, sc_src + off2, CE));
-        if (tail_par) CHK(fork_join(e, b2, s));
+        if (tail_par && (!chain_par || i == 0)) CHK(fork_join(e, b2, s));      // (chain_par: the two chains meet once, behind layer 0)
         if (i > 0) {           // the two wide layers' parameters (weight, bias, GroupNorm affine: contiguous) are final; layer 0 rides the last bucket
             if (g3) CHK(dp_bucket(e, e->c1[i].w, e->c1[i].be + e->c1[i].Co - e->c1[i].w, s));
             CHK(dp_bucket(e, e->c2[i].w, e->c2[i].be + e->c2[i].Co - e->c2[i].w, s));
@@ -2994,6 +3003,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "seq_hi" && (value == 0 || value == 1)) g_seq_hi = value;
     else if (k == "seq_skip32" && (value == 0 || value == 1)) g_seq_skip32 = value;
     else if (k == "pack_one" && (value == 0 || value == 1)) g_pack_one = value;
+    else if (k == "trunk_bwd_par" && (value == 0 || value == 1)) g_trunk_bwd_par = value;
     else if (k == "wgrad_fused" && (value == 0 || value == 1)) g_wgrad_fused = value;
     else if (k == "img" && (value == 0 || value == 1)) g_img = value;
     else if (k == "img_mask" && value >= 0 && value < 2048) g_img_mask = value;
