@@ -1291,7 +1291,9 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
         }
         if (persist) {   // start state zeroed by lstm_prep
             // the input projections the GEMM has just written are read once more, in whole lines, beside the recurrence (lstm_seq.hip)
-            const bool pw = (g_prewarm & 2) && e->side3 && g_overlap && !g_graph && !compact;
+            // (worth it from ~48 utterances on: 64 x 128 -0.08 ms; at 32 and 16 the fork / join around the recurrence costs more than warm operands
+            // gain: 32 x 128 bf16 3.00 vs 2.97 ms without, 16 x 128 3.28 vs 3.26)
+            const bool pw = (g_prewarm & 2) && e->side3 && g_overlap && !g_graph && !compact && B > 32;
             if (pw) {
                 CHK(fork_join(e, s, e->side3));
                 HIPCHK(slab_prewarm(lb.gates[l], 8 * H, nullptr, nullptr, 2 * H, e->amax, B, T, false, e->side3));
