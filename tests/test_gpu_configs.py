@@ -367,8 +367,8 @@ def test_g6_small_fixture_elementwise_and_trajectory(E):
 BF16_BOUNDS = dict(loss=1e-3, out=4e-2, grad=2e-1, grad_median=2e-2)
 
 
-@pytest.mark.parametrize('case', [('G3', 32, 128, 64), ('G6', 32, 192, 96), ('G3', 64, 192, 96)],
-                         ids=['config3_g3_32x128', 'config4_g6_32x192', 'config5_g3_64x192'])
+@pytest.mark.parametrize('case', [('G3', 32, 128, 64), ('G6', 32, 192, 96), ('G3', 64, 192, 96), ('G3', 21, 136, 64), ('G6', 5, 104, 64)],
+                         ids=['config3_g3_32x128', 'config4_g6_32x192', 'config5_g3_64x192', 'ragged_g3_21x136', 'ragged_g6_5x104'])
 def test_bf16_mode_against_fp32_oracle(E, case):
     kind, B, T, len_lo = case
     c = Case(E, kind, B, T, len_lo, wseed=0 if kind == 'G3' else 4, bseed=700 + B + T, precision='bf16')
