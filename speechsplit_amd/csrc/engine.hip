@@ -2220,7 +2220,11 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
     // Encoder_7's content (512 ch) and pitch (256 ch) stacks are independent chains in the backward as in the forward (forward_core, trunk_indep):
     // each block's output gradient comes from its own BLSTM / its own upper block, its input gradient goes to its own lower block, and the two
     // write disjoint columns of the shared slabs.  With g_trunk_bwd_par the pitch chain never leaves the stream lstm_2's backward ran on.
-    const bool chain_par = g_trunk_bwd_par && training && g3 && par && !e->dp_on && !g_graph && (g_exp & 2) == 0 && g_gn_gather;
+    // Data parallel: that stream carries the collectives, so the pitch chain takes the third branch stream instead (behind the event of lstm_2's
+    // input gradient; Encoder_t's backward and the fused weight gradients queue behind it there).
+    const bool chain_par = g_trunk_bwd_par && training && g3 && par && !g_graph && (g_exp & 2) == 0 && g_gn_gather && (!e->dp_on || (prio && b3 != s && b3 != b2));
+    hipStream_t cs = e->dp_on ? b3 : b2;
+    if (chain_par && e->dp_on) HIPCHK(hipStreamWaitEvent(b3, e->ev_join[0], 0));      // d_xf's pitch columns (lstm_2's input gradient) and the zeroed conv images
     // conv trunk, last layer first
     for (int i = 2; i >= 0; --i) {
         float* dy = e->d_xf;
@@ -2246,12 +2250,12 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
         // fills half the chip's workgroup slots -- the pitch block runs on the second branch stream beside the content block.  (Not under
         // data parallelism, where that stream carries the collectives.)
         const bool tail_par = chain_par || (i == 0 && g3 && par && !e->dp_on && !g_graph && (g_exp & 2) == 0);
-        hipStream_t s2 = tail_par ? b2 : s;
+        hipStream_t s2 = tail_par ? (chain_par ? cs : b2) : s;
         CHK(conv_block_bwd(e, e->c2[i], Slab{dy + off2, CE}, x2, i > 0 ? Slab{dxbuf + off2, CE} : Slab{nullptr, 0}, s2, sc, sc_src + off2, CE));
-        if (tail_par && (!chain_par || i == 0)) CHK(fork_join(e, b2, s));      // (chain_par: the two chains meet once, behind layer 0)
+        if (tail_par && (!chain_par || (i == 0 && !e->dp_on))) CHK(fork_join(e, b2, s));      // (chain_par: the two chains meet once, behind layer 0; data parallel: where the third branch stream joins below)
         if (i > 0) {           // the two wide layers' parameters (weight, bias, GroupNorm affine: contiguous) are final; layer 0 rides the last bucket
             if (g3) CHK(dp_bucket(e, e->c1[i].w, e->c1[i].be + e->c1[i].Co - e->c1[i].w, s));
-            CHK(dp_bucket(e, e->c2[i].w, e->c2[i].be + e->c2[i].Co - e->c2[i].w, s));
+            CHK(dp_bucket(e, e->c2[i].w, e->c2[i].be + e->c2[i].Co - e->c2[i].w, s2));
             if (e->dp_on) CHK(dec_late(i == 2 ? (e->ld.L >= 3 ? e->ld.L - 2 : 0) : 0));      // next decoder layer(s) behind this trunk layer's buckets
         }
         if (!training && i > 0) {
