@@ -240,3 +240,18 @@ def test_mel_filter_bank_closed_form_slaney_values():
             assert nz[0] == 453 and nz[-1] == 486 and len(nz) == 34 and int(w[i].argmax()) == 469
         for k, v in vals.items():
             assert abs(float(w[i, k]) - v) <= 2e-6 * v + 1e-12, (i, k, float(w[i, k]), v)
+
+
+def test_roofline_traffic_profile_matches_kernel_sources():
+    """bench.py reports `roofline.traffic` from the committed rocprofv3 --pmc passes only while the GEMM kernel sources are the ones those
+    counters were read from (tools/kernel_sha.py); this test makes a stale profile a red test here instead of a silent null in the bench line."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    from kernel_sha import kernel_sources_sha
+    recs = json.load(open(os.path.join(root, 'profiles', 'r04', 'gemm_pmc.json')))
+    assert recs and all(r.get('kernel_sources_sha') == kernel_sources_sha() for r in recs), \
+        'profiles/r04/gemm_pmc.json is stale: rerun tools/run_profiles.sh (the PMC passes) after changing gemm_*.hip / common.h'
+    dw = [r for r in recs if r['class'] == 'dec_dw']
+    assert dw and all(r['hbm_read_bytes'] > 0 and r['hbm_write_bytes'] > 0 for r in dw)
