@@ -70,19 +70,8 @@ int g_op_time_major = 0;   // experiment: ss_op_lstm_fwd / _bwd take time-major 
 int g_persist = 1;     // 1: decoder recurrences run as ONE persistent launch per layer (lstm_seq.hip) when the batch fits
 int g_split = 0;       // 1: decoder recurrences run as two batch-half chains on two streams (GEMMs of one half fill the
                        //    machine while the other half sits in its latency-bound time loop)
-// hipGraph capture + replay of the fused training step (ss_tune("graph", 1)): measured no gain while the step is GPU-bound, and under
-// ROCm 7.2 hipGraphLaunch crashed inside the RUNTIME (hip::Graph::UpdateStreams <- hip::GraphExec::Run, gpurun_out/r02/gdb.txt) when the
-// captured step had one more parallel branch and the process had created other engines before.  Round 3 went through the engine's side
-// of that: every executable graph is destroyed (after a synchronise) BEFORE any stream of its engine (drop_graphs first in ss_destroy
-// and on every geometry / tuning change), a captured graph holds kernel nodes and edges, not the capture streams, and the streams the
-// probe destroys at ss_bind never took part in a capture -- nothing of ours outlives what it refers to; the faulting access is in the
-// runtime's own per-launch stream assignment.  The schedule is therefore NOT part of the product library: it exists in the -DSS_DIAG
-// build only (tools/host_enqueue.py), where g_graph is a variable; here it is the constant 0 and the capture path compiles away.
-#ifdef SS_DIAG
-int g_graph = 0;
-#else
-constexpr int g_graph = 0;
-#endif
+// (hipGraph capture + replay of the fused step: built and measured in rounds 1-3 -- no gain while the step is GPU-bound, and a crash inside
+// the ROCm 7.2 runtime's hipGraphLaunch with more parallel branches -- and deleted in round 4; the step is enqueued eagerly.)
 int g_own_streams = 0; // 1: every C-ABI call runs on the ENGINE's own main stream (created back to back with its three branch streams at
                        //    ss_bind), ordered behind the caller's stream on entry and in front of it on exit.  Built to make the step time
                        //    independent of how many streams the process created earlier -- it does not: HIP hands a new stream the
@@ -110,7 +99,6 @@ int g_adam_early = 1;   // one-GPU fused steps: the decoder + head range of Adam
 int g_exp = 0;         // bits that switch individual schedule choices back for same-box A/B runs (bench.py --tune exp=N); 0 in production
 int g_conv_par = 1;    // 1: the two conv streams of an Encoder_7 layer (and the layer's resampling plan) run on two engine streams in the forward
 int g_early_join = 1;  // 1: join events of branch streams are recorded right behind the last kernel the consumer needs (lstm_bwd's dx_ready)
-int g_tune_epoch = 0;  // bumped by ss_tune: captured graphs bake the knobs in, so they are dropped when it changes
 }
 
 namespace {
@@ -308,23 +296,10 @@ struct ss_engine {
     hipStream_t side = nullptr;
     hipStream_t side2 = nullptr;          // independent branches (per-step weight re-layouts, Encoder_t, second encoder BLSTM); second batch-half chain
     hipStream_t side3 = nullptr;          // third independent branch of the encoder backward (Encoder_t)
-    hipStream_t cap = nullptr;            // graphs are captured and replayed here (a legacy default stream cannot capture)
-    hipEvent_t ev_io[2] = {};             // caller stream <-> cap ordering
+    hipEvent_t ev_io[2] = {};             // caller stream <-> engine main stream ordering (own_streams)
     hipEvent_t ev_join[4] = {};           // events recorded early: [0] lstm_2 branch's input gradient, [1] decoder chain done, [2] dec_in_grad done, [3] lstm_1 chain done
     hipEvent_t ev_dec[2] = {};            // split step without join: decoder chain done (caller stream) / its weight gradients done (side)
     int dec_pending = 0;                  // 0 none, 1 ev_dec[0] only, 2 both
-    // captured training steps (hipGraph), keyed by geometry / flags / grad_scale; inputs are staged into engine-owned
-    // buffers so a replay does not depend on the caller's tensor addresses
-    struct StepGraph {
-        int B, T, flags;
-        float gs;
-        hipGraph_t g;
-        hipGraphExec_t x;
-    };
-    std::vector<StepGraph> graphs;
-    int graph_epoch = 0;
-    float *stg_mel = nullptr, *stg_f0 = nullptr, *stg_emb = nullptr, *stg_sc = nullptr, *stg_loss = nullptr;
-    int *stg_len = nullptr, *stg_ls = nullptr;
     hipEvent_t ev[16] = {};
     int ev_next = 0;
     bool side_used = false;
@@ -593,16 +568,6 @@ long ss_engine::carve(int B, int T, bool assign) {
     out_slab = slab("out", head_out);
     d_out_slab = slab("d_out", head_out);
     loss_part = (float*)take(((long)B * T + 8L * B) * 4);
-    {
-        const long S7 = hp.max_len_seq / hp.min_len_seg + 1;
-        stg_mel = (float*)take((long)B * T * hp.dim_freq * 4);
-        stg_f0 = (float*)take((long)B * T * 4);
-        stg_emb = (float*)take((long)B * hp.dim_spk_emb * 4);
-        stg_sc = (float*)take(4L * B * S7 * 4);
-        stg_ls = (int*)take(4L * B * S7 * 4);
-        stg_len = (int*)take((long)B * 4);
-        stg_loss = (float*)take(256);
-    }
     qidx = (int*)take((long)B * TP * 4);
     wq_pool = (unsigned*)take(WQ_SLOTS * 16);
     colsum_ctr = (unsigned*)take(COLSUM_CTRS * 4);
@@ -624,14 +589,6 @@ namespace {
 
 hipStream_t S(void* s) { return (hipStream_t)s; }
 
-void drop_graphs(ss_engine* e) {
-    if (!e->graphs.empty() && e->cap) (void)hipStreamSynchronize(e->cap);   // never destroy an executable graph in flight
-    for (auto& g : e->graphs) {
-        (void)hipGraphExecDestroy(g.x);
-        (void)hipGraphDestroy(g.g);
-    }
-    e->graphs.clear();
-}
 
 int geometry(ss_engine* e, int B, int T, hipStream_t s) {
     if (!e->ws) return fail("engine is not bound (call ss_bind first)");
@@ -652,7 +609,6 @@ int geometry(ss_engine* e, int B, int T, hipStream_t s) {
     e->curB = B;
     e->curT = T;
     e->have_fwd = false;
-    drop_graphs(e);
     return 0;
 }
 
@@ -995,7 +951,7 @@ void prof_tick(ss_engine* e) {
 
 // ss_profile: bracket one launch with hipEvents on the stream it is launched on
 int prof_begin(ss_engine* e, int klass, hipStream_t st, double flops) {
-    if (!((e->prof_mask >> klass) & 1u) || !e->prof_live || g_graph || e->prof_n >= ss_engine::PROF_CAP) return -1;
+    if (!((e->prof_mask >> klass) & 1u) || !e->prof_live || e->prof_n >= ss_engine::PROF_CAP) return -1;
     const int i = e->prof_n;
     while ((int)e->prof_ev.size() < 2 * (i + 1)) {
         hipEvent_t ev;
@@ -1293,7 +1249,7 @@ int lstm_big_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
             // the input projections the GEMM has just written are read once more, in whole lines, beside the recurrence (lstm_seq.hip)
             // (worth it from ~48 utterances on: 64 x 128 -0.08 ms; at 32 and 16 the fork / join around the recurrence costs more than warm operands
             // gain: 32 x 128 bf16 3.00 vs 2.97 ms without, 16 x 128 3.28 vs 3.26)
-            const bool pw = (g_prewarm & 2) && e->side3 && g_overlap && !g_graph && !compact && B > 32;
+            const bool pw = (g_prewarm & 2) && e->side3 && g_overlap && !compact && B > 32;
             if (pw) {
                 CHK(fork_join(e, s, e->side3));
                 HIPCHK(slab_prewarm(lb.gates[l], 8 * H, nullptr, nullptr, 2 * H, e->amax, B, T, false, e->side3));
@@ -1657,7 +1613,7 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
     const int nch = (lb.big() && !persist) ? make_chains(e, B, s, ch) : 1;
     if (lb.big() && nch == 2) CHK(fork_join(e, s, ch[1].st));
     // see ss_engine::wq_pool: only with the weight gradients deferred (their usual schedule), on the decoder, where XCDs stay free
-    const bool xcd = persist && &lb == &e->ld && g_xcd_dw && e->side && g_overlap && (g_defer_dw || late_w) && !g_graph && !g_deterministic &&
+    const bool xcd = persist && &lb == &e->ld && g_xcd_dw && e->side && g_overlap && (g_defer_dw || late_w) && !g_deterministic &&
                      lstm_seq_free_xcds(B, H) >= 2;
     bool xcd_split[4] = {false, false, false, false};
     for (int l = lb.L - 1; l >= 0; --l) {
@@ -1679,7 +1635,7 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
             if (persist) {
                 // activated gates and cell states of the forward pass are long gone from the caches: one streaming read beside the
                 // recurrence puts them into the memory-side cache ahead of its 64-byte requests (lstm_seq.hip, slab_prewarm_kernel)
-                const bool pw = (g_prewarm & 1) && e->side3 && g_overlap && !g_graph;
+                const bool pw = (g_prewarm & 1) && e->side3 && g_overlap;
                 if (pw) {
                     CHK(fork_join(e, s, e->side3));
                     HIPCHK(slab_prewarm(dG, 8 * H, lb.csave[l], dcur, 2 * H, e->amax, B, T, false, e->side3));
@@ -1825,7 +1781,7 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
     hipStream_t b1 = par ? e->side : s, b2 = par ? e->side2 : s;
     e->grads_zeroed = false;               // set again below when this forward belongs to a fused training step
     e->bwd_sync_zeroed = false;
-    const bool pack_one = g_pack_one && !g_graph;
+    const bool pack_one = g_pack_one;
     if (pack_one) {
         ConvPackTable pt{};
         pt.img_bf16 = e->img16();
@@ -1842,7 +1798,7 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
     }
     CHK(act_scales_all(e, s));             // before every branch forks: the scale words of the conv blocks' outputs
     if (par) CHK(fork_join(e, s, b2));
-    if (e->late_org && !g_graph) {
+    if (e->late_org) {
         const ss_hparams& hh = e->hp;
         HIPCHK(copy_rows(e->late_org, hh.dim_freq, (long)T * hh.dim_freq, e->org + HALO * hh.dim_freq, hh.dim_freq, TP * hh.dim_freq, B, T,
                          hh.dim_freq, b2));
@@ -1852,7 +1808,7 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
     // warp applied to the concatenation), and the plans depend on the draws alone.  With g_trunk_indep the plans are computed first thing
     // on the branch stream and the two stacks run as independent chains on `s` and `b1` -- conv, GroupNorm, gather of their OWN columns --
     // down to their BLSTMs, instead of meeting before every gather.
-    const bool indep = g3 && par && g_conv_par && g_trunk_indep && !g_graph;
+    const bool indep = g3 && par && g_conv_par && g_trunk_indep;
     e->xf_img_valid = indep && training && (g_presplit & 4) && e->xf_img[0] && ((e->precision == SS_PRECISION_F32 && g_fwd_f16x2) || (e->img16() && g_gn_gather));     // only fp16 x 2 / 16-bit-path GEMMs read images
     hipEvent_t plans = nullptr;
     if (indep && training) {
@@ -1879,7 +1835,7 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
     // persistent recurrences, the gradient-arena memset, the parameter guard, and Encoder_t (model.py:74-89).  With g_prio_order it
     // is ENQUEUED behind the trunk's three layers (it still runs beside them: the host is far ahead of the GPU), so that on a shared
     // hardware queue it can never sit in front of trunk launches.
-    const bool prio_fwd = par && g_prio_order && !g_graph;
+    const bool prio_fwd = par && g_prio_order;
     auto branch_work = [&]() -> int {
         PrepTable tb;
         tb.n = 0;
@@ -1889,7 +1845,7 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
         CHK(lstm_prep(e, e->lt, tb, b2));
         CHK(lstm_prep(e, e->ld, tb, b2));
         HIPCHK(prep_run(tb, b2));
-        if (e->prezero && !g_graph) {        // nothing touches the gradient arena before the decoder backward; b2 is joined long before
+        if (e->prezero) {        // nothing touches the gradient arena before the decoder backward; b2 is joined long before
             HIPCHK(hipMemsetAsync(e->G, 0, e->arena * 4, b2));
             HIPCHK(hipMemsetAsync(e->amax, 0, 16 * 4, b2));
             e->grads_zeroed = true;
@@ -1949,7 +1905,7 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
         }
         // The content (512 ch) and pitch (256 ch) blocks of a layer are independent: with g_conv_par the pitch block and the layer's
         // resampling plan run on the first branch stream beside the content block.
-        const bool cpar = g3 && par && g_conv_par && !g_graph;
+        const bool cpar = g3 && par && g_conv_par;
         hipStream_t sp = cpar ? b1 : s;
         if (cpar) CHK(fork_join(e, s, b1));
         if (g3) {
@@ -2091,7 +2047,7 @@ int backward_decoder(ss_engine* e, hipStream_t s, bool late = false) {
     // head.  Only its input gradient is on the critical path; when the decoder's weight gradients are deferred to the side
     // stream (lstm_bwd), the head's weight / bias gradients go with them instead of running in front of the first recurrence.
     const long HD = 2L * e->ld.H;
-    const bool defer_head = !g_graph && e->ld.big() && g_persist && lstm_seq_supported(B, e->ld.H) && e->side && g_overlap && g_defer_dw;
+    const bool defer_head = e->ld.big() && g_persist && lstm_seq_supported(B, e->ld.H) && e->side && g_overlap && g_defer_dw;
     late = late && defer_head;
     e->dec_w_pending = late;
     {
@@ -2125,7 +2081,7 @@ int backward_decoder(ss_engine* e, hipStream_t s, bool late = false) {
 // offsets below the decoder's, so a data-parallel caller can all-reduce the decoder range meanwhile.
 int backward_encoder(ss_engine* e, hipStream_t s) {
     e->unpack.n = 0;
-    e->unpack_later = !e->dp_on && !g_graph && g_unpack_later;       // (data parallel: a trunk layer's bucket leaves right behind its block)
+    e->unpack_later = !e->dp_on && g_unpack_later;       // (data parallel: a trunk layer's bucket leaves right behind its block)
     struct UnpackOff {
         ss_engine* e;
         ~UnpackOff() { e->unpack_later = false; }
@@ -2157,7 +2113,7 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
     // has to be done by the end of the step; the latter (decoder + head weight gradients, the encoder BLSTMs' weight gradients,
     // Encoder_t's whole backward) follow below, each ordered behind its producer by an event that was recorded when the producer
     // was enqueued.
-    const bool prio = par && g_prio_order && !g_graph && !e->l2.big() && !e->l1.big() && !e->lt.big();
+    const bool prio = par && g_prio_order && !e->l2.big() && !e->l1.big() && !e->lt.big();
     struct WgDefer {           // the small blocks' weight gradients of this backward: collected, launched once on b3 below (prio schedule)
         ss_engine* e;
         ~WgDefer() { e->wg_defer = false; e->wg.n = 0; e->wg.tiles_total = 0; }
@@ -2222,7 +2178,7 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
     // write disjoint columns of the shared slabs.  With g_trunk_bwd_par the pitch chain never leaves the stream lstm_2's backward ran on.
     // Data parallel: that stream carries the collectives, so the pitch chain takes the third branch stream instead (behind the event of lstm_2's
     // input gradient; Encoder_t's backward and the fused weight gradients queue behind it there).
-    const bool chain_par = g_trunk_bwd_par && training && g3 && par && !g_graph && (g_exp & 2) == 0 && g_gn_gather && (!e->dp_on || (prio && b3 != s && b3 != b2));
+    const bool chain_par = g_trunk_bwd_par && training && g3 && par && (g_exp & 2) == 0 && g_gn_gather && (!e->dp_on || (prio && b3 != s && b3 != b2));
     hipStream_t cs = e->dp_on ? b3 : b2;
     if (chain_par && e->dp_on) HIPCHK(hipStreamWaitEvent(b3, e->ev_join[0], 0));      // d_xf's pitch columns (lstm_2's input gradient) and the zeroed conv images
     // conv trunk, last layer first
@@ -2240,7 +2196,7 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
         float* dxbuf = training ? e->d_xf : e->d_act;
         // the resampled activations also exist as pre-split images when the forward's gathers wrote them (training, independent trunk chains)
         const float* bim = (training && e->xf_img_valid && i > 0) ? e->xf_img[i - 1] : nullptr;
-        if (!chain_par && i == 0 && g3 && par && !e->dp_on && !g_graph && (g_exp & 2) == 0) CHK(fork_join(e, s, b2));      // tail_par below: the pitch block's stream forks BEFORE the content block is enqueued
+        if (!chain_par && i == 0 && g3 && par && !e->dp_on && (g_exp & 2) == 0) CHK(fork_join(e, s, b2));      // tail_par below: the pitch block's stream forks BEFORE the content block is enqueued
         if (g3) {
             Slab x1 = i == 0 ? Slab{e->in_mel, h.dim_freq} : Slab{e->xf[i - 1], CE, bim, e->act_scale + e->c1[i - 1].scale_i};
             CHK(conv_block_bwd(e, e->c1[i], Slab{dy, CE}, x1, i > 0 ? Slab{dxbuf, CE} : Slab{nullptr, 0}, s, sc, sc_src, CE));
@@ -2249,7 +2205,7 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
         // Layer 0 is the step's tail: the decoder's weight gradients are through by then, and each of its two weight-gradient GEMMs alone
         // fills half the chip's workgroup slots -- the pitch block runs on the second branch stream beside the content block.  (Not under
         // data parallelism, where that stream carries the collectives.)
-        const bool tail_par = chain_par || (i == 0 && g3 && par && !e->dp_on && !g_graph && (g_exp & 2) == 0);
+        const bool tail_par = chain_par || (i == 0 && g3 && par && !e->dp_on && (g_exp & 2) == 0);
         hipStream_t s2 = tail_par ? (chain_par ? cs : b2) : s;
         CHK(conv_block_bwd(e, e->c2[i], Slab{dy + off2, CE}, x2, i > 0 ? Slab{dxbuf + off2, CE} : Slab{nullptr, 0}, s2, sc, sc_src + off2, CE));
         if (tail_par && (!chain_par || (i == 0 && !e->dp_on))) CHK(fork_join(e, b2, s));      // (chain_par: the two chains meet once, behind layer 0; data parallel: where the third branch stream joins below)
@@ -2289,7 +2245,7 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
 }
 
 int backward_core(ss_engine* e, hipStream_t s) {
-    CHK(backward_decoder(e, s, g_prio_order && !g_graph));
+    CHK(backward_decoder(e, s, g_prio_order));
     return backward_encoder(e, s);
 }
 
@@ -2364,7 +2320,6 @@ ss_engine* ss_create(int kind, const ss_hparams* hp, int max_batch, int max_fram
 
 void ss_destroy(ss_engine* e) {
     if (!e) return;
-    drop_graphs(e);
     if (e->comm) (void)ss_comm_destroy(e);
     if (e->sticky) {
         (void)hipDeviceSynchronize();
@@ -2389,15 +2344,13 @@ void ss_destroy(ss_engine* e) {
             (void)hipStreamSynchronize(e->main_s);
             (void)hipStreamDestroy(e->main_s);
         }
-        if (e->cap) {
-            (void)hipStreamSynchronize(e->cap);
+        {
             for (auto& ev : e->ev_io)
                 if (ev) (void)hipEventDestroy(ev);
             for (auto& ev : e->ev_dec)
                 if (ev) (void)hipEventDestroy(ev);
             for (auto& ev : e->ev_join)
                 if (ev) (void)hipEventDestroy(ev);
-            (void)hipStreamDestroy(e->cap);
         }
     }
     delete e;
@@ -2471,7 +2424,6 @@ int ss_bind(ss_engine* e, float* params, float* grads, float* m, float* v, void*
             e->stream_report = "branch streams as created (probe off)";
         }
         for (auto& ev : e->ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        HIPCHK(hipStreamCreateWithFlags(&e->cap, hipStreamNonBlocking));
         for (auto& ev : e->ev_io) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         for (auto& ev : e->ev_dec) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         for (auto& ev : e->ev_join) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -2637,11 +2589,6 @@ static int g3_step_body(ss_engine* e, const float* mel, const float* f0, const f
     // x_org and the speaker embedding are first read by Encoder_t / the decoder input: their copies ride on the branch stream
     e->late_org = mel;
     e->late_emb = emb;
-    if (g_graph) {      // hipGraph capture keeps round 1's branch structure: each extra parallel branch in the captured step made
-                        // hipGraphLaunch crash inside hip::Graph::UpdateStreams (ROCm 7.2) once the process had run other engines before
-        HIPCHK(copy_rows(mel, h.dim_freq, (long)T * h.dim_freq, e->org + HALO * h.dim_freq, h.dim_freq, TP * h.dim_freq, B, T, h.dim_freq, s));
-        HIPCHK(hipMemcpyAsync(e->emb, emb, (long)B * h.dim_spk_emb * 4, hipMemcpyDeviceToDevice, s));
-    }
     e->prezero = true;
     const int frc = forward_core(e, true, scales, len_seg, 1, s);                           // solver.py:165
     e->prezero = false;
@@ -2698,49 +2645,8 @@ int ss_g3_train_step(ss_engine* e, const float* mel, const float* f0, const floa
     const ss_hparams& h = e->hp;
     if (T != h.max_len_pad) return fail("training needs T == max_len_pad (model.py:105,157,370); pass SS_STEP_BUCKET for a length-bucketed batch");
     CHK(geometry(e, B, T, s));
-    if (e->graph_epoch != g_tune_epoch) {
-        drop_graphs(e);
-        e->graph_epoch = g_tune_epoch;
-    }
     flags &= ~SS_STEP_BUCKET;
-    if (!g_graph || (flags & SS_STEP_SPLIT_BACKWARD)) return g3_step_body(e, mel, f0, emb, len_org, scales, len_seg, B, T, grad_scale, flags, loss, s);
-
-    // stage the caller's inputs, then replay (or first capture) the step on engine-owned addresses.  All of it runs on
-    // the engine's capture stream, ordered after the caller's stream and before whatever the caller enqueues next.
-    hipStream_t c = own.on ? s : e->cap;                  // a created stream (a legacy default stream cannot capture)
-    if (!own.on) {
-        HIPCHK(hipEventRecord(e->ev_io[0], s));
-        HIPCHK(hipStreamWaitEvent(c, e->ev_io[0], 0));
-    }
-    const long S7 = e->plan[0].S;
-    HIPCHK(hipMemcpyAsync(e->stg_mel, mel, (long)B * T * h.dim_freq * 4, hipMemcpyDeviceToDevice, c));
-    HIPCHK(hipMemcpyAsync(e->stg_f0, f0, (long)B * T * 4, hipMemcpyDeviceToDevice, c));
-    HIPCHK(hipMemcpyAsync(e->stg_emb, emb, (long)B * h.dim_spk_emb * 4, hipMemcpyDeviceToDevice, c));
-    HIPCHK(hipMemcpyAsync(e->stg_len, len_org, (long)B * 4, hipMemcpyDeviceToDevice, c));
-    HIPCHK(hipMemcpyAsync(e->stg_sc, scales, 4L * B * S7 * 4, hipMemcpyDeviceToDevice, c));
-    HIPCHK(hipMemcpyAsync(e->stg_ls, len_seg, 4L * B * S7 * 4, hipMemcpyDeviceToDevice, c));
-    ss_engine::StepGraph* sg = nullptr;
-    for (auto& g : e->graphs)
-        if (g.B == B && g.T == T && g.flags == flags && g.gs == grad_scale) sg = &g;
-    if (!sg) {
-        ss_engine::StepGraph ng{B, T, flags, grad_scale, nullptr, nullptr};
-        HIPCHK(hipStreamBeginCapture(c, hipStreamCaptureModeRelaxed));
-        const int rc = g3_step_body(e, e->stg_mel, e->stg_f0, e->stg_emb, e->stg_len, e->stg_sc, e->stg_ls, B, T, grad_scale,
-                                    flags, e->stg_loss, c);
-        const hipError_t ce = hipStreamEndCapture(c, &ng.g);
-        if (rc != 0) return rc;
-        if (ce != hipSuccess) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
-        HIPCHK(hipGraphInstantiate(&ng.x, ng.g, nullptr, nullptr, 0));
-        e->graphs.push_back(ng);
-        sg = &e->graphs.back();
-    }
-    HIPCHK(hipGraphLaunch(sg->x, c));
-    if (loss) HIPCHK(hipMemcpyAsync(loss, e->stg_loss, 4, hipMemcpyDeviceToDevice, c));
-    if (!own.on) {
-        HIPCHK(hipEventRecord(e->ev_io[1], c));
-        HIPCHK(hipStreamWaitEvent(s, e->ev_io[1], 0));
-    }
-    return 0;
+    return g3_step_body(e, mel, f0, emb, len_org, scales, len_seg, B, T, grad_scale, flags, loss, s);
 }
 
 int ss_train_finish(ss_engine* e, float grad_scale, int flags, void* stream) {
@@ -2905,7 +2811,6 @@ int ss_op_gemm_img(const float* a_img, long lda, const float* b_img, long ldb, f
 int ss_set_precision(ss_engine* e, int precision) {
     if (!e) return fail("ss_set_precision: null engine");
     if (precision != SS_PRECISION_F32 && precision != SS_PRECISION_BF16) return fail("ss_set_precision: unknown precision");
-    if (e->precision != precision) drop_graphs(e);      // captured steps bake the kernel choice in
     e->precision = precision;
     return 0;
 }
@@ -3032,7 +2937,6 @@ int ss_tune(const char* key, int value) {
     else if (k == "small_prio" && (value == 0 || value == 1)) g_small_prio = value;
     else if (k == "gemm_tr" && value >= 0 && value <= 2) g_gemm_tr = value;
 #ifdef SS_DIAG
-    else if (k == "graph" && (value == 0 || value == 1)) g_graph = value;
 #endif
     else if (k == "own_streams" && (value == 0 || value == 1)) g_own_streams = value;
     else if (k == "early_join" && (value == 0 || value == 1)) g_early_join = value;
@@ -3063,7 +2967,6 @@ int ss_tune(const char* key, int value) {
                      + " (the wrong-result timing modes lstm_mode / gemm_diag / seq_prio > 1 exist only in the -DSS_DIAG build: make diag)"
 #endif
     );
-    ++g_tune_epoch;
     return 0;
 }
 

@@ -420,8 +420,8 @@ def test_fused_train_step_against_reference_fixture(E, tag):
 def test_fused_train_step_full_gradients(E, case):
     """Every element of all 86 gradients against the oracle's autograd.  The last field selects the decoder recurrence
     schedule: 1 = persistent kernels (default), 0 = one launch per time step.  (Round 2's third schedule -- the per-step launches
-    captured in a hipGraph -- left the product library in round 3: no gain, and a crash inside the runtime's graph launch; it
-    exists in the -DSS_DIAG build only.)"""
+    captured in a hipGraph -- left the product library in round 3 and the source in round 4: no gain, and a crash inside the
+    runtime's graph launch.)"""
     B, T, wseed, bseed, want_safe, sched = case
     E.tune('persist', 1 if sched == 1 else 0)
     try:

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Host-side cost of enqueuing one training step (no device sync in between) vs. the device time of the step."""
 import os, sys, time, torch
-os.environ.setdefault('SS_DIAG_LIB', '1')      # the hipGraph schedule exists only in the -DSS_DIAG build
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import weights as W
@@ -14,8 +13,7 @@ sc, ls = E.draw_interp(B, 4, hp)
 sc, ls = sc.cuda(), ls.cuda()
 eng = E.Engine('G3', hp, B, T)
 eng.load_weights(W.make_weights('G3', hp, 0))
-for graph in (0, 1):
-    E.tune('graph', graph)
+for rep in range(2):
     for _ in range(5):
         eng.g3_train_step(mel, f0, emb, lens, (sc, ls))
     torch.cuda.synchronize()
@@ -28,6 +26,5 @@ for graph in (0, 1):
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    print(f'graph={graph}: host enqueue per step: first {host[0] * 1e3:.2f} ms, median {sorted(host)[10] * 1e3:.2f} ms, last {host[-1] * 1e3:.2f} ms; '
+    print(f'run {rep}: host enqueue per step: first {host[0] * 1e3:.2f} ms, median {sorted(host)[10] * 1e3:.2f} ms, last {host[-1] * 1e3:.2f} ms; '
           f'enqueue of 20 steps {1e3 * (t1 - t0):.1f} ms, device done after {1e3 * (t2 - t0):.1f} ms ({1e3 * (t2 - t0) / 20:.2f} ms/step)', flush=True)
-E.tune('graph', 0)
