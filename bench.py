@@ -367,6 +367,18 @@ def main():
                        'world': world, 'rank': rank,
                        'buckets': [{'arena_offset': o, 'mbytes': round(c * 4 / 1e6, 2), 'start_us': round(a, 1), 'end_us': round(b, 1)} for o, c, a, b in rec],
                        'last_end_us': round(max(b for _, _, _, b in rec), 1)}
+    # data parallel: every rank saw different utterances, so the replicas' weights agree bit for bit only if every bucket was reduced over all
+    # ranks and the same update applied -- a 64-bit sum over the weights' bit patterns, gathered from all ranks (outside the timed region)
+    dp_rep = None
+    if dist is not None:
+        torch.cuda.synchronize()
+        mine = eng.params.view(torch.int32).to(torch.int64).sum().reshape(1)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        sums = [int(t) for t in every]
+        dp_rep = {'identical': all(v == sums[0] for v in sums), 'ranks': world, 'weights_bit_sum': sums[0]}
+        if not dp_rep['identical']:
+            print(f'[bench] rank {rank}: REPLICAS DIVERGED: per-rank sums of the weights bit patterns {sums}', file=sys.stderr, flush=True)
     ms = dt / args.steps * 1e3
     value = B * world / (dt / args.steps)
     mean_T = timed_frames[0] / max(1, args.steps) if stream is not None else T      # config 5: mean frames per batch over the timed batches only
@@ -432,7 +444,7 @@ def main():
                        'products': PRODUCTS[args.precision]},
             'step_tflops': round(3 * 2 * (MAC_PER_FRAME_G3 if kind == 'G3' else MAC_PER_FRAME_G6) * mean_T * B * world / (dt / args.steps) / 1e12, 2),
             'roofline': roof, 'kernel_classes': classes, 'recurrence': recur, 'alt_precisions': alt,
-            'solver_loop': sl, 'dp_collectives': dp_coll, 'scratch_fallbacks': fallbacks,
+            'solver_loop': sl, 'dp_collectives': dp_coll, 'dp_replicas': dp_rep, 'scratch_fallbacks': fallbacks,
             'cpu_baseline': None if args.no_cpu_baseline else cpu_baseline(T),
         }
         print(json.dumps(out), flush=True)

@@ -42,6 +42,7 @@ def test_bench_dp_path_under_torchrun(extra):
     assert out['scaling'] == ('strong' if '--global-batch' in extra else 'weak')
     if '--global-batch' in extra:
         assert out['config']['global_batch'] == 32
+    assert out['dp_replicas'] == {'identical': True, 'ranks': 1, 'weights_bit_sum': out['dp_replicas']['weights_bit_sum']}
     if '--dp-backend' not in extra:
         # the native RCCL path reports where each bucket's collective sat relative to the end of the backward (ss_dp_profile)
         dc = out['dp_collectives']
