@@ -326,6 +326,9 @@ int ss_set_precision(ss_engine* e, int precision);
 int ss_profile(ss_engine* e, unsigned class_mask);
 int ss_profile_sample(ss_engine* e, int every_nth_step);
 int ss_profile_read(ss_engine* e, int klass, int* launches, double* total_us, double* total_flops);
+/* The same brackets as a timeline: out[3 * i .. 3 * i + 2] = (class, start, end) of record i in enqueue order, microseconds relative to the
+ * first record's start; returns the number of records written (<= cap), negative on error.  (tools/real_timeline.py) */
+int ss_profile_timeline(ss_engine* e, double* out, int cap);
 /* timing experiment: with ss_tune("gemm_diag", 16) the 128x128 NT bf16x3 GEMM accumulates, for its first 64 workgroups, the
  * s_memtime ticks every wave spends per k-loop phase; out24 = [4 waves][split+store, barrier, load issue, fragments+MFMA,
  * barrier, k-tiles (wave 0 only)].  Synchronises the device. */

@@ -81,6 +81,7 @@ SYMBOLS = {
     'ss_dp_profile': (_i, [_vp, _i]),
     'ss_dp_profile_read': (_i, [_vp, C.POINTER(C.c_double), _i]),
     'ss_profile_read': (_i, [_vp, _i, C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    'ss_profile_timeline': (_i, [_vp, C.POINTER(C.c_double), _i]),
     'ss_debug_gemm_phases': (_i, [C.POINTER(C.c_ulonglong), _i]),
     'ss_debug_xcc_map': (_i, [_i, _i, _i, _i, _vp, _vp]),
     'ss_debug_img_wq': (_i, [C.POINTER(C.c_uint), _i]),

@@ -89,6 +89,19 @@ constexpr long IMG_WQ_BYTES = 16 + 16 * 1024;
 int g_part_splitk = 1;  // split-K weight gradients of the in-loop-split kernel through partial slabs + an ordered reduce instead of fp32 atomics
 int g_unpack_later = 1; // one-GPU step: the conv weight gradients' re-layouts in one launch at the end of the backward
 int g_gn_gather = 1;    // training forward of the independent trunk chains: GroupNorm + ReLU + resampling gather in one kernel (gn_relu_gather)
+int g_dec_tail_split = 2;   // one-GPU step: on the side stream alone the decoder's twelve weight-gradient GEMMs end ~450 us after every other stream
+                        // (tools/real_timeline.py).  Layer 0's and the head's leave it for 1: the pitch chain's stream (behind the chain), 2: the third
+                        // branch stream (in FRONT of its own work: they start with layer 2's), 3: the main stream (behind the trunk); 4-6 move layer 1
+                        // as well (4: -> third, 5: layer 1 -> third + layer 0 -> pitch stream, 6: layer 1 -> pitch stream + layer 0 -> third).
+                        // 64 x 128 fp32: 5.16 / 5.05 / 5.04 / 5.16 / 5.03 / 5.12 / 5.14 ms for 0..6; 16 x 128: 3.26 -> 3.21 with 2; the 16-bit mode does
+                        // not care.  Data parallel (layer 0 + head behind the pitch chain on the third stream): +2.5-4 %, not done.
+int g_early_dw = 0;     // 16-bit data path, B <= 48: decoder layer l + 1's weight gradients as work-queue image GEMMs on the XCDs the backward recurrence of
+                        // layer l leaves free (lstm_bwd), instead of beside the encoder backward at the end of the step.  Off: 2.99 -> 2.97 ms at
+                        // 32 x 128, 2.68 -> 2.67 at 16, 3.38 -> 3.35 at 48 (tools/real_timeline.py): a work-queue launch ends only when the workgroups
+                        // parked on the recurrence's XCDs have run, i.e. with the recurrence, so ONE launch fits a recurrence and the layer's second
+                        // one starts with the next recurrence (which it delays: 289 -> 357 us); the recurrence beside a launch stretches 283 -> 297 us;
+                        // and the end of the step barely moves, because the encoder backward there is a dependent chain (~700 us at B = 32), not
+                        // throughput the decoder's GEMMs were taking.
 int g_xcd_dw = 0;       // decoder W_ih gradients beside the backward recurrences on the XCDs they leave free (B <= 48), see ss_engine::wq_pool.
                         // Off: measured 4.16 vs 4.09 ms at 32 x 128, 3.57 vs 3.53 at 16 x 128 -- the GEMM does run on the free XCDs beside the
                         // recurrence, but each recurrence stretches by ~40 us (its operand fetches share HBM with the GEMM's streams), the image
@@ -242,6 +255,8 @@ struct ss_engine {
     bool wg_defer = false;                 // backward_encoder collects every small block's layers and flushes once at the end
     int wq_next = 0;
     static constexpr int WQ_SLOTS = 16;
+    int dec_w_done = 0;                    // bit l: ALL of decoder layer l's weight gradients went out beside a recurrence (early_dw)
+    bool wq_mode = false;                  // lstm_weight_grads: image GEMMs in the work-queue form
     int dec_ih_done = 0;                   // bit l: decoder layer l's W_ih gradient went out beside a recurrence (lstm_late_weights skips it)
     // Early Adam (one GPU, Adam inside the step): the decoder + head range of the arenas (80 % of the bytes) is updated on the side stream
     // right behind its last weight-gradient GEMM, beside the encoder backward (GEMM-bound, HBM mostly idle), instead of at the step's end
@@ -1416,6 +1431,7 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
         a.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM | (am ? GEMM_F16X2 : 0);
         a.amax_a = am;                              // gradient slab: measured scale; the layer input is O(1)
         a.ksplit = pick_ksplit(a.M, a.N, a.K);
+        a.queue = e->wq_mode ? 1 : 0;
         if (dimg && l > 0) {
             a.a_pre = dimg;
             a.a_pre_scale = dsc;
@@ -1440,6 +1456,7 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
         h.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM | (am ? GEMM_F16X2 : 0);
         h.amax_a = am;
         h.ksplit = pick_ksplit(h.M, h.N, h.K);
+        h.queue = e->wq_mode ? 1 : 0;
         PGEMM_ON(lb.big() ? SS_PROF_DEC_DW : SS_PROF_ENC_LSTM, h, ws);
         if (!bias_done) {
             double* cpart;
@@ -1616,6 +1633,11 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
     const bool xcd = persist && &lb == &e->ld && g_xcd_dw && e->side && g_overlap && (g_defer_dw || late_w) && !g_deterministic &&
                      lstm_seq_free_xcds(B, H) >= 2;
     bool xcd_split[4] = {false, false, false, false};
+    // 16-bit data path: the recurrence writes the gradient image itself and every weight-gradient GEMM of a layer is one image launch per
+    // operand pair, so the WHOLE layer above goes out beside this layer's recurrence (work-queue form: 144 KB workgroups, one per free CU)
+    const bool early16 = persist && &lb == &e->ld && g_early_dw && e->img16() && g_img && g_img_batch && e->side && g_overlap && (g_defer_dw || late_w) &&
+                         !g_deterministic && !e->dp_on && e->wq_pool && lstm_seq_free_xcds(B, H) >= 2 && lb.out_img_valid;
+    bool early_ready[4] = {false, false, false, false};
     for (int l = lb.L - 1; l >= 0; --l) {
         Slab xi = l == 0 ? x : Slab{lb.out[l - 1], 2L * H};
         Slab dxi = l == 0 ? dx : Slab{lb.dmid[l & 1], 2L * H};
@@ -1657,6 +1679,21 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
                 if (skip32) e->dg32_skipped |= 1 << l;
                 prof_end(e, pi, s);
                 if (pw) CHK(fork_join(e, e->side3, s));
+                if (early16) {
+                    if (l + 1 < lb.L && early_ready[l + 1]) {
+                        HIPCHK(seq_gate(lb.sync_b(l), B, H, e->side));          // dispatched once this recurrence's grid is resident
+                        e->wq_mode = true;
+                        const int rc = lstm_weight_grads(e, lb, l + 1, Slab{lb.out[l], 2L * H}, am ? e->amax + lb.amax0 + l + 1 : nullptr, true, e->side);
+                        e->wq_mode = false;
+                        CHK(rc);
+                        e->dec_w_done |= 1 << (l + 1);
+                    }
+                    if (l >= 1 && l < 3 && dg16 && bias_in_kernel && lb.out_img[l] && lb.out_img[l - 1] && e->wq_next + 2 <= ss_engine::WQ_SLOTS) {
+                        CHK(fork_join(e, s, e->side));        // layer l's slab and image are complete behind this point
+                        early_ready[l] = true;
+                        e->side_used = true;
+                    }
+                }
                 // XCD-aware weight gradients: this recurrence leaves XCDs free, the layer above is through -- its W_ih gradient runs beside it
                 if (xcd) {
                     if (l + 1 < lb.L && xcd_split[l + 1]) {
@@ -1726,6 +1763,7 @@ int lstm_late_weights(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t ws, int l_h
     const int H = lb.H;
     const bool persist = lb.big() && g_persist && lstm_seq_supported(e->curB, H);
     for (int l = l_hi < 0 ? lb.L - 1 : l_hi; l >= l_lo; --l) {       // layers l_hi .. l_lo (default: all, last first)
+        if (&lb == &e->ld && ((e->dec_w_done >> l) & 1)) continue;        // went out beside a recurrence (early_dw)
         Slab xi = l == 0 ? x : Slab{lb.out[l - 1], 2L * H};
         float* am = (persist && g_bwd_f16x2 && lb.amax0 >= 0) ? e->amax + lb.amax0 + l : nullptr;
         const bool bias_in_kernel = persist && !g_deterministic && lb.pd[l * 2].bhh == lb.pd[l * 2].bih + 4L * H && lb.pd[l * 2 + 1].bhh == lb.pd[l * 2 + 1].bih + 4L * H;
@@ -2031,6 +2069,7 @@ int backward_decoder(ss_engine* e, hipStream_t s, bool late = false) {
     hipStream_t b2 = par ? e->side2 : s;
     if (par) CHK(fork_join(e, s, b2));
     e->dec_ih_done = 0;
+    e->dec_w_done = 0;
     e->dg16_written = 0;
     e->dg32_skipped = 0;
     e->wq_next = 0;
@@ -2144,17 +2183,25 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
     else if (par) CHK(fork_join(e, b2, s));
     // backward_decoder(late): the decoder's (layers l_hi .. l_lo) and, with its layer 0, the head's weight gradients, behind the decoder chain
     int dec_next = e->dec_w_pending ? e->ld.L - 1 : -1;       // next decoder layer whose weight gradients are still to be enqueued
-    auto dec_late = [&](int l_lo) -> int {
+    hipStream_t dec_other[2] = {nullptr, nullptr};      // streams other than the side stream that carry decoder weight gradients (tail split)
+    auto dec_late = [&](int l_lo, hipStream_t ws = nullptr) -> int {
         if (dec_next < l_lo) return 0;
+        if (!ws) ws = e->side;
         if (dec_next == e->ld.L - 1) {
             if (g_exp & 1) CHK(fork_join(e, s, e->side));      // experiment: ... and behind the conv trunk's backward as well (the two chains run one after the other)
             HIPCHK(hipStreamWaitEvent(e->side, e->ev_join[1], 0));
         }
-        CHK(lstm_late_weights(e, e->ld, dec_compact(e) ? Slab{e->ld.xc, e->dec_in_dim} : Slab{e->dec_in, e->dec_in_dim}, e->side, dec_next, l_lo));
+        if (ws != e->side) {
+            if (dec_other[0] != ws && dec_other[1] != ws) dec_other[dec_other[0] ? 1 : 0] = ws;
+            HIPCHK(hipStreamWaitEvent(ws, e->ev_join[1], 0));
+        }
+        CHK(lstm_late_weights(e, e->ld, dec_compact(e) ? Slab{e->ld.xc, e->dec_in_dim} : Slab{e->dec_in, e->dec_in_dim}, ws, dec_next, l_lo));
         dec_next = l_lo - 1;
         if (l_lo == 0) {
-            CHK(head_weight_grads(e, e->side));
+            CHK(head_weight_grads(e, ws));
             e->dec_w_pending = false;
+            for (hipStream_t o : dec_other)
+                if (o) CHK(fork_join(e, o, e->side));      // one join for the end of the step; the early optimiser update below reads what they wrote
             if (e->adam_early && g_adam_early && !e->dp_on && e->Mm && e->Vv) {
                 // every persistent recurrence and the parameter guard ran before the event this stream waited for: the status word is final
                 const long from = ss_grad_split(e);
@@ -2220,6 +2267,18 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
         }
     }
     // ---- everything that only has to be finished by the end of the step
+    // (tail split: on the side stream alone the decoder's twelve weight-gradient GEMMs end ~450 us after every other stream -- its last layer and
+    // the head go behind a stream that ends early instead)
+    if (!e->dp_on && prio && chain_par && e->dec_w_pending && e->ld.L == 3 && g_dec_tail_split) {
+        const int m = g_dec_tail_split;
+        //                              m:        1        2        3    4        5        6
+        hipStream_t for_l1 = m == 4 || m == 5 ? b3 : (m == 6 ? b2 : nullptr);                    // layer 1 (nullptr: side stream)
+        hipStream_t for_l0 = m == 1 || m == 5 ? b2 : (m == 2 || m == 6 ? b3 : (m == 3 ? s : nullptr));   // layer 0 + head
+        CHK(dec_late(2));
+        CHK(dec_late(1, for_l1));
+        CHK(dec_late(0, for_l0));
+        if (for_l1 == b2 || for_l0 == b2) CHK(fork_join(e, b2, s));
+    }
     CHK(dec_late(0));
     if (prio) {
         HIPCHK(hipStreamWaitEvent(b3, e->ev_join[0], 0));                   // lstm_2's pre-activation gradients (and the zeroed conv images)
@@ -2852,6 +2911,23 @@ int ss_profile_read(ss_engine* e, int klass, int* launches, double* total_us, do
     return 0;
 }
 
+// The brackets of ss_profile as a timeline: per record (class, start, end) in microseconds relative to the first record's start event --
+// timestamps from the real run (no tracing tool slowing the host down), across the engine's streams.  3 doubles per record, enqueue order.
+int ss_profile_timeline(ss_engine* e, double* out, int cap) {
+    if (!e || !out || cap < 0) return fail("ss_profile_timeline: null argument");
+    const int n = e->prof_n < cap ? e->prof_n : cap;
+    for (int i = 0; i < n; ++i) {
+        if (hipEventSynchronize(e->prof_ev[2 * i + 1]) != hipSuccess) return fail("ss_profile_timeline: event sync failed");
+        float a = 0, b = 0;
+        if (hipEventElapsedTime(&a, e->prof_ev[0], e->prof_ev[2 * i]) != hipSuccess || hipEventElapsedTime(&b, e->prof_ev[0], e->prof_ev[2 * i + 1]) != hipSuccess)
+            return fail("ss_profile_timeline: elapsed time failed");
+        out[3 * i] = e->prof_rec[i].klass;
+        out[3 * i + 1] = a * 1e3;
+        out[3 * i + 2] = b * 1e3;
+    }
+    return n;
+}
+
 // Where do the workgroups of a launch go?  n_wg workgroups of `threads` threads and lds_bytes of LDS each record (XCC_ID register, HW_ID
 // register) in launch order; each then idles `hold_ticks` (100 MHz) so that the whole grid has to be resident at once.
 __global__ void xcc_map_kernel(unsigned* out, long long hold_ticks) {
@@ -2943,6 +3019,8 @@ int ss_tune(const char* key, int value) {
     else if (k == "conv_par" && (value == 0 || value == 1)) g_conv_par = value;
     else if (k == "exp" && value >= 0) g_exp = value;
     else if (k == "adam_early" && (value == 0 || value == 1)) g_adam_early = value;
+    else if (k == "dec_tail_split" && value >= 0 && value <= 6) g_dec_tail_split = value;
+    else if (k == "early_dw" && (value == 0 || value == 1)) g_early_dw = value;
     else if (k == "xcd_dw" && (value == 0 || value == 1)) g_xcd_dw = value;
     else if (k == "dp_emulate" && (value == 0 || value == 1)) g_dp_emulate = value;
     else if (k == "gn_gather" && (value == 0 || value == 1)) g_gn_gather = value;

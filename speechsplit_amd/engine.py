@@ -395,6 +395,14 @@ class Engine:
                 out[name] = (n.value, us.value, fl.value)
         return out
 
+    def profile_timeline(self, cap=8192):
+        """[(class name, start_us, end_us)] of the recorded brackets in enqueue order, relative to the first one's start (ss_profile_timeline)."""
+        buf = (C.c_double * (3 * cap))()
+        n = self.lib.ss_profile_timeline(self.h, buf, cap)
+        if n < 0:
+            _capi.check(n)
+        return [(self.PROF_CLASSES[int(buf[3 * i])], buf[3 * i + 1], buf[3 * i + 2]) for i in range(n)]
+
     def debug_buffer(self, name, B, T):
         """Real frames of an internal haloed slab as a [B, T, C] tensor (copy)."""
         p, rows, cols = C.c_void_p(), C.c_long(), C.c_long()
