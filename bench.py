@@ -132,7 +132,7 @@ def kernel_report(eng, steps, ms_step, precision, top, survey, T):
              'conv_fwd': 'gemm_img_kernel<64,64,.,.,NT> segmented-K: conv trunk forward (layer 0: gemm_bf16x3_kernel)',
              'conv_dw': 'gemm_bf16x3_kernel<.,.,TN> split-K: conv weight gradients',
              'conv_dx': 'gemm_img_kernel<64,64,.,.,NT> segmented-K: conv input gradients'}
-    traffic, traffic_source = None, None
+    traffic, traffic_source, alone = None, None, None
     # HBM bytes per launch: NOT measured in this run (a PMC pass needs rocprofv3 as the parent) -- from the separate rocprofv3 --pmc passes kept
     # under profiles/ (tools/pmc_summary.py), and ONLY while the kernel sources are the ones those counters were read from: the record
     # carries a hash of them, and a stale profile gives null instead of a number that no longer describes the kernel
@@ -151,6 +151,9 @@ def kernel_report(eng, steps, ms_step, precision, top, survey, T):
                     traffic_source = f'{path} is stale (GEMM kernel sources changed since its counters were read): traffic not reported'
                     break
                 traffic = sum(r['hbm_read_bytes'] + r['hbm_write_bytes'] for r in recs) / len(recs)
+                # the same launches ALONE on the chip (the profile's durations): `achieved` above is what a launch gets inside the step, where
+                # the class runs on two or three streams beside the encoder backward -- co-scheduling shortens the step and lengthens each launch
+                alone = [{'shape': r['shape'], 'us': round(r['us'], 1), 'tflops': round(r['tflops'], 1), 'frac': round(r['tflops'] / peak, 4)} for r in recs if not r['shape'].endswith('default)')]
                 traffic_source = f'{path} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gemm_pmc.py with the gfx950 correction; a profile figure of these kernel sources, not measured in this run)'
                 break
         except Exception:
@@ -162,7 +165,7 @@ def kernel_report(eng, steps, ms_step, precision, top, survey, T):
             'vs_fp32_mfma_peak': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'launches_timed': n,
             'flops_per_launch': round(fl / n), 'us_per_launch': round(us / n, 2),
             'share_of_bracketed_gpu_time': round(survey[0][top][1] / sum(v[1] for v in survey[0].values()), 3), 'traffic': traffic,
-            'traffic_source': traffic_source,
+            'traffic_source': traffic_source, 'alone_on_the_chip': alone,
             'flops_basis': 'algorithmic: reductions and stored rows over the B x T real frames (halo rows of the slabs not counted)'}
     recur = None
     if 'rec_fwd' in rec and 'rec_bwd' in rec:
