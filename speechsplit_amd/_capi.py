@@ -106,6 +106,11 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = h
+        # SS_TUNE="key=value,key=value": experiment knobs applied once at load (A/B runs of the tests and tools against a non-default schedule)
+        for kv in filter(None, os.environ.get('SS_TUNE', '').split(',')):
+            k, v = kv.split('=')
+            if h.ss_tune(k.strip().encode(), int(v)) != 0:
+                raise RuntimeError('speechsplit_amd: SS_TUNE: ' + h.ss_last_error().decode())
     return _lib
 
 

@@ -89,6 +89,13 @@ constexpr long IMG_WQ_BYTES = 16 + 16 * 1024;
 int g_part_splitk = 1;  // split-K weight gradients of the in-loop-split kernel through partial slabs + an ordered reduce instead of fp32 atomics
 int g_unpack_later = 1; // one-GPU step: the conv weight gradients' re-layouts in one launch at the end of the backward
 int g_gn_gather = 1;    // training forward of the independent trunk chains: GroupNorm + ReLU + resampling gather in one kernel (gn_relu_gather)
+int g_enc_t_first = 1;      // prio schedule, third branch stream: Encoder_t's backward chain (waits for dec_in_grad only) in FRONT of the encoder BLSTMs' weight
+                        // gradients, which then go out in ONE fused launch with Encoder_t's.  Generator_6 32 x 192 bf16 2.26 -> 2.23 ms, 16 x 128 3.20 -> 3.18,
+                        // headline unchanged
+int g_conv_dw_off = 1;      // Generator_6 (one trunk chain, the second branch stream idle behind lstm's backward): the conv blocks' weight-gradient GEMMs leave
+                        // the dependent chain gn backward -> input gradient -> next block for that stream; every block then keeps its own conv-output
+                        // gradient slab (d_act_l).  With enc_t_first: 2.26 -> 2.17 ms (bf16), 2.50 -> 2.47 (fp32).  Generator_3 has no idle stream there
+                        // (tools/real_timeline.py: its four streams end within ~100 us of each other)
 int g_dec_tail_split = 2;   // one-GPU step: on the side stream alone the decoder's twelve weight-gradient GEMMs end ~450 us after every other stream
                         // (tools/real_timeline.py).  Layer 0's and the head's leave it for 1: the pitch chain's stream (behind the chain), 2: the third
                         // branch stream (in FRONT of its own work: they start with layer 2's), 3: the main stream (behind the trunk); 4-6 move layer 1
@@ -290,6 +297,7 @@ struct ss_engine {
     float* dg_img[3] = {nullptr, nullptr, nullptr};       // decoder layers' pre-activation gradients [B, TP, 8H]
     int dg32_skipped = 0;                                 // ... bit l = and NOT the fp32 slab: gates[l] still holds the forward's activated gates (gemm_on refuses to read it)
     int dg16_written = 0;                                 // 16-bit data path: bit l = decoder layer l's backward recurrence wrote dg_img[l] (plain bf16) in this backward
+    float *d_act_l[2] = {nullptr, nullptr}, *d_img_l[2] = {nullptr, nullptr};      // conv-output gradients of trunk layers 1 and 2 when their weight gradients run off the chain (conv_dw_off)
     float *d_img = nullptr, *d_img_t = nullptr;           // conv-output gradients of the trunk [B, TP, CE] / Encoder_t [B, TP, dim_enc_2]
     float* gscale = nullptr;               // [16]
     float* act_scale = nullptr;            // [8] per conv block: scale of its output's fp16 x 2 split (act_scales, from the GroupNorm affine)
@@ -532,6 +540,10 @@ long ss_engine::carve(int B, int T, bool assign) {
     act = slab("enc.act", CE);
     d_act = slab("enc.d_act", CE);
     d_img = slab(nullptr, CE);
+    for (int i = 0; i < 2; ++i) {
+        d_act_l[i] = slab(nullptr, CE);
+        d_img_l[i] = slab(nullptr, CE);
+    }
     d_img_t = slab(nullptr, hp.dim_enc_2);
     gscale = (float*)take(16 * 4);
     act_scale = (float*)take(8 * 4);
@@ -1044,6 +1056,8 @@ int zero_conv_grads(ss_engine* e, hipStream_t s) {
 float* grad_img_of(ss_engine* e, const float* p, long R) {
     auto in = [&](const float* b, long cols) { return b && p >= b && p < b + R * cols; };
     if (in(e->d_act, e->CE)) return e->ioff(e->d_img, p - e->d_act);
+    for (int i = 0; i < 2; ++i)
+        if (in(e->d_act_l[i], e->CE)) return e->ioff(e->d_img_l[i], p - e->d_act_l[i]);
     if (in(e->d_xf, e->CE)) return e->ioff(e->d_img, p - e->d_xf);
     if (in(e->d_act_t, e->hp.dim_enc_2)) return e->ioff(e->d_img_t, p - e->d_act_t);
     return nullptr;
@@ -1089,8 +1103,10 @@ int conv_block_fwd(ss_engine* e, ConvBlk& cb, Slab x, Slab y, hipStream_t s, con
 // scatter / src (nullable): the block's output was resampled in the forward (training): src is the gradient of the RESAMPLED output (at its
 // first real row and this block's first column, row stride src_ld); the gather's adjoint is taken inside the GroupNorm backward, which
 // writes dy
+// dws (nullable): the weight-gradient GEMM goes to that stream behind an event, the chain on `s` does not wait for it -- the caller keeps dy
+// untouched until dws is joined
 int conv_block_bwd(ss_engine* e, ConvBlk& cb, Slab dy, Slab x, Slab dx, hipStream_t s, const InterpPlan* scatter = nullptr, const float* src = nullptr,
-                   long src_ld = 0) {
+                   long src_ld = 0, hipStream_t dws = nullptr) {
     const int B = e->curB, T = e->curT;
     const long TP = T + 2 * HALO, R = (long)B * TP;
     float* am = (g_bwd_f16x2 && cb.amax_i >= 0) ? e->amax + cb.amax_i : nullptr;
@@ -1133,7 +1149,9 @@ int conv_block_bwd(ss_engine* e, ConvBlk& cb, Slab dy, Slab x, Slab dx, hipStrea
 #ifdef SS_DIAG
     if (g_exp & 8) goto conv_dw_done;            // what-if timing run (WRONG gradients): without the conv weight-gradient GEMMs
 #endif
-    PGEMM_ON(SS_PROF_CONV_DW, d, s);
+    if (dws && dws != s) CHK(fork_join(e, s, dws));
+    else dws = s;
+    PGEMM_ON(SS_PROF_CONV_DW, d, dws);
 #ifdef SS_DIAG
 conv_dw_done:
 #endif
@@ -1141,7 +1159,7 @@ conv_dw_done:
     // one-GPU step collects the blocks and unpacks them all in one launch at the end of the backward (backward_encoder) instead of seven
     // small launches on the trunk's dependent chain
     if (e->unpack_later && e->unpack.n < CONV_UNPACK_MAX) e->unpack.t[e->unpack.n++] = {cb.gp, e->G + cb.w, cb.Co, cb.Ci, cb.Cp};
-    else HIPCHK(conv_unpack_grad(cb.gp, cb.Co, cb.Ci, cb.Cp, e->G + cb.w, s));
+    else HIPCHK(conv_unpack_grad(cb.gp, cb.Co, cb.Ci, cb.Cp, e->G + cb.w, dws));
     if (dx.p) {
         GemmDesc g{};
         g.A = {dy.p, dy.ld, TP * dy.ld, cb.Co, dy.ld};
@@ -2166,6 +2184,7 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
         if (!prio) CHK(fork_join(e, s, b3));
     }
     CHK(zero_conv_grads(e, b2));                   // long done when the first conv weight gradient starts (b2 joins s, b3 forks after)
+    if (prio && g_enc_t_first && b3 != b2) CHK(fork_join(e, b2, b3));      // Encoder_t's conv weight gradient accumulates into its zeroed image before b3 sees lstm_2's event
     if (par && !prio) CHK(fork_join(e, b2, b3));
     // encoder BLSTMs -> gradient of the last fused slab
     const bool early = par && !e->l2.big() && g_early_join;         // the join event of the lstm_2 branch is taken as soon as its last kernel is queued
@@ -2228,6 +2247,9 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
     const bool chain_par = g_trunk_bwd_par && training && g3 && par && (g_exp & 2) == 0 && g_gn_gather && (!e->dp_on || (prio && b3 != s && b3 != b2));
     hipStream_t cs = e->dp_on ? b3 : b2;
     if (chain_par && e->dp_on) HIPCHK(hipStreamWaitEvent(b3, e->ev_join[0], 0));      // d_xf's pitch columns (lstm_2's input gradient) and the zeroed conv images
+    // weight gradients off the dependent chain (g_conv_dw_off): Generator_6's single chain, the second branch stream is idle behind lstm's backward
+    const bool dw_off = g_conv_dw_off == 1 && training && !g3 && par && prio && !e->dp_on && g_gn_gather && e->unpack_later && b2 != s && e->d_act_l[0] && e->d_act_l[1];
+    hipStream_t dw_s = dw_off ? b2 : nullptr;
     // conv trunk, last layer first
     for (int i = 2; i >= 0; --i) {
         float* dy = e->d_xf;
@@ -2236,7 +2258,7 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
         const float* sc_src = e->d_xf + HALO * CE;
         if (training) {
             if (!sc) HIPCHK(interp_scatter(e->plan[e->enc_plan0 + i], e->d_xf + HALO * CE, CE, TP * CE, e->d_act + HALO * CE, CE, TP * CE, CE, B, s));
-            dy = e->d_act;
+            dy = (dw_off && i > 0) ? e->d_act_l[i - 1] : e->d_act;
         }
         // input gradients of layer i become d_xf (the gradient of xf[i-1]); dy is consumed before it is overwritten
         // only when dy != d_xf, so in eval mode the input gradient goes through d_act instead.
@@ -2254,7 +2276,7 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
         // data parallelism, where that stream carries the collectives.)
         const bool tail_par = chain_par || (i == 0 && g3 && par && !e->dp_on && (g_exp & 2) == 0);
         hipStream_t s2 = tail_par ? (chain_par ? cs : b2) : s;
-        CHK(conv_block_bwd(e, e->c2[i], Slab{dy + off2, CE}, x2, i > 0 ? Slab{dxbuf + off2, CE} : Slab{nullptr, 0}, s2, sc, sc_src + off2, CE));
+        CHK(conv_block_bwd(e, e->c2[i], Slab{dy + off2, CE}, x2, i > 0 ? Slab{dxbuf + off2, CE} : Slab{nullptr, 0}, s2, sc, sc_src + off2, CE, (dw_off && i > 0) ? dw_s : nullptr));
         if (tail_par && (!chain_par || (i == 0 && !e->dp_on))) CHK(fork_join(e, b2, s));      // (chain_par: the two chains meet once, behind layer 0; data parallel: where the third branch stream joins below)
         if (i > 0) {           // the two wide layers' parameters (weight, bias, GroupNorm affine: contiguous) are final; layer 0 rides the last bucket
             if (g3) CHK(dp_bucket(e, e->c1[i].w, e->c1[i].be + e->c1[i].Co - e->c1[i].w, s));
@@ -2281,20 +2303,33 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
     }
     CHK(dec_late(0));
     if (prio) {
-        HIPCHK(hipStreamWaitEvent(b3, e->ev_join[0], 0));                   // lstm_2's pre-activation gradients (and the zeroed conv images)
-        CHK(lstm_late_weights(e, e->l2, Slab{e->xf[2] + off2, CE, nullptr, e->act_scale + e->c2[2].scale_i}, b3));
-        if (g3) {
-            HIPCHK(hipStreamWaitEvent(b3, e->ev_join[3], 0));
-            CHK(lstm_late_weights(e, e->l1, Slab{e->xf[2], CE, nullptr, e->act_scale + e->c1[2].scale_i}, b3));
-        }
-        CHK(wgrad_flush(e, b3));                   // lstm_2 and both layers of lstm_1: one launch, beside the trunk's backward
+        // Encoder_t's backward first: its input (d_ot from dec_in_grad) is the earliest thing this stream waits for, and it is a dependent chain of
+        // five launches; the BLSTMs' weight gradients (all three blocks: ONE fused launch) only have to be done by the end of the step
         HIPCHK(hipStreamWaitEvent(b3, e->ev_join[2], 0));                   // d_ot from dec_in_grad
+        if (!g_enc_t_first) {
+            HIPCHK(hipStreamWaitEvent(b3, e->ev_join[0], 0));
+            CHK(lstm_late_weights(e, e->l2, Slab{e->xf[2] + off2, CE, nullptr, e->act_scale + e->c2[2].scale_i}, b3));
+            if (g3) {
+                HIPCHK(hipStreamWaitEvent(b3, e->ev_join[3], 0));
+                CHK(lstm_late_weights(e, e->l1, Slab{e->xf[2], CE, nullptr, e->act_scale + e->c1[2].scale_i}, b3));
+            }
+            CHK(wgrad_flush(e, b3));
+        }
         CHK(lstm_bwd(e, e->lt, e->d_ot, Slab{e->act_t, h.dim_enc_2, nullptr, e->act_scale + e->ct.scale_i}, Slab{e->d_act_t, h.dim_enc_2}, b3));
         CHK(conv_block_bwd(e, e->ct, Slab{e->d_act_t, h.dim_enc_2}, Slab{e->org, h.dim_freq}, Slab{nullptr, 0}, b3));
-        CHK(wgrad_flush(e, b3));                   // Encoder_t's BLSTM
+        if (g_enc_t_first) {
+            HIPCHK(hipStreamWaitEvent(b3, e->ev_join[0], 0));                   // lstm_2's pre-activation gradients (and the zeroed conv images)
+            CHK(lstm_late_weights(e, e->l2, Slab{e->xf[2] + off2, CE, nullptr, e->act_scale + e->c2[2].scale_i}, b3));
+            if (g3) {
+                HIPCHK(hipStreamWaitEvent(b3, e->ev_join[3], 0));
+                CHK(lstm_late_weights(e, e->l1, Slab{e->xf[2], CE, nullptr, e->act_scale + e->c1[2].scale_i}, b3));
+            }
+        }
+        CHK(wgrad_flush(e, b3));                   // Encoder_t's, lstm_2's and both layers of lstm_1's: one launch
         e->wg_defer = false;
     }
     if (par) CHK(fork_join(e, b3, s));
+    if (dw_off) CHK(fork_join(e, dw_s, s));
     CHK(join_side(e, s));
     if (e->unpack.n) {
         HIPCHK(conv_unpack_grads(e->unpack, s));
@@ -3019,6 +3054,8 @@ int ss_tune(const char* key, int value) {
     else if (k == "conv_par" && (value == 0 || value == 1)) g_conv_par = value;
     else if (k == "exp" && value >= 0) g_exp = value;
     else if (k == "adam_early" && (value == 0 || value == 1)) g_adam_early = value;
+    else if (k == "enc_t_first" && (value == 0 || value == 1)) g_enc_t_first = value;
+    else if (k == "conv_dw_off" && value >= 0 && value <= 3) g_conv_dw_off = value;
     else if (k == "dec_tail_split" && value >= 0 && value <= 6) g_dec_tail_split = value;
     else if (k == "early_dw" && (value == 0 || value == 1)) g_early_dw = value;
     else if (k == "xcd_dw" && (value == 0 || value == 1)) g_xcd_dw = value;
