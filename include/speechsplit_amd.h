@@ -267,7 +267,10 @@ int ss_debug_relu_mask(ss_engine* e, const char* block, float* mask_dev, void* s
  * activations), "compact0" 0|1 (decoder layer 0 on one row per block of repeated input frames), "trunk_indep" 0|1, "batch_dirs" 0..2,
  * "prewarm" 0..3 (streaming pre-read of a decoder layer's operand slabs on a side stream beside its
  * persistent recurrence: bit 1 forward, bit 0 backward), "op_time_major" 0|1 (ss_op_lstm_fwd / _bwd
- * read their slabs as [T+4,B,C]; persistent kernels only -- a layout experiment).  The timing experiments that produce WRONG results ("lstm_mode",
+ * read their slabs as [T+4,B,C]; persistent kernels only -- a layout experiment); schedule of the end of the backward (round 4,
+ * tools/real_timeline.py): "dec_tail_split" 0..6 (which stream takes the decoder's layer-0 / layer-1 and the head's weight gradients; default 2),
+ * "enc_t_first" 0|1, "conv_dw_off" 0|1 (Generator_6: conv weight gradients off the trunk's dependent chain), "early_dw" 0|1 (16-bit mode: a decoder
+ * layer's weight gradients beside the next backward recurrence, off).  The timing experiments that produce WRONG results ("lstm_mode",
  * "gemm_diag", "seq_prio" > 1) are compiled out of this library; `make -C speechsplit_amd/csrc diag` builds
  * libspeechsplit_hip_diag.so with them for tools/ (never loaded by the package unless SS_DIAG_LIB=1 is set). */
 int ss_tune(const char* key, int value);
