@@ -326,10 +326,16 @@ int ss_set_precision(ss_engine* e, int precision);
 #define SS_PROF_ENC_LSTM 9  /* encoder BLSTM projections / gradients (small GEMMs) */
 #define SS_PROF_HEAD 10     /* LinearNorm head forward / gradients */
 #define SS_PROF_CLASSES 11
+/* timeline-only classes (no flops; ss_profile_timeline / tools/real_timeline.py): the non-GEMM launches on the step's dependent chains */
+#define SS_PROF_ENC_REC 11  /* encoder BLSTM recurrences (one launch per layer and pass) */
+#define SS_PROF_GN 12       /* GroupNorm + ReLU forward / gather / backward */
+#define SS_PROF_WGRAD 13    /* fused encoder-BLSTM weight gradients */
+#define SS_PROF_ADAM 14     /* optimiser launches */
+#define SS_PROF_PREP 15     /* per-step weight re-layouts */
 int ss_profile(ss_engine* e, unsigned class_mask);
 int ss_profile_sample(ss_engine* e, int every_nth_step);
 int ss_profile_read(ss_engine* e, int klass, int* launches, double* total_us, double* total_flops);
-/* The same brackets as a timeline: out[3 * i .. 3 * i + 2] = (class, start, end) of record i in enqueue order, microseconds relative to the
+/* The same brackets as a timeline: out[3 * i .. 3 * i + 2] = (class + 100 x stream [0 main, 1 side, 2 / 3 branch streams], start, end) of record i in enqueue order, microseconds relative to the
  * first record's start; returns the number of records written (<= cap), negative on error.  (tools/real_timeline.py) */
 int ss_profile_timeline(ss_engine* e, double* out, int cap);
 /* timing experiment: with ss_tune("gemm_diag", 16) the 128x128 NT bf16x3 GEMM accumulates, for its first 64 workgroups, the

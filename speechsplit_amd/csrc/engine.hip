@@ -96,12 +96,16 @@ int g_conv_dw_off = 1;      // Generator_6 (one trunk chain, the second branch s
                         // the dependent chain gn backward -> input gradient -> next block for that stream; every block then keeps its own conv-output
                         // gradient slab (d_act_l).  With enc_t_first: 2.26 -> 2.17 ms (bf16), 2.50 -> 2.47 (fp32).  Generator_3 has no idle stream there
                         // (tools/real_timeline.py: its four streams end within ~100 us of each other)
-int g_dec_tail_split = 2;   // one-GPU step: on the side stream alone the decoder's twelve weight-gradient GEMMs end ~450 us after every other stream
+int g_dec_tail_split = 9;   // one-GPU step: on the side stream alone the decoder's twelve weight-gradient GEMMs end ~450 us after every other stream
                         // (tools/real_timeline.py).  Layer 0's and the head's leave it for 1: the pitch chain's stream (behind the chain), 2: the third
                         // branch stream (in FRONT of its own work: they start with layer 2's), 3: the main stream (behind the trunk); 4-6 move layer 1
-                        // as well (4: -> third, 5: layer 1 -> third + layer 0 -> pitch stream, 6: layer 1 -> pitch stream + layer 0 -> third).
-                        // 64 x 128 fp32: 5.16 / 5.05 / 5.04 / 5.16 / 5.03 / 5.12 / 5.14 ms for 0..6; 16 x 128: 3.26 -> 3.21 with 2; the 16-bit mode does
-                        // not care.  Data parallel (layer 0 + head behind the pitch chain on the third stream): +2.5-4 %, not done.
+                        // as well (4: -> third, 5: layer 1 -> third + layer 0 -> pitch stream, 6: layer 1 -> pitch stream + layer 0 -> third); 7-10: as
+                        // 2 plus single GEMMs of layer 1's reverse direction (7: dW_ih -> third, dW_hh -> pitch; 8: both -> third; 9: dW_hh -> third;
+                        // 10: 9 + layer 2's reverse dW_hh -> third).  64 x 128 fp32: 5.16 / 5.05 / 5.04 / 5.16 / 5.03 / 5.12 / 5.14 ms for 0..6;
+                        // 2 / 7 / 8 / 9 / 10 on another box: 5.07 / 5.06 / 5.07 / 5.01 / 5.01.  16 x 128: 3.26 -> 3.20 with 2 or 9; the 16-bit mode does
+                        // not care (its weight gradients are batched per layer and its end of step is a dependent chain).  With 9 all four streams end
+                        // within 200 us of each other under full contention.  Data parallel (layer 0 + head behind the pitch chain on the third
+                        // stream): +2.5-4 %, not done.
 int g_early_dw = 0;     // 16-bit data path, B <= 48: decoder layer l + 1's weight gradients as work-queue image GEMMs on the XCDs the backward recurrence of
                         // layer l leaves free (lstm_bwd), instead of beside the encoder backward at the end of the step.  Off: 2.99 -> 2.97 ms at
                         // 32 x 128, 2.68 -> 2.67 at 16, 3.38 -> 3.35 at 48 (tools/real_timeline.py): a work-queue launch ends only when the workgroups
@@ -263,6 +267,7 @@ struct ss_engine {
     int wq_next = 0;
     static constexpr int WQ_SLOTS = 16;
     int dec_w_done = 0;                    // bit l: ALL of decoder layer l's weight gradients went out beside a recurrence (early_dw)
+    hipStream_t dw_over[2] = {nullptr, nullptr};   // lstm_weight_grads, unbatched decoder path: the reverse direction's dW_ih / dW_hh go to these streams (tail split)
     bool wq_mode = false;                  // lstm_weight_grads: image GEMMs in the work-queue form
     int dec_ih_done = 0;                   // bit l: decoder layer l's W_ih gradient went out beside a recurrence (lstm_late_weights skips it)
     // Early Adam (one GPU, Adam inside the step): the decoder + head range of the arenas (80 % of the bytes) is updated on the side stream
@@ -332,6 +337,7 @@ struct ss_engine {
     struct ProfRec {
         int klass;
         double flops;
+        int stream;                       // 0 caller / main, 1 side, 2 second branch, 3 third branch, -1 other
     };
     std::vector<hipEvent_t> prof_ev;      // 2 per record, created on demand
     std::vector<ProfRec> prof_rec;
@@ -754,6 +760,9 @@ bool colsum_scratch(ss_engine* e, int cols, double** part, unsigned** ctr) {
     return true;
 }
 
+int prof_begin(ss_engine* e, int klass, hipStream_t st, double flops);
+void prof_end(ss_engine* e, int i, hipStream_t st);
+
 // launch the pending encoder-BLSTM weight-gradient tasks (one kernel for all of them) on `st`: everything they read must be complete in
 // st's order.  Scratch: partial tiles from the step's bump allocator, arrival counters from the column sums' ring.
 int wgrad_flush(ss_engine* e, hipStream_t st) {
@@ -771,7 +780,9 @@ int wgrad_flush(ss_engine* e, hipStream_t st) {
     if (e->colsum_next + w.tiles_total > ss_engine::COLSUM_CTRS) e->colsum_next = 0;
     w.ctr = e->colsum_ctr + e->colsum_next;
     e->colsum_next += w.tiles_total;
+    const int pa_ = prof_begin(e, SS_PROF_WGRAD, st, 0.0);
     const hipError_t rc = lstm_small_wgrad(w, st);
+    prof_end(e, pa_, st);
     w.n = 0;
     w.tiles_total = 0;
     HIPCHK(rc);
@@ -986,7 +997,7 @@ int prof_begin(ss_engine* e, int klass, hipStream_t st, double flops) {
         e->prof_ev.push_back(ev);
     }
     if ((int)e->prof_rec.size() <= i) e->prof_rec.resize(i + 1);
-    e->prof_rec[i] = {klass, flops};
+    e->prof_rec[i] = {klass, flops, st == e->side ? 1 : (st == e->side2 ? 2 : (st == e->side3 ? 3 : 0))};
     if (hipEventRecord(e->prof_ev[2 * i], st) != hipSuccess) return -1;
     e->prof_n = i + 1;
     return i;
@@ -1090,11 +1101,15 @@ int conv_block_fwd(ss_engine* e, ConvBlk& cb, Slab x, Slab y, hipStream_t s, con
     PGEMM_FWD_ON(SS_PROF_CONV_FWD, d, s);
     if (gather) {
         if (gather_ready) HIPCHK(hipStreamWaitEvent(s, gather_ready, 0));
+        { const int pa_ = prof_begin(e, SS_PROF_GN, s, 0.0);
         HIPCHK(gn_relu_gather(cb.cout, cb.Co, TP * cb.Co, gy, gy_ld, TP * gy_ld, gy_img, e->act_scale + cb.scale_i, e->P + cb.ga, e->P + cb.be, cb.stats,
                               *gather, B, T, cb.Co, s, e->img16()));
+        prof_end(e, pa_, s); }
         return 0;
     }
+    { const int pa_ = prof_begin(e, SS_PROF_GN, s, 0.0);
     HIPCHK(gn_relu_fwd(cb.cout, cb.Co, TP * cb.Co, y.p, y.ld, TP * y.ld, e->P + cb.ga, e->P + cb.be, cb.stats, B, T, cb.Co, s));
+    prof_end(e, pa_, s); }
     return 0;
 }
 
@@ -1114,8 +1129,10 @@ int conv_block_bwd(ss_engine* e, ConvBlk& cb, Slab dy, Slab x, Slab dx, hipStrea
     // 16-bit data path: the GroupNorm backward writes the gradient's bf16 image itself (the image's halo rows are zero since the geometry
     // was planned and nobody writes them); fp32 mode: a split_image pass with the scale gn_relu_bwd has just measured
     float* im16 = (i16 && g_img && cb.Co % 8 == 0 && dy.ld % 8 == 0) ? grad_img_of(e, dy.p, R) : nullptr;
+    { const int pa_ = prof_begin(e, SS_PROF_GN, s, 0.0);
     HIPCHK(gn_relu_bwd(cb.cout, cb.Co, TP * cb.Co, dy.p, dy.ld, TP * dy.ld, e->P + cb.ga, e->P + cb.be, cb.stats,
                        e->G + cb.ga, e->G + cb.be, e->G + cb.b, am, cb.part, B, T, cb.Co, s, scatter, src, src_ld, TP * src_ld, im16));
+    prof_end(e, pa_, s); }
     // the conv-output gradient as an image for the image GEMM (scale: the power of two for the maximum gn_relu_bwd has just measured)
     const float* dimg = im16;
     const float* dsc = nullptr;
@@ -1336,8 +1353,10 @@ int lstm_fwd(ss_engine* e, LstmBlk& lb, Slab x, hipStream_t s) {
             flatten_rows(d, B, T);
             PGEMM_FWD_ON(SS_PROF_ENC_LSTM, d, s);
         }
+        { const int pa_ = prof_begin(e, SS_PROF_ENC_REC, s, 0.0);
         HIPCHK(lstm_small_fwd(lb.gates[l], e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, lb.out[l], lb.csave[l], B, T, H,
                               s));
+        prof_end(e, pa_, s); }
     }
     return 0;
 }
@@ -1527,7 +1546,8 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
         a.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM | (am ? GEMM_F16X2 : 0);
         a.amax_a = am;                              // gradient slab: measured scale; the layer input is O(1)
         a.ksplit = pick_ksplit(a.M, a.N, a.K);
-        if (part != 2 || compact) PGEMM_ON(lb.big() ? SS_PROF_DEC_DW : SS_PROF_ENC_LSTM, a, ws);
+        hipStream_t wa = (dir == 1 && e->dw_over[0]) ? e->dw_over[0] : ws, wh = (dir == 1 && e->dw_over[1]) ? e->dw_over[1] : ws;
+        if (part != 2 || compact) PGEMM_ON(lb.big() ? SS_PROF_DEC_DW : SS_PROF_ENC_LSTM, a, wa);
         // dW_hh[n][k] = sum_r dG[r][n] * h_prev[r][k];  h_prev = out one row earlier (fwd) / later (reverse)
         GemmDesc h{};
         h.A = {dir == 0 ? dGd + 8L * H : dGd, 8L * H, 0, 0, 0};
@@ -1546,7 +1566,7 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
         h.flags = GEMM_TA | GEMM_TB | GEMM_ACCUM | (am ? GEMM_F16X2 : 0);
         h.amax_a = am;
         h.ksplit = pick_ksplit(h.M, h.N, h.K);
-        PGEMM_ON(lb.big() ? SS_PROF_DEC_DW : SS_PROF_ENC_LSTM, h, ws);
+        PGEMM_ON(lb.big() ? SS_PROF_DEC_DW : SS_PROF_ENC_LSTM, h, wh);
         if (!bias_done) {     // the persistent backward kernel accumulates both bias gradients itself
             double* cpart;
             unsigned* cctr;
@@ -1734,7 +1754,9 @@ int lstm_bwd(ss_engine* e, LstmBlk& lb, const float* d_top, Slab x, Slab dx, hip
                                          dcur + r0 * 2L * H, lb.csave[l] + r0 * 2L * H, lb.dc[c], ch[c].nb, T, H, st, ch[c].st));
                 }
         } else {
+            { const int pa_ = prof_begin(e, SS_PROF_ENC_REC, s, 0.0);
             HIPCHK(lstm_small_bwd(dG, e->P + lb.pd[l * 2].whh, e->P + lb.pd[l * 2 + 1].whh, dcur, lb.csave[l], B, T, H, s));
+            prof_end(e, pa_, s); }
         }
         // Decoder on the persistent kernels: its weight-gradient GEMMs are held back until the whole recurrence chain
         // (layer L-1 .. 0 and the input gradients between them) is through.  Co-scheduled they do not fill idle cycles:
@@ -1847,7 +1869,9 @@ int forward_core(ss_engine* e, bool training, const float* scales, const int* le
             const bool img = cb->img_ok();
             pt.t[pt.n++] = {e->P + cb->w, cb->wf, cb->wb, img ? cb->wf_img : nullptr, img ? cb->wb_img : nullptr, cb->Co, cb->Ci, cb->Cp};
         }
+        { const int pa_ = prof_begin(e, SS_PROF_PREP, s, 0.0);
         HIPCHK(conv_pack_many(pt, s));
+        prof_end(e, pa_, s); }
     } else {
         if (g3) CHK(conv_pack_all(e, e->c1[0], s));
         CHK(conv_pack_all(e, e->c2[0], s));
@@ -2203,9 +2227,20 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
     // backward_decoder(late): the decoder's (layers l_hi .. l_lo) and, with its layer 0, the head's weight gradients, behind the decoder chain
     int dec_next = e->dec_w_pending ? e->ld.L - 1 : -1;       // next decoder layer whose weight gradients are still to be enqueued
     hipStream_t dec_other[2] = {nullptr, nullptr};      // streams other than the side stream that carry decoder weight gradients (tail split)
-    auto dec_late = [&](int l_lo, hipStream_t ws = nullptr) -> int {
+    auto dec_late = [&](int l_lo, hipStream_t ws = nullptr, hipStream_t over_ih = nullptr, hipStream_t over_hh = nullptr) -> int {
         if (dec_next < l_lo) return 0;
         if (!ws) ws = e->side;
+        for (hipStream_t o : {over_ih, over_hh})
+            if (o && o != ws && o != e->side) {
+                if (dec_other[0] != o && dec_other[1] != o) dec_other[dec_other[0] ? 1 : 0] = o;
+                HIPCHK(hipStreamWaitEvent(o, e->ev_join[1], 0));
+            }
+        struct Over {
+            ss_engine* e;
+            ~Over() { e->dw_over[0] = e->dw_over[1] = nullptr; }
+        } over_scope{e};
+        e->dw_over[0] = over_ih;
+        e->dw_over[1] = over_hh;
         if (dec_next == e->ld.L - 1) {
             if (g_exp & 1) CHK(fork_join(e, s, e->side));      // experiment: ... and behind the conv trunk's backward as well (the two chains run one after the other)
             HIPCHK(hipStreamWaitEvent(e->side, e->ev_join[1], 0));
@@ -2226,7 +2261,9 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
                 const long from = ss_grad_split(e);
                 if (from % 4 == 0 && from < e->arena) {
                     HIPCHK(adam_prepare(e->adam, e->sticky, nullptr, e->side));
+                    { const int pa_ = prof_begin(e, SS_PROF_ADAM, e->side, 0.0);
                     HIPCHK(adam_range(e->P + from, e->G + from, e->Mm + from, e->Vv + from, e->arena - from, e->adam, e->adam_early_gs, e->side));
+                    prof_end(e, pa_, e->side); }
                     e->adam_early_from = from;
                 }
             }
@@ -2295,11 +2332,14 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
         const int m = g_dec_tail_split;
         //                              m:        1        2        3    4        5        6
         hipStream_t for_l1 = m == 4 || m == 5 ? b3 : (m == 6 ? b2 : nullptr);                    // layer 1 (nullptr: side stream)
-        hipStream_t for_l0 = m == 1 || m == 5 ? b2 : (m == 2 || m == 6 ? b3 : (m == 3 ? s : nullptr));   // layer 0 + head
-        CHK(dec_late(2));
-        CHK(dec_late(1, for_l1));
+        hipStream_t for_l0 = m == 1 || m == 5 ? b2 : (m == 2 || m == 6 || m >= 7 ? b3 : (m == 3 ? s : nullptr));   // layer 0 + head
+        // 7-9: as 2, and layer 1's reverse direction leaves the side stream as well: 7: dW_ih -> third, dW_hh -> pitch stream; 8: both -> third; 9: dW_hh -> third
+        hipStream_t l1_ih = m == 7 || m == 8 ? b3 : nullptr, l1_hh = m == 7 ? b2 : (m == 8 || m == 9 ? b3 : nullptr);
+        CHK(dec_late(2, nullptr, nullptr, m == 10 ? b3 : nullptr));      // 10: as 9, and layer 2's reverse dW_hh -> third as well
+        if (m == 10) l1_hh = b3;
+        CHK(dec_late(1, for_l1, l1_ih, l1_hh));
         CHK(dec_late(0, for_l0));
-        if (for_l1 == b2 || for_l0 == b2) CHK(fork_join(e, b2, s));
+        if (for_l1 == b2 || for_l0 == b2 || l1_hh == b2) CHK(fork_join(e, b2, s));
     }
     CHK(dec_late(0));
     if (prio) {
@@ -2553,10 +2593,14 @@ static int adam_enqueue(ss_engine* e, float grad_scale, hipStream_t s) {
     if (e->adam_early_from >= 0) {         // the decoder + head range went out beside the encoder backward (backward_encoder): the rest, same step state
         const long n = e->adam_early_from;
         e->adam_early_from = -1;
+        { const int pa_ = prof_begin(e, SS_PROF_ADAM, s, 0.0);
         HIPCHK(adam_range(e->P, e->G, e->Mm, e->Vv, n, e->adam, grad_scale, s));
+        prof_end(e, pa_, s); }
         return 0;
     }
+    { const int pa_ = prof_begin(e, SS_PROF_ADAM, s, 0.0);
     HIPCHK(adam_step(e->P, e->G, e->Mm, e->Vv, e->arena, e->adam, grad_scale, e->sticky, e->G + e->status_off, s));
+    prof_end(e, pa_, s); }
     return 0;
 }
 // a fused training step announces that Adam follows its backward inside the same call
@@ -2956,7 +3000,7 @@ int ss_profile_timeline(ss_engine* e, double* out, int cap) {
         float a = 0, b = 0;
         if (hipEventElapsedTime(&a, e->prof_ev[0], e->prof_ev[2 * i]) != hipSuccess || hipEventElapsedTime(&b, e->prof_ev[0], e->prof_ev[2 * i + 1]) != hipSuccess)
             return fail("ss_profile_timeline: elapsed time failed");
-        out[3 * i] = e->prof_rec[i].klass;
+        out[3 * i] = e->prof_rec[i].klass + 100 * e->prof_rec[i].stream;      // class + 100 x stream (0 main, 1 side, 2 / 3 branch streams)
         out[3 * i + 1] = a * 1e3;
         out[3 * i + 2] = b * 1e3;
     }
@@ -3056,7 +3100,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "adam_early" && (value == 0 || value == 1)) g_adam_early = value;
     else if (k == "enc_t_first" && (value == 0 || value == 1)) g_enc_t_first = value;
     else if (k == "conv_dw_off" && value >= 0 && value <= 3) g_conv_dw_off = value;
-    else if (k == "dec_tail_split" && value >= 0 && value <= 6) g_dec_tail_split = value;
+    else if (k == "dec_tail_split" && value >= 0 && value <= 10) g_dec_tail_split = value;
     else if (k == "early_dw" && (value == 0 || value == 1)) g_early_dw = value;
     else if (k == "xcd_dw" && (value == 0 || value == 1)) g_xcd_dw = value;
     else if (k == "dp_emulate" && (value == 0 || value == 1)) g_dp_emulate = value;

@@ -373,16 +373,21 @@ class Engine:
     PROF_CLASSES = ('dec_proj', 'dec_proj0', 'dec_dw', 'dec_dx', 'conv_fwd', 'conv_dw', 'conv_dx', 'rec_fwd', 'rec_bwd',
                     'enc_lstm', 'head')
 
+    PROF_TIMELINE = ('enc_rec', 'gn', 'wgrad', 'adam', 'prep')      # timeline-only classes (SS_PROF_ENC_REC ..): non-GEMM launches, no flops
+
     def profile(self, classes, every=1):
         """ss_profile: bracket the launches of the named classes (True: all; False / empty: stop) with hipEvents; starting
         clears the record.  every = n: only every n-th training step is bracketed (ss_profile_sample)."""
         _capi.check(self.lib.ss_profile_sample(self.h, int(every)))
+        names = self.PROF_CLASSES + self.PROF_TIMELINE
         if classes is True:
             mask = (1 << len(self.PROF_CLASSES)) - 1
+        elif classes == 'timeline':                  # every class including the timeline-only ones
+            mask = (1 << len(names)) - 1
         elif not classes:
             mask = 0
         else:
-            mask = sum(1 << self.PROF_CLASSES.index(c) for c in classes)
+            mask = sum(1 << names.index(c) for c in classes)
         _capi.check(self.lib.ss_profile(self.h, mask))
 
     def profile_read(self):
@@ -396,12 +401,14 @@ class Engine:
         return out
 
     def profile_timeline(self, cap=8192):
-        """[(class name, start_us, end_us)] of the recorded brackets in enqueue order, relative to the first one's start (ss_profile_timeline)."""
+        """[(class name, start_us, end_us, stream)] of the recorded brackets in enqueue order, relative to the first one's start
+        (ss_profile_timeline); stream: 0 main, 1 side, 2 / 3 the branch streams."""
         buf = (C.c_double * (3 * cap))()
         n = self.lib.ss_profile_timeline(self.h, buf, cap)
         if n < 0:
             _capi.check(n)
-        return [(self.PROF_CLASSES[int(buf[3 * i])], buf[3 * i + 1], buf[3 * i + 2]) for i in range(n)]
+        names = self.PROF_CLASSES + self.PROF_TIMELINE
+        return [(names[int(buf[3 * i]) % 100], buf[3 * i + 1], buf[3 * i + 2], int(buf[3 * i]) // 100) for i in range(n)]
 
     def debug_buffer(self, name, B, T):
         """Real frames of an internal haloed slab as a [B, T, C] tensor (copy)."""

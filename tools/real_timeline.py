@@ -47,7 +47,7 @@ for i in range(10):
 torch.cuda.synchronize()
 for i in range(3):
     one(draws[i])
-eng.profile(True)
+eng.profile('timeline')
 for i in range(3):
     one(draws[3 + i])
 torch.cuda.synchronize()
@@ -59,7 +59,8 @@ n = len(tl) // 3
 t0 = tl[n][1]
 print(f'# {"Generator_3" if kind == "G3" else "Generator_6"} {B} x {T} {prec}: second of three bracketed steps ({n} brackets per step; every bracket holds the next launch of its stream back by 4-8 us); '
       f'step period {tl[2 * n][1] - tl[n][1]:.0f} us')
-print('#  start_us    end_us    dur_us  class')
-for k, a, b in tl[n:2 * n]:
-    print(f'{a - t0:9.1f} {b - t0:9.1f} {b - a:9.1f}  {k}')
+print('#  start_us    end_us    dur_us  stream class')
+names = ('main', 'side', 'branch2', 'branch3')
+for k, a, b, st in tl[n:2 * n]:
+    print(f'{a - t0:9.1f} {b - t0:9.1f} {b - a:9.1f}  {names[st]:7s} {k}')
 print(f'{tl[2 * n][1] - t0:9.1f}  next step starts')
