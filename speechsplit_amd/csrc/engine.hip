@@ -104,8 +104,9 @@ int g_dec_tail_split = 9;   // one-GPU step: on the side stream alone the decode
                         // 10: 9 + layer 2's reverse dW_hh -> third).  64 x 128 fp32: 5.16 / 5.05 / 5.04 / 5.16 / 5.03 / 5.12 / 5.14 ms for 0..6;
                         // 2 / 7 / 8 / 9 / 10 on another box: 5.07 / 5.06 / 5.07 / 5.01 / 5.01.  16 x 128: 3.26 -> 3.20 with 2 or 9; the 16-bit mode does
                         // not care (its weight gradients are batched per layer and its end of step is a dependent chain).  With 9 all four streams end
-                        // within 200 us of each other under full contention.  Data parallel (layer 0 + head behind the pitch chain on the third
-                        // stream): +2.5-4 %, not done.
+                        // within 200 us of each other under full contention.  Data parallel: layer 0 + head behind the pitch chain on the third stream
+                        // +2.5-4 %; layer 0's forward direction + head at the very end of the third stream's and its reverse direction at the end of
+                        // the main stream's enqueue order: 5.245 -> 5.226 ms at 64 x 128, +3-5 % at B <= 32: not done.
 int g_early_dw = 0;     // 16-bit data path, B <= 48: decoder layer l + 1's weight gradients as work-queue image GEMMs on the XCDs the backward recurrence of
                         // layer l leaves free (lstm_bwd), instead of beside the encoder backward at the end of the step.  Off: 2.99 -> 2.97 ms at
                         // 32 x 128, 2.68 -> 2.67 at 16, 3.38 -> 3.35 at 48 (tools/real_timeline.py): a work-queue launch ends only when the workgroups
@@ -1578,7 +1579,8 @@ int lstm_weight_grads(ss_engine* e, LstmBlk& lb, int l, Slab xi, const float* am
         // collective keeps the communication stream busy 140 us earlier than a bucket per layer (modelled N = 8: the last collective ends
         // closer to the backward's end)
         if (&lb == &e->ld && e->dp_on && part == 0 && pd.bhh + 4L * H > pd.wih) {
-            CHK(dp_bucket(e, pd.wih, pd.bhh + 4L * H - pd.wih, ws));
+            if (wa != wh) return fail("internal: a direction's weight gradients on two streams under data parallelism");
+            CHK(dp_bucket(e, pd.wih, pd.bhh + 4L * H - pd.wih, wh));
             e->dp_dir_buckets = true;
         }
     }
@@ -2368,6 +2370,7 @@ int backward_encoder(ss_engine* e, hipStream_t s) {
         CHK(wgrad_flush(e, b3));                   // Encoder_t's, lstm_2's and both layers of lstm_1's: one launch
         e->wg_defer = false;
     }
+
     if (par) CHK(fork_join(e, b3, s));
     if (dw_off) CHK(fork_join(e, dw_s, s));
     CHK(join_side(e, s));

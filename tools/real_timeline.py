@@ -2,7 +2,7 @@
 """Timeline of one training step from the engine's own hipEvent brackets (ss_profile_timeline): where each GEMM / recurrence class really
 starts and ends when the host runs ahead of the device, without a tracing tool's host-side lag (rocprofv3 stretches a 3.0 ms step to 3.3 ms and
 moves launches that wait for the host).  Two consecutive steps are bracketed; the second step's first record marks the end of the first.
-usage: real_timeline.py [batch] [f32|bf16] [frames] [G3|G6] [key=value ...]"""
+usage: real_timeline.py [batch] [f32|bf16] [frames] [G3|G6] [dp] [key=value ...]   (dp: the data-parallel step with the engine's RCCL communicator at world 1)"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -35,8 +35,19 @@ if kind == 'G6':
     onehot, qidx = onehot.contiguous(), qidx.to(torch.int32).contiguous()
 
 
+dp = 'dp' in sys.argv[4:]
+if dp:
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    eng.comm_init(0, 1)
+
+
 def one(d):
-    if kind == 'G3':
+    if kind == 'G3' and dp:
+        eng.dp_train_step_native(mel, f0, emb, lens, d)
+    elif kind == 'G3':
         eng.g3_train_step(mel, f0, emb, lens, d)
     else:
         eng.g6_train_step(mel, onehot, qidx, d)
@@ -57,7 +68,7 @@ eng.profile(False)
 firsts = [i for i, r in enumerate(tl) if r[0] == tl[0][0] and (i == 0 or tl[i - 1][0] != tl[0][0])]
 n = len(tl) // 3
 t0 = tl[n][1]
-print(f'# {"Generator_3" if kind == "G3" else "Generator_6"} {B} x {T} {prec}: second of three bracketed steps ({n} brackets per step; every bracket holds the next launch of its stream back by 4-8 us); '
+print(f'# {"Generator_3" if kind == "G3" else "Generator_6"} {B} x {T} {prec}{" data-parallel step (world 1)" if dp else ""}: second of three bracketed steps ({n} brackets per step; every bracket holds the next launch of its stream back by 4-8 us); '
       f'step period {tl[2 * n][1] - tl[n][1]:.0f} us')
 print('#  start_us    end_us    dur_us  stream class')
 names = ('main', 'side', 'branch2', 'branch3')
