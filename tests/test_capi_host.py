@@ -255,3 +255,16 @@ def test_roofline_traffic_profile_matches_kernel_sources():
         'profiles/r04/gemm_pmc.json is stale: rerun tools/run_profiles.sh (the PMC passes) after changing gemm_*.hip / common.h'
     dw = [r for r in recs if r['class'] == 'dec_dw']
     assert dw and all(r['hbm_read_bytes'] > 0 and r['hbm_write_bytes'] > 0 for r in dw)
+
+
+def test_ss_tune_env_hook_applies_knobs_at_load():
+    """SS_TUNE="key=value,..." is applied once when the library is loaded (A/B runs of tests and tools); an unknown key is an error, not a silently
+    ignored typo.  (ss_tune only sets process-global knobs: no GPU needed.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = 'from speechsplit_amd import _capi; _capi.lib(); print("loaded")'
+    ok = subprocess.run([sys.executable, '-c', code], cwd=root, env=dict(os.environ, SS_TUNE='dec_tail_split=2, conv_dw_off=0'), capture_output=True, text=True)
+    assert ok.returncode == 0 and 'loaded' in ok.stdout, ok.stderr[-500:]
+    bad = subprocess.run([sys.executable, '-c', code], cwd=root, env=dict(os.environ, SS_TUNE='no_such_knob=1'), capture_output=True, text=True)
+    assert bad.returncode != 0 and 'SS_TUNE' in bad.stderr and 'unknown key' in bad.stderr

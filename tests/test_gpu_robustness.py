@@ -286,3 +286,49 @@ def test_fused_groupnorm_resampling_is_bit_identical(E):
         for n, g in res[0][2].items():
             assert torch.equal(g, res[2][2][n]), (kind, n, 'not reproducible')
             assert torch.equal(g, res[1][2][n]), (kind, n, float((g - res[1][2][n]).abs().max()), float(g.abs().max()))
+
+
+def test_profile_timeline_and_tail_split_placement(E):
+    """ss_profile_timeline: every bracket of a step with its class, its stream and its start / end relative to the step's first bracket
+    (tools/real_timeline.py).  Checked: the record is consistent with ss_profile_read (same launches, same summed durations), two steps
+    record the same launches, times are ordered within each stream, and the schedule it exists to show is the one that runs -- the
+    decoder's weight gradients go out on TWO streams (side + third branch stream: dec_tail_split), the trunk's on the main stream and
+    the pitch chain's stream; with dec_tail_split = 0 they are back on the side stream alone, with identical gradients."""
+    B, T = 16, 128
+    mel, f0, emb, lens = synth_batch(91, B, T, 64)
+    d = stack_draws(draws_for(92, B, 4))
+    eng = fresh(E, B, T)
+    for _ in range(2):
+        eng.g3_train_step(mel, f0, emb, lens, d, no_adam=True)
+    eng.profile('timeline')
+    for _ in range(2):
+        eng.g3_train_step(mel, f0, emb, lens, d, no_adam=True)
+    torch.cuda.synchronize()
+    tl = eng.profile_timeline()
+    rd = eng.profile_read()
+    eng.profile(False)
+    g_split = {n: t.clone() for n, t in eng.grad_views().items()}
+    assert len(tl) % 2 == 0 and len(tl) >= 100
+    n = len(tl) // 2
+    assert [(k, st) for k, _, _, st in tl[:n]] == [(k, st) for k, _, _, st in tl[n:]]          # same launches on the same streams in both steps
+    assert all(b >= a for _, a, b, _ in tl) and all(st in (0, 1, 2, 3) for *_, st in tl)
+    for st in range(4):                   # a stream executes in order: brackets of one stream do not overlap
+        ts = [(a, b) for _, a, b, s_ in tl if s_ == st]
+        assert all(ts[i + 1][0] >= ts[i][1] - 1.0 for i in range(len(ts) - 1)), st
+    for k, (launches, us, _) in rd.items():       # the GEMM / recurrence classes agree with ss_profile_read
+        mine = [b - a for kk, a, b, _ in tl if kk == k]
+        assert len(mine) == launches and abs(sum(mine) - us) <= 1e-3 * us + 1.0, k
+    on = lambda k: {st for kk, _, _, st in tl[:n] if kk == k}
+    assert on('dec_dw') == {1, 3} and on('rec_bwd') == {0} and on('conv_dx') == {0, 2}
+    assert {'enc_rec', 'gn', 'wgrad', 'prep'} <= {k for k, *_ in tl}
+    E.tune('dec_tail_split', 0)
+    try:
+        eng.profile('timeline')
+        eng.g3_train_step(mel, f0, emb, lens, d, no_adam=True)
+        torch.cuda.synchronize()
+        assert {st for k, _, _, st in eng.profile_timeline() if k == 'dec_dw'} == {1}
+        eng.profile(False)
+    finally:
+        E.tune('dec_tail_split', 9)
+    for name, g in eng.grad_views().items():
+        assert rel(g, g_split[name]) <= 2e-5, name          # same contractions on other streams (split-K sums in fp32 atomics: not bit-identical)
