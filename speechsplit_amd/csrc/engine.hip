@@ -31,6 +31,7 @@ int g_bwd_f16x2 = 1;   // 1: the decoder's and the conv trunk's gradient GEMMs a
                        //    of two its producer kernel measured (max |value| of the slab), the activation / weight operand by the fixed one
 int g_overlap = 1;     // 1: weight-gradient GEMMs on the side stream
 int g_dx_batched = 2;  // input-gradient GEMMs per utterance without halo rows; 2: with 128 x 128 tiles from 512 workgroups on
+int g_conv_small_old = 1;  // see try_img_gemm
 int g_conv_want = 256;    // experiment: workgroup target of the conv GEMMs' tile choice (0: library default)
 int g_defer_dw = 1;    // 1: the decoder's weight-gradient GEMMs start after its last input gradient (see lstm_bwd)
 int g_side_prio = 0;   // 1: create the side stream with the lowest priority (read at ss_bind).  Measured: 2.3x SLOWER
@@ -666,6 +667,9 @@ int try_img_gemm(ss_engine* e, const GemmDesc& d, hipStream_t st) {
     } else {
         if (!(d.flags & GEMM_F16X2) || (d.flags & GEMM_BF16)) return 0;
         if (g_cur_klass >= 0 && !((g_img_mask >> g_cur_klass) & 1) && !d.queue) return 0;
+        // conv trunk at B x T <= 2048 rows: the image kernel's smallest tile (128 x 128) gives a 512-channel layer 64 workgroups; round 2's kernel
+        // on 64 x 64 tiles fills the chip (16 x 128: 3.22 -> 3.18 ms; equal from 32 x 128 on and at 8 x 128)
+        if ((g_cur_klass == SS_PROF_CONV_FWD || g_cur_klass == SS_PROF_CONV_DX) && g_conv_small_old && (long)e->curB * e->curT <= 2048 && (long)e->curB * e->curT > 1024) return 0;
     }
     ImgGemmDesc g{};
     g.bf16 = b16 ? 1 : 0;
@@ -3091,6 +3095,7 @@ int ss_tune(const char* key, int value) {
     else if (k == "defer_dw" && (value == 0 || value == 1)) g_defer_dw = value;
     else if (k == "dx_batched" && value >= 0 && value <= 2) g_dx_batched = value;
     else if (k == "conv_want" && value >= 0) g_conv_want = value;
+    else if (k == "conv_small_old" && (value == 0 || value == 1)) g_conv_small_old = value;
     else if (k == "small_lds" && value >= 0 && value <= 2) g_small_lds = value;
     else if (k == "small_prio" && (value == 0 || value == 1)) g_small_prio = value;
     else if (k == "gemm_tr" && value >= 0 && value <= 2) g_gemm_tr = value;
