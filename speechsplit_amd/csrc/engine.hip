@@ -668,8 +668,8 @@ int try_img_gemm(ss_engine* e, const GemmDesc& d, hipStream_t st) {
         if (!(d.flags & GEMM_F16X2) || (d.flags & GEMM_BF16)) return 0;
         if (g_cur_klass >= 0 && !((g_img_mask >> g_cur_klass) & 1) && !d.queue) return 0;
         // conv trunk at B x T <= 2048 rows: the image kernel's smallest tile (128 x 128) gives a 512-channel layer 64 workgroups; round 2's kernel
-        // on 64 x 64 tiles fills the chip (16 x 128: 3.22 -> 3.18 ms; equal from 32 x 128 on and at 8 x 128)
-        if ((g_cur_klass == SS_PROF_CONV_FWD || g_cur_klass == SS_PROF_CONV_DX) && g_conv_small_old && (long)e->curB * e->curT <= 2048 && (long)e->curB * e->curT > 1024) return 0;
+        // on 64 x 64 tiles fills the chip (16 x 128: 3.22 -> 3.17 ms, 12 x 128: 3.08 -> 3.04; equal at 8 x 128 and from 32 x 128 on)
+        if ((g_cur_klass == SS_PROF_CONV_FWD || g_cur_klass == SS_PROF_CONV_DX) && g_conv_small_old && (long)e->curB * e->curT <= 2048) return 0;
     }
     ImgGemmDesc g{};
     g.bf16 = b16 ? 1 : 0;
