@@ -332,3 +332,35 @@ def test_profile_timeline_and_tail_split_placement(E):
         E.tune('dec_tail_split', 9)
     for name, g in eng.grad_views().items():
         assert rel(g, g_split[name]) <= 2e-5, name          # same contractions on other streams (split-K sums in fp32 atomics: not bit-identical)
+
+
+def test_early_dw_schedule_gives_the_same_gradients(E):
+    """ss_tune("early_dw", 1) (off by default: measured): in the 16-bit mode, where the backward recurrences leave XCDs
+    free (B <= 48), a decoder layer's weight gradients run as work-queue image GEMMs beside the next layer's recurrence.  Same contractions,
+    other split-K factor and stream: the gradients agree to the mode's own run-to-run spread (bf16 images of atomically summed slabs)."""
+    B, T = 32, 128
+    mel, f0, emb, lens = synth_batch(95, B, T, 64)
+    d = stack_draws(draws_for(96, B, 4))
+    eng = fresh(E, B, T)
+    eng.set_precision('bf16')
+    grads = []
+    try:
+        for knob in (0, 1, 0):
+            E.tune('early_dw', knob)
+            eng.profile('timeline')
+            loss = float(eng.g3_train_step(mel, f0, emb, lens, d, no_adam=True))
+            torch.cuda.synchronize()
+            eng.check()
+            tl = eng.profile_timeline()
+            eng.profile(False)
+            first_bwd = min(a for k, a, _, _ in tl if k == 'rec_bwd')
+            last_bwd = max(b for k, _, b, _ in tl if k == 'rec_bwd')
+            beside = [1 for k, a, _, _ in tl if k == 'dec_dw' and first_bwd < a < last_bwd - 50.0]
+            assert (len(beside) >= 2) == (knob == 1), (knob, len(beside))          # the schedule under test is the one that ran
+            grads.append((loss, {n: t.clone() for n, t in eng.grad_views().items()}))
+    finally:
+        E.tune('early_dw', 0)
+    assert abs(grads[0][0] - grads[1][0]) <= 1e-5 * abs(grads[0][0])
+    for name in grads[0][1]:
+        noise = rel(grads[2][1][name], grads[0][1][name])          # default schedule twice
+        assert rel(grads[1][1][name], grads[0][1][name]) <= max(3.0 * noise, 2e-3), name
