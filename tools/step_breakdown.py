@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Summarise one training step from a rocprofv3 --kernel-trace CSV: per-kernel totals, stream overlap, busy time."""
+"""Summarise one training step from a rocprofv3 --kernel-trace CSV: per-kernel totals, stream overlap, busy time.
+usage: step_breakdown.py <kernel_trace.csv> [rows] [label of the traced configuration]"""
 import collections, csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
@@ -21,7 +22,10 @@ for a, b in ivals:
         cur_e = max(cur_e, b)
 busy += cur_e - cur_s
 tot = sum(b - a for a, b in ivals)
-print(f'# one Generator_3 training step (B=64, T=128, fp32): wall {(t1 - t0) / 1e3:.1f} us, GPU busy (union of kernels) {busy / 1e3:.1f} us, '
+extra = sys.argv[2:]
+label = next((a for a in extra if not a.isdigit()), 'Generator_3 training step (B=64, T=128, fp32)')
+limit = next((int(a) for a in extra if a.isdigit()), 1000)
+print(f'# one {label}: wall {(t1 - t0) / 1e3:.1f} us, GPU busy (union of kernels) {busy / 1e3:.1f} us, '
       f'sum of kernel durations {tot / 1e3:.1f} us, {len(step)} dispatches')
 agg = collections.OrderedDict()
 for r in step:
@@ -29,5 +33,5 @@ for r in step:
     key = (nm, int(r['Grid_Size_X']) // int(r['Workgroup_Size_X']), r['Grid_Size_Y'], r['Grid_Size_Z'])
     agg.setdefault(key, []).append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 print(f"{'kernel':58s} {'grid(blocks)':>14s} {'calls':>5s} {'total_us':>10s} {'avg_us':>9s}")
-for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:int(sys.argv[2]) if len(sys.argv) > 2 else 1000]:
+for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:limit]:
     print(f"{k[0][:58]:58s} {str(k[1]) + 'x' + k[2] + 'x' + k[3]:>14s} {len(v):5d} {sum(v):10.1f} {sum(v) / len(v):9.1f}")
