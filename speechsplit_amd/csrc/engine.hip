@@ -718,6 +718,10 @@ int try_img_gemm(ss_engine* e, const GemmDesc& d, hipStream_t st) {
     auto wgs = [&](int bm, int bn) { return (long)cdiv(g.M, bm) * cdiv(g.N, bn) * g.batch; };
     if (d.ksplit > 1 && !g.row_period) {
         g.cfg = (g.M >= 256 && g.N >= 128) ? 2 : 1;
+        // 16-bit mode: 128 x 128 tiles (64 KB of LDS, two workgroups per CU).  The 256 x 128 form is 147 KB: one workgroup per CU, so the trunk's
+        // weight-gradient GEMMs on the dependent chain queue for CUs behind the decoder's on the side streams (real_timeline: 147 us for a 32-us
+        // launch).  32 x 128: 2.96 -> 2.91 ms, 64 x 128: 3.75 -> 3.69; the work-queue form keeps one workgroup per CU by design
+        if (b16 && !d.queue) g.cfg = 1;
         if (g_img_dw_cfg >= 0) g.cfg = g_img_dw_cfg;
         const long t = (g.cfg == 2 || g.cfg == 3) ? wgs(256, 128) : (g.cfg == 0 ? wgs(256, 256) : wgs(128, 128));
         long ks = ((d.queue ? 2 * g_img_dw_wgs : g_img_dw_wgs) + t / 2) / (t > 0 ? t : 1);       // work-queue form: twice the tiles (finer hand-over when the recurrence beside it ends)
